@@ -1,0 +1,17 @@
+"""gconv_adapter_amd — MI355X-native GConv-Adapter hot path.
+
+The directory is called ``gconv-adapter_amd`` (not importable as written); the
+repo-root module ``gconv_adapter_amd.py`` aliases it, so
+``_target_: gconv_adapter_amd.GConvAdapter`` works in the reference's Hydra config.
+"""
+from .adapter import GConvAdapter, GCNConvParams
+from .functional import GConvAdapterFunction, gconv_adapter, spmm, gemm_down, gemm_up_fused
+from .graph import GraphPlan, PlanCache, PLAN_CACHE, get_plan
+from .hydra_compat import instantiate, load_finetune_config
+from . import synth, dist, _lib
+
+__all__ = [
+    "GConvAdapter", "GCNConvParams", "GConvAdapterFunction", "gconv_adapter", "spmm",
+    "gemm_down", "gemm_up_fused", "GraphPlan", "PlanCache", "PLAN_CACHE", "get_plan",
+    "instantiate", "load_finetune_config", "synth", "dist",
+]

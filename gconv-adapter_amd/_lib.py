@@ -1,0 +1,131 @@
+"""ctypes binding of ``libgconv_adapter.so`` (the C ABI in ``include/gconv_adapter.h``).
+
+There is no CPU compute path in this package: if the HIP library is missing or
+cannot be loaded, every entry point raises ``RuntimeError`` — loudly, so a GPU
+run can never pass on a silent fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgconv_adapter.so")
+
+ACT_CODES = {"none": 0, "relu": 1, "silu": 2}
+SPMM_IN_PRESCALED = 1
+SPMM_OUT_PRESCALE = 2
+LONG_ROW = 64
+SEG_EDGES = 128
+
+_i32p = C.POINTER(C.c_int32)
+
+
+class CsrStruct(C.Structure):
+    """``gconv_csr_t``"""
+    _fields_ = [
+        ("num_nodes", C.c_int32),
+        ("nnz", C.c_int32),
+        ("rowptr", C.c_void_p),
+        ("col", C.c_void_p),
+        ("n_long", C.c_int32),
+        ("n_seg", C.c_int32),
+        ("long_rows", C.c_void_p),
+        ("long_seg_base", C.c_void_p),
+        ("seg_long", C.c_void_p),
+    ]
+
+
+class GraphInfo(C.Structure):
+    """``gconv_graph_info_t``"""
+    _fields_ = [
+        ("nnz", C.c_int32),
+        ("n_long", C.c_int32),
+        ("n_seg", C.c_int32),
+        ("max_degree", C.c_int32),
+        ("bad_index", C.c_int32),
+        ("reserved", C.c_int32 * 3),
+    ]
+
+
+class AdapterParams(C.Structure):
+    """``gconv_adapter_params_t``"""
+    _fields_ = [
+        ("w_down", C.c_void_p),
+        ("b_down", C.c_void_p),
+        ("w_up", C.c_void_p),
+        ("b_up", C.c_void_p),
+        ("scalar", C.c_void_p),
+        ("hidden", C.c_int32),
+        ("rank", C.c_int32),
+        ("act", C.c_int32),
+        ("skip", C.c_int32),
+    ]
+
+
+_vp, _sz, _i32, _i64, _u32 = C.c_void_p, C.c_size_t, C.c_int32, C.c_int64, C.c_uint32
+_csr_p = C.POINTER(CsrStruct)
+
+#: name -> (restype, argtypes); must list every function declared in include/gconv_adapter.h
+SIGNATURES = {
+    "gconv_abi_version": (_i32, []),
+    "gconv_status_string": (C.c_char_p, [_i32]),
+    "gconv_padded_rank": (_i32, [_i32]),
+    "gconv_graph_max_long_rows": (_i64, [_i64]),
+    "gconv_graph_max_segments": (_i64, [_i64]),
+    "gconv_graph_prep_workspace_bytes": (_sz, [_i64, _i32]),
+    "gconv_graph_prep": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _vp, _sz, C.POINTER(GraphInfo), _vp]),
+    "gconv_csr_equal": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32p, _vp]),
+    "gconv_spmm_workspace_bytes": (_sz, [_csr_p, _i32]),
+    "gconv_spmm_csr_f32": (_i32, [_csr_p, _vp, _vp, _vp, _i32, _vp, _i32, _u32, _vp, _sz, _vp]),
+    "gconv_gemm_down_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "gconv_gemm_up_fused_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
+    "gconv_adapter_fwd_workspace_bytes": (_sz, [_csr_p, _i32, _i32]),
+    "gconv_adapter_bwd_workspace_bytes": (_sz, [_csr_p, _i32, _i32]),
+    "gconv_adapter_fwd_f32": (_i32, [_csr_p, _vp, C.POINTER(AdapterParams), _vp, _vp, _vp, _vp,
+                                     _vp, _vp, _sz, _vp]),
+    "gconv_adapter_bwd_f32": (_i32, [_csr_p, _vp, C.POINTER(AdapterParams), _vp, _vp, _vp, _vp,
+                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Loads the HIP library (once). Raises RuntimeError if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"gconv_adapter_amd: HIP library not built ({LIB_PATH} is missing). Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` in the repo root; "
+            "there is no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as exc:  # pragma: no cover - depends on the host
+        raise RuntimeError(f"gconv_adapter_amd: cannot load {LIB_PATH}: {exc}") from exc
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.gconv_abi_version() != 1:
+        raise RuntimeError("gconv_adapter_amd: ABI version mismatch, rebuild the library")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    """Maps a non-zero ``gconv_status_t`` to RuntimeError (the exception type the
+    reference's train/eval loops catch and skip on:
+    ``scripts/finetune_inductive_learning.py:51-53,109-111``)."""
+    if status != 0:
+        msg = load().gconv_status_string(status).decode()
+        raise RuntimeError(f"gconv_adapter_amd.{what} failed: {msg} (status {status})")
+
+
+def ptr(t) -> Optional[int]:
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

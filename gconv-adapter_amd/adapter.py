@@ -1,0 +1,160 @@
+"""``GConvAdapter`` — drop-in ``nn.Module`` surface of the reference adapter.
+
+Mirrors ``/root/reference/src/finetune/gconv_adapter.py``:
+  * constructor kwargs, defaults and ``ValueError`` messages      (``:23-61``)
+  * parameter names / shapes, hence ``state_dict`` keys           (``:40-41,65``)
+        conv_down.lin.weight [r, d]   conv_down.bias [r]
+        conv_up.lin.weight   [d, r]   conv_up.bias   [d]
+        scalar [1] (only with learnable_scalar)   normalization.* (optional)
+  * near-identity init: W ~ N(0, 1e-5), biases 0, scalar 1        (``:65,73-78``)
+  * ``forward(x, edge_index, edge_attr=None) -> Tensor[x.shape]``  (``:80-108``);
+    ``edge_attr`` is accepted and ignored, ``x`` may be ``[N, d]`` or ``[1, N, d]``.
+
+The arithmetic is NOT torch: forward and backward run in the hand-written HIP
+library through ``functional.GConvAdapterFunction``. There is no CPU path.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .functional import gconv_adapter
+from .graph import get_plan
+
+
+class GCNConvParams(nn.Module):
+    """Parameter holder with PyG ``GCNConv``'s attribute layout (``.lin.weight``
+    ``[out, in]`` bias-free, ``.bias`` ``[out]``) so that state_dict keys and the
+    reference's init code (``gconv_adapter.py:73-78``) line up. It has no forward:
+    the propagation is fused into the adapter kernels."""
+
+    def __init__(self, in_channels: int, out_channels: int, normalize: bool = True):
+        super().__init__()
+        self.in_channels, self.out_channels, self.normalize = in_channels, out_channels, normalize
+        self.lin = nn.Linear(in_channels, out_channels, bias=False)
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+
+    def extra_repr(self) -> str:
+        return f"{self.in_channels}, {self.out_channels}, normalize={self.normalize}"
+
+
+class GConvAdapter(nn.Module):
+    """
+    GConv-Adapter (MI355X-native).
+
+    Args:
+        hidden_size (int): Size of the hidden layer.
+        bottleneck_size (int): Size of the bottleneck layer.
+        conv_type (str): Type of graph convolution. Only 'gcn' is implemented; the
+            reference's 'sage' / 'gat' branches cannot be constructed there either
+             and raise NotImplementedError here.
+        non_linearity (str): 'relu', 'silu' or 'none'.
+        normalization (str): 'batch_norm', 'layer_norm' or 'none'.
+        learnable_scalar (bool): Multiply the output by a learnable scalar.
+        skip_connection (bool): Add the input to the output.
+        normalize (bool): Add self-loops and apply symmetric normalization.
+
+    Raises:
+        ValueError: If an invalid conv_type, non_linearity, or normalization is provided.
+    """
+
+    def __init__(self, hidden_size: int, bottleneck_size: int,
+                 conv_type: str = 'gcn', non_linearity: str = 'relu',
+                 normalization: str = 'none', learnable_scalar: bool = False,
+                 skip_connection: bool = True, normalize: bool = True):
+        super().__init__()
+        if conv_type == 'gcn':
+            pass
+        elif conv_type in ('sage', 'gat'):
+            raise NotImplementedError(
+                f"conv_type='{conv_type}' is dead code in the reference "
+                "(gconv_adapter.py:32-35,40,73-78 cannot construct it); only 'gcn' is built.")
+        else:
+            raise ValueError("Invalid conv_type. Supported types: 'gcn', 'sage', 'gat'.")
+
+        self.hidden_size, self.bottleneck_size = int(hidden_size), int(bottleneck_size)
+        self.normalize = bool(normalize)
+        self.conv_down = GCNConvParams(self.hidden_size, self.bottleneck_size, self.normalize)
+        self.conv_up = GCNConvParams(self.bottleneck_size, self.hidden_size, self.normalize)
+
+        if non_linearity == 'relu':
+            self.act_fn = nn.ReLU()
+        elif non_linearity == 'silu':
+            self.act_fn = nn.SiLU()
+        elif non_linearity == 'none':
+            self.act_fn = nn.Identity()
+        else:
+            raise ValueError("Invalid non_linearity. Supported types: 'relu', 'silu', 'none'.")
+        self.non_linearity = non_linearity
+
+        if normalization == 'batch_norm':
+            self.normalization = nn.BatchNorm1d(self.hidden_size)
+        elif normalization == 'layer_norm':
+            self.normalization = nn.LayerNorm(self.hidden_size)
+        elif normalization == 'none':
+            self.normalization = None
+        else:
+            raise ValueError("Invalid normalization. Supported types: 'batch_norm', 'layer_norm', 'none'.")
+
+        if learnable_scalar:
+            self.scalar = nn.Parameter(torch.ones(1))
+        else:
+            self.scalar = None
+        self.skip_connection = skip_connection
+
+        # near-identity init (reference :73-78)
+        nn.init.normal_(self.conv_down.lin.weight, mean=0.0, std=1e-5)
+        nn.init.zeros_(self.conv_down.bias)
+        nn.init.normal_(self.conv_up.lin.weight, mean=0.0, std=1e-5)
+        nn.init.zeros_(self.conv_up.bias)
+
+    def _forward_2d(self, x2d: torch.Tensor, edge_index: torch.Tensor, fuse_scalar: bool) -> torch.Tensor:
+        plan = get_plan(edge_index, x2d.size(0), self.normalize)
+        return gconv_adapter(x2d, plan,
+                             self.conv_down.lin.weight, self.conv_down.bias,
+                             self.conv_up.lin.weight, self.conv_up.bias,
+                             self.scalar if fuse_scalar else None,
+                             act=self.non_linearity, skip=self.skip_connection)
+
+    def forward(self, x: torch.Tensor, edge_index: torch.Tensor,
+                edge_attr: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """
+        Args:
+            x: ``[N, hidden]`` or ``[B, N, hidden]`` (the reference passes B = 1).
+            edge_index: int64 ``[2, num_edges]``, row 0 = source, row 1 = target.
+            edge_attr: accepted for interface parity, ignored (as in the reference).
+        Returns:
+            Tensor of the same shape as ``x``.
+        """
+        if not x.is_cuda:
+            raise RuntimeError("gconv_adapter_amd.GConvAdapter has no CPU path: move the module and "
+                               "its inputs to a HIP device (x is on %s)" % x.device)
+        if x.dim() not in (2, 3) or x.size(-1) != self.hidden_size:
+            raise RuntimeError(f"x must be [N, {self.hidden_size}] or [B, N, {self.hidden_size}], "
+                               f"got {tuple(x.shape)}")
+        # the scalar is fused into the kernel epilogue unless a normalization layer sits
+        # between the residual add and the scalar (reference order :94-106)
+        fuse_scalar = self.normalization is None
+        if x.dim() == 2:
+            out = self._forward_2d(x, edge_index, fuse_scalar)
+        else:
+            out = torch.stack([self._forward_2d(x[b], edge_index, fuse_scalar)
+                               for b in range(x.size(0))]) if x.size(0) != 1 else \
+                self._forward_2d(x[0], edge_index, fuse_scalar).unsqueeze(0)
+
+        if isinstance(self.normalization, nn.BatchNorm1d):
+            if out.size(0) > 1:  # reference :99 (always skipped for [1, N, d])
+                out = self.normalization(out)
+        elif isinstance(self.normalization, nn.LayerNorm):
+            out = self.normalization(out)
+        if not fuse_scalar and self.scalar is not None:
+            out = out * self.scalar
+        return out
+
+    def extra_repr(self) -> str:
+        return (f"hidden_size={self.hidden_size}, bottleneck_size={self.bottleneck_size}, "
+                f"non_linearity={self.non_linearity}, normalize={self.normalize}, "
+                f"skip_connection={self.skip_connection}, learnable_scalar={self.scalar is not None}")

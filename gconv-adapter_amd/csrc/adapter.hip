@@ -1,0 +1,242 @@
+// Whole-adapter forward / backward: kernel sequencing and workspace carving.
+//
+// Replaces GConvAdapter.forward (/root/reference/src/finetune/gconv_adapter.py:80-108,
+// normalization='none') and its autograd backward. Identical math, reassociated
+// so that BOTH propagations run at rank r (PyG's conv_up propagates at width d):
+//
+//   forward   H0' = dis . (X Wd^T)                         K1  gemm_rowsA<DOWN>
+//             H2' = dis . act(dis . (A0 H0' + H0') + bd)   K2  spmm<EPI_FWD1>
+//             P   =       dis . (A0 H2' + H2')             K2' spmm<EPI_STORE>
+//             out = s (P Wu^T + bu + X)                    K3  up_fwd
+//   backward  dP' = dis . s (G Wu)          ; ds1          B1  gemm_rowsA<DP>
+//             dH1'= dis . (S^T dP) . act'   ; dbd          B2  spmm<EPI_BWD1> on S^T
+//             T   = S^T dH1                                B3  spmm<EPI_STORE> on S^T
+//             dX  = T Wd + s G ; dWd^T, dWu^T, colsum(G)   B4  bwd_main
+//             parameter gradients                          B5  finalize
+// (dis . = row scaling by deg^-1/2; without normalisation dis == 1 and the
+// implicit self-loop term disappears.)
+#include "gemm.h"
+#include "spmm.h"
+
+namespace gconv {
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* p) : base(static_cast<char*>(p)) {}
+  template <typename T>
+  T* take(size_t count) {
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += align_up(count * sizeof(T) + 16, 256);
+    return p;
+  }
+};
+
+struct FwdWs {
+  float* h0;
+  float* seg;
+  size_t bytes;
+};
+static FwdWs carve_fwd(void* ws, const gconv_csr_t* g, int fp) {
+  Carver c(ws);
+  FwdWs w;
+  w.h0 = c.take<float>(static_cast<size_t>(g->num_nodes) * fp);
+  w.seg = c.take<float>(static_cast<size_t>(g->n_seg) * fp);
+  w.bytes = c.off;
+  return w;
+}
+
+struct BwdWs {
+  float* dp;    // dP', later reused for T
+  float* dh1;
+  float* seg;
+  float* part_ds1;
+  float* part_bd;
+  float* part_wd;
+  float* part_wu;
+  float* part_cs;
+  float* part_dsx;
+  float* cs_tmp;
+  int n_ds1, n_bd;
+  BwdMainGeom geom;
+  size_t bytes;
+};
+static BwdWs carve_bwd(void* ws, const gconv_csr_t* gt, int d, int fp) {
+  Carver c(ws);
+  BwdWs w;
+  const size_t n = gt->num_nodes;
+  w.geom = bwd_main_geom(gt->num_nodes, d);
+  w.n_ds1 = rowsA_grid(gt->num_nodes);
+  w.n_bd = spmm_bias_partial_rows(gt, fp);
+  w.dp = c.take<float>(n * fp);
+  w.dh1 = c.take<float>(n * fp);
+  w.seg = c.take<float>(static_cast<size_t>(gt->n_seg) * fp);
+  w.part_ds1 = c.take<float>(w.n_ds1);
+  w.part_bd = c.take<float>(static_cast<size_t>(w.n_bd) * fp);
+  w.part_wd = c.take<float>(static_cast<size_t>(w.geom.nparts) * fp * d);
+  w.part_wu = c.take<float>(static_cast<size_t>(w.geom.nparts) * fp * d);
+  w.part_cs = c.take<float>(static_cast<size_t>(w.geom.nparts) * d);
+  w.part_dsx = c.take<float>(static_cast<size_t>(w.geom.nparts) * w.geom.nchunks);
+  w.cs_tmp = c.take<float>(d);
+  w.bytes = c.off;
+  return w;
+}
+
+static gconv_status_t check_common(const gconv_csr_t* g, const gconv_adapter_params_t* p) {
+  if (!g || !p || !g->rowptr || (g->nnz > 0 && !g->col) || g->num_nodes < 0)
+    return GCONV_E_INVALID_ARG;
+  if (p->hidden <= 0 || p->rank <= 0 || !p->w_down || !p->w_up) return GCONV_E_INVALID_ARG;
+  if (p->act < GCONV_ACT_NONE || p->act > GCONV_ACT_SILU) return GCONV_E_INVALID_ARG;
+  if (p->hidden % 4 != 0 || p->hidden > 1024 || padded_rank(p->rank) == 0)
+    return GCONV_E_UNSUPPORTED;
+  if (rowsA_lds_bytes(p->hidden, padded_rank(p->rank)) > 64 * 1024) return GCONV_E_UNSUPPORTED;
+  if (g->n_long > 0 && (!g->long_rows || !g->long_seg_base || !g->seg_long))
+    return GCONV_E_INVALID_ARG;
+  return GCONV_OK;
+}
+
+}  // namespace gconv
+
+using namespace gconv;
+
+extern "C" int32_t gconv_abi_version(void) { return GCONV_ABI_VERSION; }
+
+extern "C" int32_t gconv_padded_rank(int32_t rank) { return padded_rank(rank); }
+
+extern "C" const char* gconv_status_string(gconv_status_t status) {
+  switch (status) {
+    case GCONV_OK: return "success";
+    case GCONV_E_INVALID_ARG: return "invalid argument";
+    case GCONV_E_UNSUPPORTED:
+      return "unsupported shape (hidden must be a multiple of 4 and <= 1024, rank in 1..64)";
+    case GCONV_E_WORKSPACE: return "workspace too small";
+    case GCONV_E_BAD_INDEX: return "edge_index entry outside [0, num_nodes)";
+    case GCONV_E_ALIGNMENT: return "float buffer is not 16-byte aligned";
+  }
+  if (status > 0) return hipGetErrorString(static_cast<hipError_t>(status));
+  return "unknown gconv status";
+}
+
+extern "C" size_t gconv_adapter_fwd_workspace_bytes(const gconv_csr_t* graph, int32_t hidden,
+                                                    int32_t rank) {
+  (void)hidden;
+  const int fp = padded_rank(rank);
+  if (!graph || fp == 0) return 0;
+  return carve_fwd(nullptr, graph, fp).bytes;
+}
+
+extern "C" size_t gconv_adapter_bwd_workspace_bytes(const gconv_csr_t* graph_t, int32_t hidden,
+                                                    int32_t rank) {
+  const int fp = padded_rank(rank);
+  if (!graph_t || fp == 0 || hidden <= 0) return 0;
+  return carve_bwd(nullptr, graph_t, hidden, fp).bytes;
+}
+
+extern "C" gconv_status_t gconv_adapter_fwd_f32(const gconv_csr_t* graph, const float* dis,
+                                                const gconv_adapter_params_t* p, const float* x,
+                                                float* out, float* saved_h, float* saved_h1,
+                                                float* saved_p, void* workspace,
+                                                size_t workspace_bytes, gconv_stream_t stream_) {
+  gconv_status_t st = check_common(graph, p);
+  if (st != GCONV_OK) return st;
+  const int n = graph->num_nodes, d = p->hidden, r = p->rank, fp = padded_rank(r);
+  if (n == 0) return GCONV_OK;
+  if (!x || !out || !saved_h || !saved_p || !workspace) return GCONV_E_INVALID_ARG;
+  if (p->act == GCONV_ACT_SILU && !saved_h1) return GCONV_E_INVALID_ARG;
+  if (!aligned16(x) || !aligned16(out) || !aligned16(saved_h) || !aligned16(saved_p) ||
+      (saved_h1 && !aligned16(saved_h1)) || !aligned16(workspace) ||
+      (p->b_up && !aligned16(p->b_up)) || !aligned16(p->w_down))
+    return GCONV_E_ALIGNMENT;
+  const FwdWs ws = carve_fwd(workspace, graph, fp);
+  if (workspace_bytes < ws.bytes) return GCONV_E_WORKSPACE;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+
+  RowsAArgs k1{};
+  k1.X = x; k1.W = p->w_down; k1.row_scale = dis; k1.out = ws.h0;
+  k1.n = n; k1.d = d; k1.r = r; k1.fp = fp; k1.mode = ROWSA_DOWN;
+  st = launch_rowsA(k1, stream);
+  if (st != GCONV_OK) return st;
+
+  SpmmArgs k2{};
+  k2.dis = dis; k2.H = ws.h0; k2.Y = saved_h; k2.Y2 = saved_h1;
+  k2.bias = p->b_down; k2.act = p->act; k2.rank = r; k2.seg_partial = ws.seg;
+  st = launch_spmm(graph, k2, fp, EPI_FWD1, stream);
+  if (st != GCONV_OK) return st;
+
+  SpmmArgs k2b{};
+  k2b.dis = dis; k2b.H = saved_h; k2b.Y = saved_p; k2b.rank = r; k2b.seg_partial = ws.seg;
+  st = launch_spmm(graph, k2b, fp, EPI_STORE, stream);
+  if (st != GCONV_OK) return st;
+
+  UpArgs k3{};
+  k3.P = saved_p; k3.W_up = p->w_up; k3.b_up = p->b_up; k3.scalar = p->scalar;
+  k3.X = x; k3.out = out; k3.n = n; k3.d = d; k3.r = r; k3.fp = fp; k3.skip = p->skip;
+  return launch_up_fwd(k3, stream);
+}
+
+extern "C" gconv_status_t gconv_adapter_bwd_f32(const gconv_csr_t* graph_t, const float* dis,
+                                                const gconv_adapter_params_t* p, const float* x,
+                                                const float* grad_out, const float* saved_h,
+                                                const float* saved_h1, const float* saved_p,
+                                                float* grad_x, float* grad_w_down,
+                                                float* grad_b_down, float* grad_w_up,
+                                                float* grad_b_up, float* grad_scalar,
+                                                void* workspace, size_t workspace_bytes,
+                                                gconv_stream_t stream_) {
+  gconv_status_t st = check_common(graph_t, p);
+  if (st != GCONV_OK) return st;
+  const int n = graph_t->num_nodes, d = p->hidden, r = p->rank, fp = padded_rank(r);
+  if (!grad_w_down || !grad_w_up || !workspace) return GCONV_E_INVALID_ARG;
+  if (n > 0 && (!x || !grad_out || !saved_h || !saved_p)) return GCONV_E_INVALID_ARG;
+  if (p->act == GCONV_ACT_SILU && n > 0 && !saved_h1) return GCONV_E_INVALID_ARG;
+  if (!aligned16(x) || !aligned16(grad_out) || !aligned16(saved_h) || !aligned16(saved_p) ||
+      (saved_h1 && !aligned16(saved_h1)) || (grad_x && !aligned16(grad_x)) ||
+      !aligned16(workspace) || !aligned16(p->w_down))
+    return GCONV_E_ALIGNMENT;
+  const BwdWs ws = carve_bwd(workspace, graph_t, d, fp);
+  if (workspace_bytes < ws.bytes) return GCONV_E_WORKSPACE;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+
+  if (n > 0) {
+    RowsAArgs b1{};
+    b1.X = grad_out; b1.W = p->w_up; b1.row_scale = dis; b1.scalar = p->scalar;
+    b1.P = grad_scalar ? saved_p : nullptr;
+    b1.ds_partial = grad_scalar ? ws.part_ds1 : nullptr;
+    b1.out = ws.dp; b1.n = n; b1.d = d; b1.r = r; b1.fp = fp; b1.mode = ROWSA_DP;
+    st = launch_rowsA(b1, stream);
+    if (st != GCONV_OK) return st;
+
+    SpmmArgs b2{};
+    b2.dis = dis; b2.H = ws.dp; b2.Y = ws.dh1;
+    b2.saved = (p->act == GCONV_ACT_SILU) ? saved_h1 : saved_h;
+    b2.act = p->act; b2.rank = r; b2.seg_partial = ws.seg; b2.bias_partial = ws.part_bd;
+    st = launch_spmm(graph_t, b2, fp, EPI_BWD1, stream);
+    if (st != GCONV_OK) return st;
+
+    SpmmArgs b3{};
+    b3.dis = dis; b3.H = ws.dh1; b3.Y = ws.dp; b3.rank = r; b3.seg_partial = ws.seg;
+    st = launch_spmm(graph_t, b3, fp, EPI_STORE, stream);
+    if (st != GCONV_OK) return st;
+
+    BwdMainArgs b4{};
+    b4.G = grad_out; b4.X = x; b4.T = ws.dp; b4.P = saved_p; b4.W_down = p->w_down;
+    b4.scalar = p->scalar; b4.dX = grad_x;
+    b4.part_wd = ws.part_wd; b4.part_wu = ws.part_wu; b4.part_cs = ws.part_cs;
+    b4.part_dsx = ws.part_dsx;
+    b4.n = n; b4.d = d; b4.r = r; b4.fp = fp; b4.skip = p->skip;
+    st = launch_bwd_main(b4, stream);
+    if (st != GCONV_OK) return st;
+  }
+
+  FinalizeArgs f{};
+  f.part_wd = ws.part_wd; f.part_wu = ws.part_wu; f.part_cs = ws.part_cs;
+  f.nparts = n > 0 ? ws.geom.nparts : 0;
+  f.part_dsx = ws.part_dsx; f.n_dsx = n > 0 ? ws.geom.nparts * ws.geom.nchunks : 0;
+  f.part_ds1 = ws.part_ds1; f.n_ds1 = n > 0 ? ws.n_ds1 : 0;
+  f.part_bd = ws.part_bd; f.n_bd = n > 0 ? ws.n_bd : 0;
+  f.scalar = p->scalar; f.b_up = p->b_up; f.cs_tmp = ws.cs_tmp;
+  f.g_wd = grad_w_down; f.g_bd = grad_b_down; f.g_wu = grad_w_up; f.g_bu = grad_b_up;
+  f.g_s = grad_scalar;
+  f.d = d; f.r = r; f.fp = fp; f.skip = p->skip;
+  return launch_finalize(f, stream);
+}

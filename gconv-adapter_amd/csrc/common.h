@@ -1,0 +1,62 @@
+// Shared device/host helpers for the gfx950 GConv-Adapter kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gconv_adapter.h"
+
+#define GCONV_HIP(expr)                                         \
+  do {                                                          \
+    hipError_t _e = (expr);                                     \
+    if (_e != hipSuccess) return static_cast<gconv_status_t>(_e); \
+  } while (0)
+
+#define GCONV_LAUNCH_CHECK() GCONV_HIP(hipGetLastError())
+
+namespace gconv {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;
+constexpr int kNumCU = 256;
+
+__host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline int padded_rank(int r) {
+  if (r < 1 || r > 64) return 0;
+  int f = 4;
+  while (f < r) f <<= 1;
+  return f;
+}
+
+__device__ __forceinline__ f32x4 ldg4(const float* p) {
+  return *reinterpret_cast<const f32x4*>(p);
+}
+__device__ __forceinline__ void stg4(float* p, f32x4 v) {
+  *reinterpret_cast<f32x4*>(p) = v;
+}
+
+__device__ __forceinline__ float act_fwd(int act, float h) {
+  if (act == GCONV_ACT_RELU) return h > 0.f ? h : 0.f;
+  if (act == GCONV_ACT_SILU) return h / (1.f + expf(-h));
+  return h;
+}
+
+// derivative of SiLU at pre-activation h
+__device__ __forceinline__ float silu_grad(float h) {
+  float sig = 1.f / (1.f + expf(-h));
+  return sig * (1.f + h * (1.f - sig));
+}
+
+// D(16x16) += A(16x4) * B(4x16), exact fp32.
+//   A: lane l holds A[l & 15][l >> 4];  B: lane l holds B[l >> 4][l & 15]
+//   D: lane l, reg m holds D[4 * (l >> 4) + m][l & 15]
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+}  // namespace gconv

@@ -1,0 +1,78 @@
+// Internal interface of the skinny projection kernels (gemm.hip <-> adapter.hip).
+#pragma once
+
+#include "common.h"
+
+namespace gconv {
+
+// ---- contraction over the hidden dimension d: out[N, Fp] = f(X[N, d] * Wt[d, Fp])
+enum RowsAMode {
+  ROWSA_DOWN = 0,  // K1: Wt(k, c) = W_down[c, k];  out = row_scale * acc
+  ROWSA_DP = 1     // B1: Wt(k, c) = W_up[k, c];    out = row_scale * s * acc, ds1 += acc . P
+};
+
+struct RowsAArgs {
+  const float* X;          // [n, d]
+  const float* W;          // W_down [r, d] or W_up [d, r]
+  const float* row_scale;  // dis [n] or nullptr
+  const float* scalar;     // device scalar s or nullptr (ROWSA_DP)
+  const float* P;          // [n, Fp] saved P (ROWSA_DP, for the scalar gradient) or nullptr
+  float* out;              // [n, Fp]
+  float* ds_partial;       // [grid] (ROWSA_DP with P) or nullptr
+  int n, d, r, fp;
+  int mode;
+};
+
+size_t rowsA_lds_bytes(int d, int fp);
+int rowsA_grid(int n);
+gconv_status_t launch_rowsA(const RowsAArgs& a, hipStream_t stream);
+
+// ---- K3: out[N, d] = s * (P[N, Fp] * W_up^T + b_up + (skip ? X : 0))
+struct UpArgs {
+  const float* P;
+  const float* W_up;    // [d, r]
+  const float* b_up;    // [d] or nullptr
+  const float* scalar;  // device scalar or nullptr
+  const float* X;       // [n, d] (read when skip)
+  float* out;           // [n, d]
+  int n, d, r, fp;
+  int skip;
+};
+gconv_status_t launch_up_fwd(const UpArgs& a, hipStream_t stream);
+
+// ---- B4: dX, per-workgroup partials of dW_down^T, dW_up^T, colsum(G), sum(G.X)
+struct BwdMainArgs {
+  const float* G;       // [n, d] upstream gradient
+  const float* X;       // [n, d]
+  const float* T;       // [n, Fp]  S^T (S^T dP . act')
+  const float* P;       // [n, Fp]  saved P
+  const float* W_down;  // [r, d]
+  const float* scalar;  // device scalar or nullptr
+  float* dX;            // [n, d] or nullptr
+  float* part_wd;       // [nparts, Fp, d]
+  float* part_wu;       // [nparts, Fp, d]
+  float* part_cs;       // [nparts, d]
+  float* part_dsx;      // [nparts * nchunks]
+  int n, d, r, fp;
+  int skip;
+};
+struct BwdMainGeom {
+  int nchunks, nslots, grid, nparts;
+};
+BwdMainGeom bwd_main_geom(int n, int d);
+gconv_status_t launch_bwd_main(const BwdMainArgs& a, hipStream_t stream);
+
+// ---- B5: deterministic reduction of all partials into the parameter gradients
+struct FinalizeArgs {
+  const float* part_wd; const float* part_wu; const float* part_cs; int nparts;
+  const float* part_dsx; int n_dsx;
+  const float* part_ds1; int n_ds1;
+  const float* part_bd;  int n_bd;     // [n_bd, fp] from the EPI_BWD1 SpMM
+  const float* scalar; const float* b_up;
+  float* cs_tmp;                       // [d] scratch: colsum(G)
+  float* g_wd; float* g_bd; float* g_wu; float* g_bu; float* g_s;
+  int d, r, fp, skip;
+};
+gconv_status_t launch_finalize(const FinalizeArgs& a, hipStream_t stream);
+
+}  // namespace gconv

@@ -1,0 +1,551 @@
+// K1 / K3 / B1 / B4 / B5 — skinny fp32 projections on v_mfma_f32_16x16x4_f32.
+//
+// Replaces GCNConv.lin (bias-free nn.Linear) of conv_down / conv_up
+// (/root/reference/src/finetune/gconv_adapter.py:40-41), the residual + scalar
+// tail (:94-95,105-106) and their autograd backward.
+//
+// All four streaming kernels are HBM-bound (arithmetic intensity <= r/2
+// flop/B): the [N, d] operands are touched once per kernel with 16-byte lane
+// accesses, everything of rank width stays in registers / LDS / L2.
+//
+// Two register layouts for a 16-node block of an [N, d] matrix:
+//   "A layout"  (contraction over d; K1, B1): lane (node = l & 15, kq = l >> 4)
+//       holds float4 X[i0 + node][16 q + 4 kq .. +3] for k-step q; the MFMA k
+//       index is permuted (k = 16 q + 4 kq + t for MFMA t), the weight
+//       fragment uses the same permutation.
+//   "L layout"  (contraction over rank or over nodes; K3, B4): one wave owns a
+//       64-column chunk; lane (jj = l & 15, t = l >> 4) holds, for m = 0..3,
+//       float4 M[i0 + 4 t + m][64 J + 4 jj .. +3]  (256 B contiguous per row).
+//       The same registers are (i) the MFMA B operand for products that
+//       contract over nodes (dW^T = Z^T M; k-step m, MFMA c uses component c)
+//       and (ii) the element-wise operand of products that output [node, col]
+//       tiles (D register m of MFMA c is element (i0 + 4 t + m, 64 J + 4 jj + c)).
+#include "gemm.h"
+
+namespace gconv {
+
+// ===========================================================================
+// K1 / B1: out[N, Fp] = epilogue(X[N, d] * Wt[d, Fp])
+// ===========================================================================
+size_t rowsA_lds_bytes(int d, int fp) {
+  const int nq = ceil_div(d, 16), ncb = fp >= 16 ? fp / 16 : 1;
+  return static_cast<size_t>(nq) * ncb * 64 * sizeof(f32x4);
+}
+
+int rowsA_grid(int n) {
+  const int nblk = ceil_div(n, 16);
+  int g = ceil_div(nblk, 4);
+  return g < 1 ? 1 : (g > 1024 ? 1024 : g);
+}
+
+template <int NCB>
+__global__ __launch_bounds__(256) void gemm_rowsA_kernel(RowsAArgs a) {
+  extern __shared__ f32x4 wl[];  // [nq][NCB][64] weight fragments
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nq = ceil_div(a.d, 16);
+
+  for (int idx = threadIdx.x; idx < nq * NCB * 64; idx += 256) {
+    const int ln = idx & 63, cb = (idx >> 6) % NCB, q = (idx >> 6) / NCB;
+    const int c = 16 * cb + (ln & 15), k0 = 16 * q + 4 * (ln >> 4);
+    f32x4 w;
+    for (int t = 0; t < 4; ++t) {
+      const int k = k0 + t;
+      float v = 0.f;
+      if (k < a.d && c < a.r)
+        v = (a.mode == ROWSA_DOWN) ? a.W[static_cast<size_t>(c) * a.d + k]
+                                   : a.W[static_cast<size_t>(k) * a.r + c];
+      w[t] = v;
+    }
+    wl[idx] = w;
+  }
+  __syncthreads();
+
+  const float sval = (a.mode == ROWSA_DP && a.scalar) ? a.scalar[0] : 1.f;
+  const int node = lane & 15, kq = lane >> 4;
+  const int nblk = ceil_div(a.n, 16);
+  float ds_acc = 0.f;
+
+  for (int blk = blockIdx.x * 4 + wave; blk < nblk; blk += gridDim.x * 4) {
+    const int i0 = blk * 16;
+    const int rowA = min(i0 + node, a.n - 1);
+    const float* __restrict__ xrow = a.X + static_cast<size_t>(rowA) * a.d + 4 * kq;
+    f32x4 acc[NCB][2];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) acc[cb][0] = acc[cb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 4
+    for (int q = 0; q < nq; ++q) {
+      f32x4 xa = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (16 * q + 4 * kq < a.d) xa = ldg4(xrow + 16 * q);
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const f32x4 w = wl[(q * NCB + cb) * 64 + lane];
+        acc[cb][0] = mfma16(xa[0], w[0], acc[cb][0]);
+        acc[cb][1] = mfma16(xa[1], w[1], acc[cb][1]);
+        acc[cb][0] = mfma16(xa[2], w[2], acc[cb][0]);
+        acc[cb][1] = mfma16(xa[3], w[3], acc[cb][1]);
+      }
+    }
+
+    // D register m <-> (row i0 + 4 kq + m, column 16 cb + node)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      const f32x4 res = acc[cb][0] + acc[cb][1];
+      const int c = 16 * cb + node;
+      if (c < a.fp) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int row = i0 + 4 * kq + m;
+          if (row < a.n) {
+            float v = res[m];
+            const size_t o = static_cast<size_t>(row) * a.fp + c;
+            if (a.mode == ROWSA_DP) {
+              if (a.P) ds_acc += v * a.P[o];
+              v *= sval;
+            }
+            if (a.row_scale) v *= a.row_scale[row];
+            a.out[o] = v;
+          }
+        }
+      }
+    }
+  }
+
+  if (a.ds_partial) {  // block-wide sum in a fixed order
+    __shared__ float red[4];
+    for (int off = 32; off > 0; off >>= 1) ds_acc += __shfl_xor(ds_acc, off);
+    if (lane == 0) red[wave] = ds_acc;
+    __syncthreads();
+    if (threadIdx.x == 0) a.ds_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
+gconv_status_t launch_rowsA(const RowsAArgs& a, hipStream_t stream) {
+  if (a.n == 0) return GCONV_OK;
+  const size_t lds = rowsA_lds_bytes(a.d, a.fp);
+  if (lds > 64 * 1024) return GCONV_E_UNSUPPORTED;
+  const int grid = rowsA_grid(a.n);
+  switch (a.fp >= 16 ? a.fp / 16 : 1) {
+    case 1: gemm_rowsA_kernel<1><<<grid, 256, lds, stream>>>(a); break;
+    case 2: gemm_rowsA_kernel<2><<<grid, 256, lds, stream>>>(a); break;
+    case 4: gemm_rowsA_kernel<4><<<grid, 256, lds, stream>>>(a); break;
+    default: return GCONV_E_UNSUPPORTED;
+  }
+  GCONV_LAUNCH_CHECK();
+  return GCONV_OK;
+}
+
+// ===========================================================================
+// Shared helpers for the L-layout kernels
+// ===========================================================================
+// MFMA k index that lane-quarter t feeds in k-step s of a rank-width operand:
+//   FP >= 16: float4 fragments, k = 16 (s / 4) + 4 t + (s % 4);  FP < 16: k = 4 s + t
+template <int FP>
+__device__ __forceinline__ int rank_k(int s, int t) {
+  return FP >= 16 ? 16 * (s >> 2) + 4 * t + (s & 3) : 4 * s + t;
+}
+
+// A fragments of a rank-width matrix Z[N, FP] for node row `row`:
+// frag[s] = Z[row][rank_k(s, t)], s = 0 .. FP/4 - 1.
+template <int FP>
+__device__ __forceinline__ void load_rank_frag(const float* __restrict__ Z, int row, int t,
+                                               float (&frag)[FP / 4]) {
+  const float* p = Z + static_cast<size_t>(row) * FP;
+  if constexpr (FP >= 16) {
+#pragma unroll
+    for (int q = 0; q < FP / 16; ++q) {
+      const f32x4 v = ldg4(p + 16 * q + 4 * t);
+      frag[4 * q + 0] = v[0]; frag[4 * q + 1] = v[1];
+      frag[4 * q + 2] = v[2]; frag[4 * q + 3] = v[3];
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < FP / 4; ++s) frag[s] = p[4 * s + t];
+  }
+}
+
+static int chunk_slots(int nchunks) {
+  if (nchunks >= 4) return 1;
+  return 4 / nchunks;  // 1 chunk -> 4 slots, 2 -> 2, 3 -> 1
+}
+
+// ===========================================================================
+// K3: out = s * (P W_up^T + b_up + X)
+// ===========================================================================
+template <int FP, int TB>
+__global__ __launch_bounds__(TB) void up_fwd_kernel(UpArgs a, int nchunks, int nslots) {
+  constexpr int KS = FP / 4;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int J = w % nchunks, slot = w / nchunks;
+  const int jj = lane & 15, t = lane >> 4;
+  const int colbase = 64 * J + 4 * jj;
+  const bool colvalid = colbase < a.d;
+  const float sval = a.scalar ? a.scalar[0] : 1.f;
+
+  // B fragments: wb[s][c] = W_up[colbase + c][rank_k(s, t)]
+  float wb[KS][4];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int k = rank_k<FP>(s, t);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      wb[s][c] = (colvalid && k < a.r) ? a.W_up[static_cast<size_t>(colbase + c) * a.r + k] : 0.f;
+  }
+  f32x4 bu = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (colvalid && a.b_up) bu = ldg4(a.b_up + colbase);
+
+  const int nblk = ceil_div(a.n, 16);
+  for (int blk = blockIdx.x * nslots + slot; blk < nblk; blk += gridDim.x * nslots) {
+    const int i0 = blk * 16;
+    f32x4 xv[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int row = i0 + 4 * t + m;
+      xv[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a.skip && colvalid && row < a.n) xv[m] = ldg4(a.X + static_cast<size_t>(row) * a.d + colbase);
+    }
+    float pa[KS];
+    load_rank_frag<FP>(a.P, min(i0 + jj, a.n - 1), t, pa);
+    f32x4 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = mfma16(pa[s], wb[s][c], acc[c]);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int row = i0 + 4 * t + m;
+      if (colvalid && row < a.n) {
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = sval * (acc[c][m] + bu[c] + xv[m][c]);
+        stg4(a.out + static_cast<size_t>(row) * a.d + colbase, o);
+      }
+    }
+  }
+}
+
+template <int FP>
+static gconv_status_t launch_up_fwd_fp(const UpArgs& a, int grid, int threads, int nchunks,
+                                       int nslots, hipStream_t stream) {
+  if (threads <= 256)
+    up_fwd_kernel<FP, 256><<<grid, threads, 0, stream>>>(a, nchunks, nslots);
+  else if (threads <= 512)
+    up_fwd_kernel<FP, 512><<<grid, threads, 0, stream>>>(a, nchunks, nslots);
+  else
+    up_fwd_kernel<FP, 1024><<<grid, threads, 0, stream>>>(a, nchunks, nslots);
+  GCONV_LAUNCH_CHECK();
+  return GCONV_OK;
+}
+
+gconv_status_t launch_up_fwd(const UpArgs& a, hipStream_t stream) {
+  if (a.n == 0) return GCONV_OK;
+  const int nchunks = ceil_div(a.d, 64);
+  if (nchunks > 16) return GCONV_E_UNSUPPORTED;
+  const int nslots = chunk_slots(nchunks);
+  const int nblk = ceil_div(a.n, 16);
+  int grid = ceil_div(nblk, nslots);
+  if (grid > 2048) grid = 2048;
+  const int threads = 64 * nchunks * nslots;
+  switch (a.fp) {
+    case 4:  return launch_up_fwd_fp<4>(a, grid, threads, nchunks, nslots, stream);
+    case 8:  return launch_up_fwd_fp<8>(a, grid, threads, nchunks, nslots, stream);
+    case 16: return launch_up_fwd_fp<16>(a, grid, threads, nchunks, nslots, stream);
+    case 32: return launch_up_fwd_fp<32>(a, grid, threads, nchunks, nslots, stream);
+    case 64: return launch_up_fwd_fp<64>(a, grid, threads, nchunks, nslots, stream);
+  }
+  return GCONV_E_UNSUPPORTED;
+}
+
+// ===========================================================================
+// B4: dX = T W_down + s G ; partials of dW_down^T = T^T X, dW_up^T = P^T G,
+//     colsum(G), sum(G . X)
+// ===========================================================================
+BwdMainGeom bwd_main_geom(int n, int d) {
+  BwdMainGeom g;
+  g.nchunks = ceil_div(d, 64);
+  g.nslots = chunk_slots(g.nchunks);
+  const int nblk = ceil_div(n, 16);
+  // >= 4 node blocks per wave slot amortise the partial write-out; <= 256 partials
+  int grid = ceil_div(nblk, 4 * g.nslots);
+  const int cap = 256 / g.nslots;
+  if (grid > cap) grid = cap;
+  if (grid < 1) grid = 1;
+  g.grid = grid;
+  g.nparts = grid * g.nslots;
+  return g;
+}
+
+template <int FP, bool NEED_DX, int TB>
+__global__ __launch_bounds__(TB) void bwd_main_kernel(BwdMainArgs a, int nchunks, int nslots) {
+  constexpr int KS = FP / 4;
+  constexpr int NCB = FP >= 16 ? FP / 16 : 1;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int J = w % nchunks, slot = w / nchunks;
+  const int jj = lane & 15, t = lane >> 4;
+  const int colbase = 64 * J + 4 * jj;
+  const bool colvalid = colbase < a.d;
+  const float sval = a.scalar ? a.scalar[0] : 1.f;
+
+  // B fragments for dX: wd[s][c] = W_down[rank_k(s, t)][colbase + c]
+  float wd[NEED_DX ? KS : 1][4];
+  if (NEED_DX) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k = rank_k<FP>(s, t);
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (colvalid && k < a.r) v = ldg4(a.W_down + static_cast<size_t>(k) * a.d + colbase);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) wd[s][c] = v[c];
+    }
+  }
+
+  f32x4 awd[NCB][4], awu[NCB][4];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) awd[cb][c] = awu[cb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dsx = 0.f;
+
+  const int nblk = ceil_div(a.n, 16);
+  for (int blk = blockIdx.x * nslots + slot; blk < nblk; blk += gridDim.x * nslots) {
+    const int i0 = blk * 16;
+    f32x4 gv[4], xv[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int row = i0 + 4 * t + m;
+      gv[m] = xv[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (colvalid && row < a.n) {
+        gv[m] = ldg4(a.G + static_cast<size_t>(row) * a.d + colbase);
+        xv[m] = ldg4(a.X + static_cast<size_t>(row) * a.d + colbase);
+      }
+    }
+
+    // contraction over the 16 nodes: k-step m covers nodes i0 + 4 t + m
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int row = i0 + 4 * t + m;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const int rc = 16 * cb + jj;  // rank column this lane feeds as the A row
+        float at = 0.f, ap = 0.f;
+        if (row < a.n && rc < FP) {
+          at = a.T[static_cast<size_t>(row) * FP + rc];
+          ap = a.P[static_cast<size_t>(row) * FP + rc];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          awd[cb][c] = mfma16(at, xv[m][c], awd[cb][c]);
+          awu[cb][c] = mfma16(ap, gv[m][c], awu[cb][c]);
+        }
+      }
+      cs += gv[m];
+      if (a.skip) dsx += gv[m][0] * xv[m][0] + gv[m][1] * xv[m][1] + gv[m][2] * xv[m][2] + gv[m][3] * xv[m][3];
+    }
+
+    if (NEED_DX) {
+      float ta[KS];
+      load_rank_frag<FP>(a.T, min(i0 + jj, a.n - 1), t, ta);
+      f32x4 acc[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = mfma16(ta[s], wd[s][c], acc[c]);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int row = i0 + 4 * t + m;
+        if (colvalid && row < a.n) {
+          f32x4 o;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) o[c] = acc[c][m] + (a.skip ? sval * gv[m][c] : 0.f);
+          stg4(a.dX + static_cast<size_t>(row) * a.d + colbase, o);
+        }
+      }
+    }
+  }
+
+  // ---- write this wave's partials
+  const int pid = blockIdx.x * nslots + slot;
+  if (colvalid) {
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int rk = 16 * cb + 4 * t + m;  // D row = rank index
+        if (rk < FP) {
+          const size_t o = (static_cast<size_t>(pid) * FP + rk) * a.d + colbase;
+          stg4(a.part_wd + o, f32x4{awd[cb][0][m], awd[cb][1][m], awd[cb][2][m], awd[cb][3][m]});
+          stg4(a.part_wu + o, f32x4{awu[cb][0][m], awu[cb][1][m], awu[cb][2][m], awu[cb][3][m]});
+        }
+      }
+    }
+  }
+  // colsum(G): add the four lane quarters (fixed order), quarter 0 stores
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    cs[c] += __shfl_xor(cs[c], 16);
+    cs[c] += __shfl_xor(cs[c], 32);
+  }
+  if (colvalid && t == 0) stg4(a.part_cs + static_cast<size_t>(pid) * a.d + colbase, cs);
+  for (int off = 32; off > 0; off >>= 1) dsx += __shfl_xor(dsx, off);
+  if (lane == 0) a.part_dsx[static_cast<size_t>(pid) * nchunks + J] = dsx;
+}
+
+template <int FP>
+static gconv_status_t launch_bwd_main_fp(const BwdMainArgs& a, const BwdMainGeom& g,
+                                         hipStream_t stream) {
+  const int threads = 64 * g.nchunks * g.nslots;
+#define GCONV_BWD_LAUNCH(DX, TB_) \
+  bwd_main_kernel<FP, DX, TB_><<<g.grid, threads, 0, stream>>>(a, g.nchunks, g.nslots)
+  if (a.dX) {
+    if (threads <= 256) GCONV_BWD_LAUNCH(true, 256);
+    else if (threads <= 512) GCONV_BWD_LAUNCH(true, 512);
+    else GCONV_BWD_LAUNCH(true, 1024);
+  } else {
+    if (threads <= 256) GCONV_BWD_LAUNCH(false, 256);
+    else if (threads <= 512) GCONV_BWD_LAUNCH(false, 512);
+    else GCONV_BWD_LAUNCH(false, 1024);
+  }
+#undef GCONV_BWD_LAUNCH
+  GCONV_LAUNCH_CHECK();
+  return GCONV_OK;
+}
+
+gconv_status_t launch_bwd_main(const BwdMainArgs& a, hipStream_t stream) {
+  const BwdMainGeom g = bwd_main_geom(a.n, a.d);
+  if (g.nchunks > 16) return GCONV_E_UNSUPPORTED;
+  switch (a.fp) {
+    case 4:  return launch_bwd_main_fp<4>(a, g, stream);
+    case 8:  return launch_bwd_main_fp<8>(a, g, stream);
+    case 16: return launch_bwd_main_fp<16>(a, g, stream);
+    case 32: return launch_bwd_main_fp<32>(a, g, stream);
+    case 64: return launch_bwd_main_fp<64>(a, g, stream);
+  }
+  return GCONV_E_UNSUPPORTED;
+}
+
+// ===========================================================================
+// B5: fixed-order reduction of the per-workgroup partials
+// ===========================================================================
+// element space: [0, r d) dW_down | [r d, 2 r d) dW_up | [2 r d, 2 r d + d) colsum(G)
+//                | [2 r d + d, 2 r d + d + r) db_down
+// block = 32 consecutive elements x 8 interleaved partial streams.
+__global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
+  __shared__ float red[8][32];
+  const int e = blockIdx.x * 32 + (threadIdx.x & 31), ps = threadIdx.x >> 5;
+  const int rd = a.r * a.d, total = 2 * rd + a.d + a.r;
+  float sum = 0.f;
+  if (e < total) {
+    if (e < 2 * rd) {
+      const float* part = e < rd ? a.part_wd : a.part_wu;
+      const int idx = e < rd ? e : e - rd;
+      const int c = idx / a.d, j = idx % a.d;
+      for (int p = ps; p < a.nparts; p += 8)
+        sum += part[(static_cast<size_t>(p) * a.fp + c) * a.d + j];
+    } else if (e < 2 * rd + a.d) {
+      const int j = e - 2 * rd;
+      for (int p = ps; p < a.nparts; p += 8) sum += a.part_cs[static_cast<size_t>(p) * a.d + j];
+    } else {
+      const int c = e - 2 * rd - a.d;
+      for (int p = ps; p < a.n_bd; p += 8) sum += a.part_bd[static_cast<size_t>(p) * a.fp + c];
+    }
+  }
+  red[ps][threadIdx.x & 31] = sum;
+  __syncthreads();
+  if (ps == 0 && e < total) {
+    const int x = threadIdx.x;
+    const float v = ((red[0][x] + red[1][x]) + (red[2][x] + red[3][x])) +
+                    ((red[4][x] + red[5][x]) + (red[6][x] + red[7][x]));
+    const float sval = a.scalar ? a.scalar[0] : 1.f;
+    if (e < rd) {
+      a.g_wd[e] = v;
+    } else if (e < 2 * rd) {
+      const int idx = e - rd, c = idx / a.d, j = idx % a.d;
+      a.g_wu[static_cast<size_t>(j) * a.r + c] = sval * v;
+    } else if (e < 2 * rd + a.d) {
+      const int j = e - 2 * rd;
+      a.cs_tmp[j] = v;
+      if (a.g_bu) a.g_bu[j] = sval * v;
+    } else {
+      if (a.g_bd) a.g_bd[e - 2 * rd - a.d] = v;
+    }
+  }
+}
+
+// d(scalar) = sum_i (G_i W_up) . P_i  +  b_up . colsum(G)  +  [skip] sum(G . X)
+__global__ __launch_bounds__(256) void finalize_scalar_kernel(FinalizeArgs a) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < a.n_ds1; i += 256) acc += a.part_ds1[i];
+  if (a.skip)
+    for (int i = threadIdx.x; i < a.n_dsx; i += 256) acc += a.part_dsx[i];
+  if (a.b_up)
+    for (int j = threadIdx.x; j < a.d; j += 256) acc += a.b_up[j] * a.cs_tmp[j];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) a.g_s[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+gconv_status_t launch_finalize(const FinalizeArgs& a, hipStream_t stream) {
+  const int total = 2 * a.r * a.d + a.d + a.r;
+  finalize_kernel<<<ceil_div(total, 32), 256, 0, stream>>>(a);
+  GCONV_LAUNCH_CHECK();
+  if (a.g_s) {
+    finalize_scalar_kernel<<<1, 256, 0, stream>>>(a);
+    GCONV_LAUNCH_CHECK();
+  }
+  return GCONV_OK;
+}
+
+}  // namespace gconv
+
+using namespace gconv;
+
+// ---------------------------------------------------------------------------
+// C ABI: stand-alone projections
+// ---------------------------------------------------------------------------
+static gconv_status_t check_dims(int32_t n, int32_t d, int32_t r) {
+  if (n < 0 || d <= 0 || r <= 0) return GCONV_E_INVALID_ARG;
+  if (d % 4 != 0 || d > 1024 || padded_rank(r) == 0) return GCONV_E_UNSUPPORTED;
+  return GCONV_OK;
+}
+
+extern "C" gconv_status_t gconv_gemm_down_f32(const float* x, const float* w_down,
+                                              const float* row_scale, float* h0,
+                                              int32_t num_nodes, int32_t hidden, int32_t rank,
+                                              gconv_stream_t stream) {
+  gconv_status_t st = check_dims(num_nodes, hidden, rank);
+  if (st != GCONV_OK) return st;
+  if (num_nodes == 0) return GCONV_OK;
+  if (!x || !w_down || !h0) return GCONV_E_INVALID_ARG;
+  if (!aligned16(x) || !aligned16(h0)) return GCONV_E_ALIGNMENT;
+  RowsAArgs a{};
+  a.X = x; a.W = w_down; a.row_scale = row_scale; a.out = h0;
+  a.n = num_nodes; a.d = hidden; a.r = rank; a.fp = padded_rank(rank);
+  a.mode = ROWSA_DOWN;
+  return launch_rowsA(a, static_cast<hipStream_t>(stream));
+}
+
+extern "C" gconv_status_t gconv_gemm_up_fused_f32(const float* p, const float* w_up,
+                                                  const float* b_up, const float* scalar,
+                                                  const float* x, int32_t skip, float* out,
+                                                  int32_t num_nodes, int32_t hidden,
+                                                  int32_t rank, gconv_stream_t stream) {
+  gconv_status_t st = check_dims(num_nodes, hidden, rank);
+  if (st != GCONV_OK) return st;
+  if (num_nodes == 0) return GCONV_OK;
+  if (!p || !w_up || !out || (skip && !x)) return GCONV_E_INVALID_ARG;
+  if (!aligned16(p) || !aligned16(out) || (x && !aligned16(x)) || (b_up && !aligned16(b_up)))
+    return GCONV_E_ALIGNMENT;
+  UpArgs a{};
+  a.P = p; a.W_up = w_up; a.b_up = b_up; a.scalar = scalar; a.X = x; a.out = out;
+  a.n = num_nodes; a.d = hidden; a.r = rank; a.fp = padded_rank(rank); a.skip = skip;
+  return launch_up_fwd(a, static_cast<hipStream_t>(stream));
+}

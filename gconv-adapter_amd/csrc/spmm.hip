@@ -1,0 +1,300 @@
+// K2 — CSR SpMM at rank width F in {4, 8, 16, 32, 64} for gfx950.
+//
+// Replaces MessagePassing.propagate (index_select -> weight mul -> scatter_add,
+// float atomics on GPU) + `out + bias` of PyG's GCNConv.forward, reached from
+// /root/reference/src/finetune/gconv_adapter.py:92. No atomics: every output
+// row is produced by exactly one lane group in a fixed edge order, so results
+// are bitwise reproducible.
+//
+// Work decomposition
+//   * a row of F floats is F/4 lanes x float4; a wave carries 64/(F/4) rows.
+//     Each lane group walks its row's edge list (8 gathers in flight per lane).
+//   * symmetric normalisation never touches an edge weight: the producer
+//     stores rows pre-multiplied by dis[j], the kernel adds the implicit
+//     self-loop and multiplies the finished row by dis[i]:
+//         Y[i] = dis[i] * (sum_j H'[j] + H'[i]),   H'[j] = dis[j] * H[j].
+//   * rows longer than GCONV_LONG_ROW edges are skipped by the row kernel and
+//     cut into GCONV_SEG_EDGES-edge segments; one wave reduces one segment
+//     (extra blocks at the tail of the same launch), and a second small launch
+//     adds a row's segment sums in segment order and runs the epilogue.
+#include "spmm.h"
+
+namespace gconv {
+
+template <int F>
+struct RowShape {
+  static constexpr int LPR = F / 4;        // lanes per row
+  static constexpr int RPW = kWave / LPR;  // rows per wave
+};
+
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+// ---------------------------------------------------------------------------
+// Epilogue shared by the row kernel and the long-row fix-up kernel.
+//   `sum` = plain sum over the row's stored edges of the gathered rows.
+// ---------------------------------------------------------------------------
+template <int F, bool NORM, int EPI>
+__device__ __forceinline__ void spmm_epilogue(const SpmmArgs& a, int row, int sub, f32x4 sum,
+                                              f32x4& bias_grad) {
+  constexpr int LPR = RowShape<F>::LPR;
+  const size_t off = static_cast<size_t>(row) * F + 4 * sub;
+  float di = 1.f;
+  f32x4 v = sum;
+  if (NORM) {
+    di = a.dis[row];
+    f32x4 self = ldg4(a.H + off);
+    if (EPI == EPI_GENERIC && !(a.flags & GCONV_SPMM_IN_PRESCALED)) self *= di;
+    v = (sum + self) * di;
+  }
+  if (EPI == EPI_STORE) {
+    stg4(a.Y + off, v);
+  } else if (EPI == EPI_GENERIC) {
+    if (a.bias) v += ldg4(a.bias + 4 * sub);
+    for (int k = 0; k < 4; ++k) v[k] = act_fwd(a.act, v[k]);
+    if (NORM && (a.flags & GCONV_SPMM_OUT_PRESCALE)) v *= di;
+    stg4(a.Y + off, v);
+  } else if (EPI == EPI_FWD1) {
+    // h1 = v + b_down ; h2 = act(h1) ; store h2 (row-scaled for the next hop)
+    for (int k = 0; k < 4; ++k) {
+      int c = 4 * sub + k;
+      if (a.bias && c < a.rank) v[k] += a.bias[c];
+    }
+    if (a.act == GCONV_ACT_SILU && a.Y2) stg4(a.Y2 + off, v);
+    for (int k = 0; k < 4; ++k) v[k] = act_fwd(a.act, v[k]);
+    if (NORM) v *= di;
+    stg4(a.Y + off, v);
+  } else {  // EPI_BWD1: dh1 = dh2 * act'(h1); accumulate bias grad; store row-scaled dh1
+    if (a.act == GCONV_ACT_RELU) {
+      f32x4 h2 = ldg4(a.saved + off);  // dis * relu(h1): same sign pattern as relu(h1)
+      for (int k = 0; k < 4; ++k) v[k] = h2[k] > 0.f ? v[k] : 0.f;
+    } else if (a.act == GCONV_ACT_SILU) {
+      f32x4 h1 = ldg4(a.saved + off);
+      for (int k = 0; k < 4; ++k) v[k] *= silu_grad(h1[k]);
+    }
+    bias_grad += v;
+    if (NORM) v *= di;
+    stg4(a.Y + off, v);
+  }
+  (void)LPR;
+}
+
+// Sums `bias_grad` over the lanes of a block that own the same column slot and
+// writes one [F] row of partials per block (EPI_BWD1 only).
+template <int F>
+__device__ __forceinline__ void block_bias_partial(f32x4 bias_grad, float* part_row) {
+  constexpr int LPR = RowShape<F>::LPR;
+  __shared__ float red[4][F];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = LPR; off < kWave; off <<= 1) {
+    for (int k = 0; k < 4; ++k) bias_grad[k] += __shfl_xor(bias_grad[k], off);
+  }
+  if (lane < LPR) {
+    for (int k = 0; k < 4; ++k) red[wave][4 * lane + k] = bias_grad[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < F) {
+    part_row[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] +
+                            red[3][threadIdx.x];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Row kernel: blocks [0, row_blocks) walk rows, blocks [row_blocks, grid) reduce
+// long-row segments (one wave per segment).
+// ---------------------------------------------------------------------------
+template <int F, bool NORM, int EPI>
+__global__ __launch_bounds__(256) void spmm_rows_kernel(SpmmArgs a) {
+  constexpr int LPR = RowShape<F>::LPR;
+  constexpr int RPW = RowShape<F>::RPW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPR, grp = lane / LPR;
+  const bool gather_scale = NORM && EPI == EPI_GENERIC && !(a.flags & GCONV_SPMM_IN_PRESCALED);
+  const float* __restrict__ H = a.H;
+  const int32_t* __restrict__ col = a.col;
+
+  if (static_cast<int>(blockIdx.x) >= a.row_blocks) {
+    // ---- long-row segment: the 64/LPR lane groups stride over the segment's edges
+    const int s = (blockIdx.x - a.row_blocks) * 4 + wave;
+    if (s >= a.n_seg) return;
+    const int lr = a.seg_long[s];
+    const int row = a.long_rows[lr];
+    const int k = s - a.long_seg_base[lr];
+    const int e0 = a.rowptr[row] + k * GCONV_SEG_EDGES;
+    const int e1 = min(e0 + GCONV_SEG_EDGES, a.rowptr[row + 1]);
+    f32x4 acc = zero4();
+#pragma unroll 4
+    for (int e = e0 + grp; e < e1; e += RPW) {
+      int c = col[e];
+      f32x4 h = ldg4(H + static_cast<size_t>(c) * F + 4 * sub);
+      if (gather_scale) h *= a.dis[c];
+      acc += h;
+    }
+#pragma unroll
+    for (int off = LPR; off < kWave; off <<= 1) {
+      for (int q = 0; q < 4; ++q) acc[q] += __shfl_xor(acc[q], off);
+    }
+    if (grp == 0) stg4(a.seg_partial + static_cast<size_t>(s) * F + 4 * sub, acc);
+    return;
+  }
+
+  f32x4 bias_grad = zero4();
+  const int row = (blockIdx.x * 4 + wave) * RPW + grp;
+  if (row < a.n) {
+    const int e0 = a.rowptr[row], e1 = a.rowptr[row + 1];
+    if (e1 - e0 <= GCONV_LONG_ROW) {
+      f32x4 acc0 = zero4(), acc1 = zero4();
+      int e = e0;
+      for (; e + 8 <= e1; e += 8) {
+        int c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] = col[e + u];
+        f32x4 h[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) h[u] = ldg4(H + static_cast<size_t>(c[u]) * F + 4 * sub);
+        if (gather_scale) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) h[u] *= a.dis[c[u]];
+        }
+        // fixed association order: ((h0+h1)+(h2+h3)) + ((h4+h5)+(h6+h7))
+        acc0 += (h[0] + h[1]) + (h[2] + h[3]);
+        acc1 += (h[4] + h[5]) + (h[6] + h[7]);
+      }
+      for (; e < e1; ++e) {
+        int c = col[e];
+        f32x4 h = ldg4(H + static_cast<size_t>(c) * F + 4 * sub);
+        if (gather_scale) h *= a.dis[c];
+        acc0 += h;
+      }
+      spmm_epilogue<F, NORM, EPI>(a, row, sub, acc0 + acc1, bias_grad);
+    }
+  }
+  if (EPI == EPI_BWD1) block_bias_partial<F>(bias_grad, a.bias_partial + static_cast<size_t>(blockIdx.x) * F);
+}
+
+// ---------------------------------------------------------------------------
+// Long-row fix-up: one wave per long row adds the row's segment sums (lane
+// groups stride over segments, fixed shuffle tree) and runs the epilogue.
+// ---------------------------------------------------------------------------
+template <int F, bool NORM, int EPI>
+__global__ __launch_bounds__(256) void spmm_fixup_kernel(SpmmArgs a) {
+  constexpr int LPR = RowShape<F>::LPR;
+  constexpr int RPW = RowShape<F>::RPW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPR, grp = lane / LPR;
+  const int lr = blockIdx.x * 4 + wave;
+  f32x4 bias_grad = zero4();
+  if (lr < a.n_long) {
+    const int row = a.long_rows[lr];
+    const int base = a.long_seg_base[lr];
+    const int deg = a.rowptr[row + 1] - a.rowptr[row];
+    const int nseg = (deg + GCONV_SEG_EDGES - 1) / GCONV_SEG_EDGES;
+    f32x4 acc = zero4();
+    for (int k = grp; k < nseg; k += RPW)
+      acc += ldg4(a.seg_partial + static_cast<size_t>(base + k) * F + 4 * sub);
+#pragma unroll
+    for (int off = LPR; off < kWave; off <<= 1) {
+      for (int q = 0; q < 4; ++q) acc[q] += __shfl_xor(acc[q], off);
+    }
+    if (grp == 0) spmm_epilogue<F, NORM, EPI>(a, row, sub, acc, bias_grad);
+  }
+  if (EPI == EPI_BWD1)
+    block_bias_partial<F>(bias_grad, a.bias_partial + static_cast<size_t>(a.row_blocks + blockIdx.x) * F);
+}
+
+template <int F, bool NORM, int EPI>
+static gconv_status_t launch_spmm_t(SpmmArgs& a, hipStream_t stream) {
+  constexpr int RPW = RowShape<F>::RPW;
+  a.row_blocks = ceil_div(a.n, 4 * RPW);
+  const int seg_blocks = ceil_div(a.n_seg, 4);
+  const int grid = a.row_blocks + seg_blocks;
+  if (grid > 0) {
+    spmm_rows_kernel<F, NORM, EPI><<<grid, 256, 0, stream>>>(a);
+    GCONV_LAUNCH_CHECK();
+  }
+  if (a.n_long > 0) {
+    spmm_fixup_kernel<F, NORM, EPI><<<ceil_div(a.n_long, 4), 256, 0, stream>>>(a);
+    GCONV_LAUNCH_CHECK();
+  }
+  return GCONV_OK;
+}
+
+template <int F, bool NORM>
+static gconv_status_t launch_spmm_e(SpmmArgs& a, int epi, hipStream_t stream) {
+  switch (epi) {
+    case EPI_GENERIC: return launch_spmm_t<F, NORM, EPI_GENERIC>(a, stream);
+    case EPI_STORE:   return launch_spmm_t<F, NORM, EPI_STORE>(a, stream);
+    case EPI_FWD1:    return launch_spmm_t<F, NORM, EPI_FWD1>(a, stream);
+    case EPI_BWD1:    return launch_spmm_t<F, NORM, EPI_BWD1>(a, stream);
+  }
+  return GCONV_E_INVALID_ARG;
+}
+
+template <int F>
+static gconv_status_t launch_spmm_n(SpmmArgs& a, int epi, hipStream_t stream) {
+  return a.dis ? launch_spmm_e<F, true>(a, epi, stream) : launch_spmm_e<F, false>(a, epi, stream);
+}
+
+int spmm_bias_partial_rows(const gconv_csr_t* g, int width) {
+  const int rpw = kWave / (width / 4);
+  return ceil_div(g->num_nodes, 4 * rpw) + ceil_div(g->n_long, 4);
+}
+
+gconv_status_t launch_spmm(const gconv_csr_t* g, SpmmArgs a, int width, int epi,
+                           hipStream_t stream) {
+  a.n = g->num_nodes;
+  a.rowptr = g->rowptr;
+  a.col = g->col;
+  a.n_long = g->n_long;
+  a.n_seg = g->n_seg;
+  a.long_rows = g->long_rows;
+  a.long_seg_base = g->long_seg_base;
+  a.seg_long = g->seg_long;
+  if (a.n == 0) return GCONV_OK;
+  if (a.n_seg > 0 && !a.seg_partial) return GCONV_E_WORKSPACE;
+  switch (width) {
+    case 4:  return launch_spmm_n<4>(a, epi, stream);
+    case 8:  return launch_spmm_n<8>(a, epi, stream);
+    case 16: return launch_spmm_n<16>(a, epi, stream);
+    case 32: return launch_spmm_n<32>(a, epi, stream);
+    case 64: return launch_spmm_n<64>(a, epi, stream);
+  }
+  return GCONV_E_UNSUPPORTED;
+}
+
+}  // namespace gconv
+
+using namespace gconv;
+
+extern "C" size_t gconv_spmm_workspace_bytes(const gconv_csr_t* graph, int32_t width) {
+  if (!graph || width <= 0) return 0;
+  return align_up(static_cast<size_t>(graph->n_seg) * width * sizeof(float) + 16, 256);
+}
+
+extern "C" gconv_status_t gconv_spmm_csr_f32(const gconv_csr_t* graph, const float* dis,
+                                             const float* H, float* Y, int32_t width,
+                                             const float* bias, int32_t act, uint32_t flags,
+                                             void* workspace, size_t workspace_bytes,
+                                             gconv_stream_t stream) {
+  if (!graph || !graph->rowptr || (graph->nnz > 0 && !graph->col) || graph->num_nodes < 0)
+    return GCONV_E_INVALID_ARG;
+  if (graph->num_nodes == 0) return GCONV_OK;
+  if (!H || !Y) return GCONV_E_INVALID_ARG;
+  if (act < GCONV_ACT_NONE || act > GCONV_ACT_SILU) return GCONV_E_INVALID_ARG;
+  if (width != 4 && width != 8 && width != 16 && width != 32 && width != 64)
+    return GCONV_E_UNSUPPORTED;
+  if (!aligned16(H) || !aligned16(Y) || (bias && !aligned16(bias))) return GCONV_E_ALIGNMENT;
+  if (graph->n_seg > 0 &&
+      (!workspace || workspace_bytes < gconv_spmm_workspace_bytes(graph, width)))
+    return GCONV_E_WORKSPACE;
+  SpmmArgs a{};
+  a.dis = dis;
+  a.H = H;
+  a.Y = Y;
+  a.bias = bias;
+  a.act = act;
+  a.flags = flags;
+  a.rank = width;
+  a.seg_partial = static_cast<float*>(workspace);
+  return launch_spmm(graph, a, width, EPI_GENERIC, static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,107 @@
+"""Graph-sharded data parallelism for the adapter path (one process per GPU).
+
+The reference is single-process / single-device (``torch.device("cuda:0")``,
+``/root/reference/scripts/finetune_inductive_learning.py:179``); this module is
+new. Molecule batches are block-diagonal, so a batch is partitioned BY GRAPH
+across ranks with no halo and no data-path collective
+(``synth.shard_graphs``); the only exchange per optimizer step is one
+all-reduce of the trainable-parameter gradients.
+
+That set is small — adapters + head + norm affine params, ~29 k fp32 ≈ 116 KB
+for HIV / rank 8 (freeze policy ``src/models/inductive/gnn.py:230-241``) — so
+the all-reduce is latency-bound on xGMI: ONE flat bucket, ONE RCCL call per
+step. ``FlatGradBucket`` makes every ``p.grad`` a view into one contiguous
+buffer so no packing copy is needed before the collective.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_process_group_from_env(backend: Optional[str] = None) -> int:
+    """torchrun-style rendezvous (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).
+    Backend "nccl" is RCCL on ROCm; "gloo" is used for the CPU logic tests."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 or dist.is_initialized():
+        return world
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend=backend, rank=int(os.environ.get("RANK", "0")),
+                            world_size=world)
+    return world
+
+
+def adapter_trainable_parameters(model: torch.nn.Module) -> List[torch.nn.Parameter]:
+    """Trainable set under the reference's freeze rule: a parameter trains iff its
+    name contains 'adapter' or it belongs to the prediction head / a norm layer
+    (``gnn.py:230-241``; ``nodeformer.py:377-388``). Here: every parameter that
+    currently requires grad, in ``named_parameters`` order (identical on all ranks)."""
+    return [p for _, p in model.named_parameters() if p.requires_grad]
+
+
+class FlatGradBucket:
+    """One contiguous gradient buffer for a parameter list.
+
+    ``p.grad`` of every parameter is a view into ``self.flat``; autograd
+    accumulates into the views in place, so after ``backward()`` the bucket is
+    ready for a single ``all_reduce``."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("FlatGradBucket needs at least one parameter")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        for p in self.params:
+            if p.device != dev or p.dtype != dt:
+                raise ValueError("all bucketed parameters must share device and dtype")
+        self.offsets = []
+        total = 0
+        for p in self.params:
+            self.offsets.append(total)
+            total += p.numel()
+        self.flat = torch.zeros(total, dtype=dt, device=dev)
+        for p, off in zip(self.params, self.offsets):
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+
+    @property
+    def nbytes(self) -> int:
+        return self.flat.numel() * self.flat.element_size()
+
+    def zero_(self) -> None:
+        """Replaces ``optimizer.zero_grad()``: keeps the views, zeroes in one op."""
+        self.flat.zero_()
+
+    def all_reduce(self, average: bool = False, async_op: bool = False):
+        """Sum (or mean) of the bucket over all ranks: one collective per step.
+
+        With the reference's loss normalisation (sum over valid targets divided by
+        the batch's count, ``finetune_inductive_learning.py:62-63``) each rank should
+        divide by the GLOBAL count (see ``global_count``) and use ``average=False``."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return None
+        work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
+        if average and not async_op:
+            self.flat.div_(dist.get_world_size())
+        return work
+
+
+def global_count(local_count: torch.Tensor) -> torch.Tensor:
+    """All-reduced number of valid targets, so that per-shard losses are divided by
+    the count of the whole batch as the single-process reference does."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        local_count = local_count.clone()
+        dist.all_reduce(local_count, op=dist.ReduceOp.SUM)
+    return local_count
+
+
+def shard_bounds(num_graphs: int, rank: int, world: int):
+    """Contiguous [lo, hi) slice of graphs owned by ``rank``."""
+    return (num_graphs * rank) // world, (num_graphs * (rank + 1)) // world

@@ -1,0 +1,220 @@
+/*
+ * gconv_adapter.h — C ABI of the MI355X (gfx950) GConv-Adapter hot path.
+ *
+ * Drop-in boundary for the forward/backward of the reference's GConvAdapter
+ * (`/root/reference/src/finetune/gconv_adapter.py`). The reference is pure
+ * Python and has no FFI of its own; the arithmetic it calls lives in
+ * torch-geometric's `GCNConv` (construction `gconv_adapter.py:40-41`, call
+ * `gconv_adapter.py:92`). Every entry point below names the reference
+ * interface it replaces. `INTEGRATION.md` shows the ctypes binding a
+ * maintainer of the reference adds.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, POD structs; no torch / C++ types.
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`.
+ *   - the caller owns every buffer; nothing is allocated or freed here, and no
+ *     pointer is retained after a call returns.
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*). Only
+ *     gconv_graph_prep() and gconv_csr_equal() synchronise that stream (they
+ *     read a few counters back to the host); everything else is asynchronous
+ *     and hipGraph-capturable.
+ *   - return value: 0 = success, > 0 = a hipError_t, < 0 = GCONV_E_*.
+ *     No exceptions cross this boundary and no entry point aborts.
+ *   - fp32 data, int32 CSR indices, int64 COO `edge_index` (PyG layout:
+ *     row 0 = source j, row 1 = target i; messages flow j -> i).
+ *
+ * Rank-width buffers ("[N, Fp]"): the bottleneck rank r is padded to
+ * Fp = gconv_padded_rank(r) in {4, 8, 16, 32, 64}; rows are Fp floats,
+ * 16-byte aligned, columns >= r hold zeros.
+ */
+#ifndef GCONV_ADAPTER_H
+#define GCONV_ADAPTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCONV_ABI_VERSION 1
+
+typedef int32_t gconv_status_t;
+typedef void*   gconv_stream_t; /* hipStream_t */
+
+enum {
+  GCONV_OK              = 0,
+  GCONV_E_INVALID_ARG   = -1, /* null pointer, negative size, bad enum            */
+  GCONV_E_UNSUPPORTED   = -2, /* shape outside the compiled kernel set            */
+  GCONV_E_WORKSPACE     = -3, /* workspace_bytes smaller than *_workspace_bytes() */
+  GCONV_E_BAD_INDEX     = -4, /* edge_index entry outside [0, num_nodes)          */
+  GCONV_E_ALIGNMENT     = -5  /* a float buffer is not 16-byte aligned            */
+};
+
+/* non_linearity of the adapter (`gconv_adapter.py:44-51`) */
+enum { GCONV_ACT_NONE = 0, GCONV_ACT_RELU = 1, GCONV_ACT_SILU = 2 };
+
+/* rows with more than GCONV_LONG_ROW edges are split into segments of
+ * GCONV_SEG_EDGES edges that separate waves reduce (deterministic, no atomics) */
+#define GCONV_LONG_ROW  64
+#define GCONV_SEG_EDGES 128
+
+/* ------------------------------------------------------------------------- */
+/* Introspection                                                             */
+/* ------------------------------------------------------------------------- */
+int32_t     gconv_abi_version(void);
+const char* gconv_status_string(gconv_status_t status);
+/* Fp for a bottleneck rank r (0 if r is unsupported: r < 1 or r > 64). */
+int32_t     gconv_padded_rank(int32_t rank);
+
+/* ------------------------------------------------------------------------- */
+/* K0 graph preparation                                                      */
+/* replaces: PyG `gcn_norm` (add_remaining_self_loops + degree + deg^-1/2),  */
+/* which GCNConv re-runs on every conv call (2x per adapter per forward) for */
+/* the same `edge_index` — reached from `gconv_adapter.py:92`; and the       */
+/* implicit COO gather/scatter indexing of `MessagePassing.propagate`.       */
+/* ------------------------------------------------------------------------- */
+
+/* CSR view of the propagation operator (or of its transpose). Row i lists the
+ * source nodes j of the edges j -> i (duplicates kept, sorted by j). With
+ * `normalize`, pre-existing self-loops are removed and the unit self-loop of
+ * every node is IMPLICIT (not stored); the kernels add it. */
+typedef struct gconv_csr {
+  int32_t        num_nodes;
+  int32_t        nnz;           /* stored edges (after self-loop removal)     */
+  const int32_t* rowptr;        /* [num_nodes + 1]                            */
+  const int32_t* col;           /* [nnz]                                      */
+  int32_t        n_long;        /* rows with more than GCONV_LONG_ROW edges   */
+  int32_t        n_seg;         /* total GCONV_SEG_EDGES-edge segments        */
+  const int32_t* long_rows;     /* [n_long] row ids                           */
+  const int32_t* long_seg_base; /* [n_long] first segment of each long row    */
+  const int32_t* seg_long;      /* [n_seg]  segment -> index into long_rows   */
+} gconv_csr_t;
+
+typedef struct gconv_graph_info {
+  int32_t nnz;
+  int32_t n_long;
+  int32_t n_seg;
+  int32_t max_degree;
+  int32_t bad_index;   /* 1 if any edge endpoint was outside [0, num_nodes)   */
+  int32_t reserved[3];
+} gconv_graph_info_t;
+
+/* Upper bounds for the caller-allocated outputs of gconv_graph_prep(). */
+int64_t gconv_graph_max_long_rows(int64_t num_edges);
+int64_t gconv_graph_max_segments(int64_t num_edges);
+size_t  gconv_graph_prep_workspace_bytes(int64_t num_edges, int32_t num_nodes);
+
+/* Builds one CSR direction from a COO edge list.
+ *   transpose = 0: rows = targets (the forward operator S)
+ *   transpose = 1: rows = sources (S^T, used by the backward pass)
+ *   dis_out (nullable): deg^-1/2 of the looped in-degree, [num_nodes]; only
+ *     meaningful with normalize = 1 and transpose = 0 (S^T reuses it).
+ * Synchronises `stream` once to fill `info_host`. Returns GCONV_E_BAD_INDEX
+ * (outputs undefined) if an endpoint is out of range — never a device fault. */
+gconv_status_t gconv_graph_prep(const int64_t* edge_index, int64_t num_edges,
+                                int32_t num_nodes, int32_t normalize, int32_t transpose,
+                                int32_t* rowptr_out, int32_t* col_out, float* dis_out,
+                                int32_t* long_rows_out, int32_t* long_seg_base_out,
+                                int32_t* seg_long_out,
+                                void* workspace, size_t workspace_bytes,
+                                gconv_graph_info_t* info_host, gconv_stream_t stream);
+
+/* *equal_host = 1 iff both CSRs describe the same matrix (S == S^T test that
+ * lets the backward reuse the forward CSR). Synchronises `stream`. */
+gconv_status_t gconv_csr_equal(const int32_t* rowptr_a, const int32_t* col_a,
+                               const int32_t* rowptr_b, const int32_t* col_b,
+                               int32_t num_nodes, int32_t nnz,
+                               int32_t* flag_dev, int32_t* equal_host, gconv_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* K2 SpMM                                                                   */
+/* replaces: `MessagePassing.propagate` (index_select -> weight mul ->       */
+/* scatter_add) + `out + bias` of GCNConv.forward, reached from              */
+/* `gconv_adapter.py:92`.                                                    */
+/* ------------------------------------------------------------------------- */
+enum {
+  GCONV_SPMM_IN_PRESCALED = 1u, /* H rows are already multiplied by dis[row]  */
+  GCONV_SPMM_OUT_PRESCALE = 2u  /* multiply output rows by dis[row] (chaining) */
+};
+
+/* scratch floats needed by gconv_spmm_csr_f32 for long-row partial sums */
+size_t gconv_spmm_workspace_bytes(const gconv_csr_t* graph, int32_t width);
+
+/* Y = act(S * H + bias), S = A (dis == NULL) or D^-1/2 (A0 + I) D^-1/2.
+ * H, Y: [num_nodes, width] contiguous, width in {4, 8, 16, 32, 64}.
+ * bias: [width] or NULL. */
+gconv_status_t gconv_spmm_csr_f32(const gconv_csr_t* graph, const float* dis,
+                                  const float* H, float* Y, int32_t width,
+                                  const float* bias, int32_t act, uint32_t flags,
+                                  void* workspace, size_t workspace_bytes,
+                                  gconv_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* K1 / K3 skinny projections                                                */
+/* replaces: `GCNConv.lin` (bias-free nn.Linear) of conv_down / conv_up      */
+/* (`gconv_adapter.py:40-41`) and the residual / scalar tail                 */
+/* (`gconv_adapter.py:94-95,105-106`).                                       */
+/* ------------------------------------------------------------------------- */
+
+/* H0[N, Fp] = row_scale .* (X[N, d] * W_down[r, d]^T); row_scale nullable. */
+gconv_status_t gconv_gemm_down_f32(const float* x, const float* w_down, const float* row_scale,
+                                   float* h0, int32_t num_nodes, int32_t hidden, int32_t rank,
+                                   gconv_stream_t stream);
+
+/* out[N, d] = s * (P[N, Fp] * W_up[d, r]^T + b_up + (skip ? X : 0));
+ * b_up, scalar (device, 1 float) nullable. */
+gconv_status_t gconv_gemm_up_fused_f32(const float* p, const float* w_up, const float* b_up,
+                                       const float* scalar, const float* x, int32_t skip,
+                                       float* out, int32_t num_nodes, int32_t hidden,
+                                       int32_t rank, gconv_stream_t stream);
+
+/* ------------------------------------------------------------------------- */
+/* Whole adapter                                                             */
+/* ------------------------------------------------------------------------- */
+typedef struct gconv_adapter_params {
+  const float* w_down;  /* conv_down.lin.weight [rank, hidden]                */
+  const float* b_down;  /* conv_down.bias       [rank]         (nullable)     */
+  const float* w_up;    /* conv_up.lin.weight   [hidden, rank]                */
+  const float* b_up;    /* conv_up.bias         [hidden]       (nullable)     */
+  const float* scalar;  /* scalar [1], NULL when learnable_scalar = False     */
+  int32_t hidden;       /* d, multiple of 4, <= 1024                          */
+  int32_t rank;         /* r, 1..64                                           */
+  int32_t act;          /* GCONV_ACT_*                                        */
+  int32_t skip;         /* skip_connection                                    */
+} gconv_adapter_params_t;
+
+size_t gconv_adapter_fwd_workspace_bytes(const gconv_csr_t* graph, int32_t hidden, int32_t rank);
+size_t gconv_adapter_bwd_workspace_bytes(const gconv_csr_t* graph_t, int32_t hidden, int32_t rank);
+
+/* replaces: `GConvAdapter.forward` (`gconv_adapter.py:80-108`) for
+ * normalization='none':  out = s * (S act(S X Wd^T + bd) Wu^T + bu + X).
+ *   dis == NULL selects normalize=False.
+ *   saved_h  [N, Fp]: act output (row-scaled by dis when normalised), kept for backward
+ *   saved_h1 [N, Fp]: pre-activation, written only for GCONV_ACT_SILU (else may be NULL)
+ *   saved_p  [N, Fp]: P = S act(...), kept for backward                       */
+gconv_status_t gconv_adapter_fwd_f32(const gconv_csr_t* graph, const float* dis,
+                                     const gconv_adapter_params_t* params, const float* x,
+                                     float* out, float* saved_h, float* saved_h1, float* saved_p,
+                                     void* workspace, size_t workspace_bytes,
+                                     gconv_stream_t stream);
+
+/* replaces: the autograd backward of the same ops, entered from
+ * `loss.backward()` (`scripts/finetune_inductive_learning.py:66`,
+ * `scripts/finetune_transductive_learning.py:229`).
+ *   graph_t: CSR of S^T (the forward CSR when the edge list is symmetric)
+ *   grad_x nullable (skipped when x needs no gradient); grad_scalar nullable.
+ *   All grad outputs are overwritten (not accumulated).                      */
+gconv_status_t gconv_adapter_bwd_f32(const gconv_csr_t* graph_t, const float* dis,
+                                     const gconv_adapter_params_t* params, const float* x,
+                                     const float* grad_out, const float* saved_h,
+                                     const float* saved_h1, const float* saved_p,
+                                     float* grad_x, float* grad_w_down, float* grad_b_down,
+                                     float* grad_w_up, float* grad_b_up, float* grad_scalar,
+                                     void* workspace, size_t workspace_bytes,
+                                     gconv_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCONV_ADAPTER_H */

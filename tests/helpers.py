@@ -1,0 +1,96 @@
+"""Shared test helpers: golden loading and oracle <-> module plumbing."""
+from __future__ import annotations
+
+import os
+from typing import Dict
+
+import numpy as np
+import torch
+
+from oracle import pyg_restated as oracle
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PARAM_KEYS = ["conv_down.lin.weight", "conv_down.bias", "conv_up.lin.weight", "conv_up.bias",
+              "scalar", "normalization.weight", "normalization.bias"]
+RTOL = ATOL = 1e-5   # north_star tolerance, vs the fp64 oracle
+
+
+def flags_from_record(rec) -> oracle.AdapterFlags:
+    act, norm, scalar, skip, normalize = [str(v) for v in rec]
+    return oracle.AdapterFlags(non_linearity=act, normalization=norm,
+                               learnable_scalar=scalar == "True", skip_connection=skip == "True",
+                               normalize=normalize == "True")
+
+
+def load_golden(name: str) -> dict:
+    with np.load(os.path.join(GOLDEN, name)) as z:
+        return {k: z[k] for k in z.files}
+
+
+def golden_case(rec: dict, index=None) -> dict:
+    """Splits a golden record into flags / inputs / params / expected (torch tensors)."""
+    def get(k):
+        v = rec[k]
+        return v[index] if index is not None else v
+    flags = flags_from_record(get("flags"))
+    params = {}
+    for k in PARAM_KEYS:
+        if "param." + k not in rec:
+            continue
+        if k == "scalar" and not flags.learnable_scalar:
+            continue
+        if k.startswith("normalization") and flags.normalization == "none":
+            continue
+        params[k] = torch.from_numpy(np.asarray(get("param." + k)))
+    expected = {"out": torch.from_numpy(np.asarray(get("out"))),
+                "x": torch.from_numpy(np.asarray(get("grad.x")))}
+    for k in params:
+        expected[k] = torch.from_numpy(np.asarray(get("grad." + k)))
+    return dict(flags=flags, x=torch.from_numpy(np.asarray(get("x"))),
+                edge_index=torch.from_numpy(np.asarray(get("edge_index"))),
+                grad_out=torch.from_numpy(np.asarray(get("grad_out"))),
+                params=params, expected=expected)
+
+
+def build_module(ga, d: int, r: int, flags: oracle.AdapterFlags, params: Dict[str, torch.Tensor], device):
+    mod = ga.GConvAdapter(d, r, non_linearity=flags.non_linearity, normalization=flags.normalization,
+                          learnable_scalar=flags.learnable_scalar,
+                          skip_connection=flags.skip_connection, normalize=flags.normalize).to(device)
+    with torch.no_grad():
+        for k, v in params.items():
+            mod.get_parameter(k).copy_(v.float())
+    mod.train()
+    return mod
+
+
+def run_module(mod, x: torch.Tensor, edge_index: torch.Tensor, grad_out: torch.Tensor, device,
+               need_dx: bool = True):
+    xd = x.to(device).requires_grad_(need_dx)
+    out = mod(xd, edge_index.to(device))
+    mod.zero_grad(set_to_none=True)
+    out.backward(grad_out.to(device))
+    got = {"out": out.detach().cpu().double()}
+    if need_dx:
+        got["x"] = xd.grad.detach().cpu().double()
+    for k, p in mod.named_parameters():
+        got[k] = p.grad.detach().cpu().double()
+    return got
+
+
+def grad_atol(want: torch.Tensor, base: float = ATOL) -> float:
+    """Absolute tolerance for PARAMETER gradients. dW / db / ds are sums over all N
+    nodes with cancellation: an entry can be ~0 while the terms summed are O(max|dW|),
+    and fp32 accumulation error scales with the terms, not with the entry. So the
+    absolute term is taken relative to the tensor's scale: 1e-5 * max(1, max|want|).
+    `out` and `dX` (no reduction over nodes) keep the plain element-wise 1e-5."""
+    return base * max(1.0, float(want.abs().max())) if want.numel() else base
+
+
+def assert_close(got: torch.Tensor, want: torch.Tensor, what: str, rtol=RTOL, atol=ATOL):
+    want = want.double()
+    err = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    assert got.shape == want.shape, f"{what}: shape {tuple(got.shape)} != {tuple(want.shape)}"
+    bad = err > tol
+    assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.numel()} elements out of tolerance, "
+                           f"max abs err {err.max().item():.3e}, max |want| {want.abs().max().item():.3e}")

@@ -1,0 +1,364 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle — `-m gpu`.
+
+Tolerance: rtol = atol = 1e-5 against the fp64 oracle (north_star "within 1e-5
+fp32"; SURVEY.md §0.4 explains why the relative term is needed for
+unnormalised sums). Integer outputs of graph prep are compared exactly.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+import gconv_adapter_amd as ga
+from oracle import dense_ref
+from oracle import pyg_restated as oracle
+
+from helpers import (assert_close, build_module, golden_case, grad_atol, load_golden, run_module)
+
+pytestmark = pytest.mark.gpu
+
+
+# ---------------------------------------------------------------------------
+# K0 graph prep: exact integer parity with a numpy CSR build
+# ---------------------------------------------------------------------------
+def _numpy_csr(ei: np.ndarray, n: int, normalize: bool, transpose: bool):
+    src, dst = ei[0], ei[1]
+    if normalize:
+        keep = src != dst
+        src, dst = src[keep], dst[keep]
+    row, col = (src, dst) if transpose else (dst, src)
+    order = np.lexsort((col, row))
+    row, col = row[order], col[order]
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(rowptr, row + 1, 1)
+    return np.cumsum(rowptr), col
+
+
+def _random_graph(n, e, seed, symmetric=False, loops=True):
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randint(n, (e,), generator=g)
+    dst = torch.randint(n, (e,), generator=g)
+    if not loops:
+        keep = src != dst
+        src, dst = src[keep], dst[keep]
+    if symmetric:
+        src, dst = torch.cat([src, dst]), torch.cat([dst, src])
+    return torch.stack([src, dst])
+
+
+@pytest.mark.parametrize("normalize", [True, False])
+@pytest.mark.parametrize("n,e,symmetric", [(1, 0, False), (7, 0, False), (5, 9, False),
+                                           (300, 2000, True), (5000, 40000, False)])
+def test_graph_prep_matches_numpy(dev, n, e, symmetric, normalize):
+    ei = _random_graph(n, e, seed=n + e, symmetric=symmetric)
+    plan = ga.GraphPlan(ei.to(dev), n, normalize)
+    for transpose, csr in ((False, plan.fwd), (True, plan.bwd)):
+        rp, col = _numpy_csr(ei.numpy(), n, normalize, transpose)
+        assert csr.nnz == rp[-1]
+        np.testing.assert_array_equal(csr.rowptr.cpu().numpy(), rp)
+        np.testing.assert_array_equal(csr.col.cpu().numpy()[:csr.nnz], col)
+    if normalize:
+        rp, _ = _numpy_csr(ei.numpy(), n, True, False)
+        deg = np.diff(rp) + 1
+        np.testing.assert_allclose(plan.dis.cpu().numpy()[:n], deg.astype(np.float64) ** -0.5, rtol=2e-7)
+    if symmetric:
+        assert plan.symmetric and plan.bwd is plan.fwd
+
+
+def test_graph_prep_long_rows_and_segments(dev):
+    n = 2000
+    hub_src = torch.arange(1, 1500)
+    ei = torch.stack([torch.cat([hub_src, torch.tensor([5, 6, 7])]),
+                      torch.cat([torch.zeros(1499, dtype=torch.long), torch.tensor([9, 9, 9])])])
+    plan = ga.GraphPlan(ei.to(dev), n, True)
+    assert plan.fwd.n_long == 1 and plan.fwd.max_degree == 1499
+    assert plan.fwd.n_seg == -(-1499 // ga._lib.SEG_EDGES)
+    assert plan.fwd.long_rows.cpu()[0].item() == 0
+    assert not plan.symmetric and plan.bwd.n_long == 0
+
+
+def test_graph_prep_rejects_bad_index(dev):
+    ei = torch.tensor([[0, 1, 7], [1, 0, 2]])
+    with pytest.raises(RuntimeError, match="outside"):
+        ga.GraphPlan(ei.to(dev), 5, True)
+    with pytest.raises(RuntimeError, match="outside"):
+        ga.GraphPlan(torch.tensor([[0, -1], [1, 0]]).to(dev), 5, False)
+
+
+# ---------------------------------------------------------------------------
+# K2 SpMM vs oracle propagate
+# ---------------------------------------------------------------------------
+def _oracle_spmm(h64, ei, n, normalize, transpose=False):
+    if transpose:
+        S = dense_ref.propagation_matrix(ei.numpy(), n, normalize)
+        return torch.from_numpy(S.T @ h64.numpy())
+    if normalize:
+        e2, w = oracle.gcn_norm(ei, n, torch.float64)
+        return oracle.propagate(h64, e2, w, n)
+    return oracle.propagate(h64, ei, None, n)
+
+
+@pytest.mark.parametrize("width", [4, 8, 16, 32, 64])
+@pytest.mark.parametrize("normalize", [True, False])
+def test_spmm_matches_oracle(dev, width, normalize):
+    n = 700
+    ei = _random_graph(n, 4000, seed=width, symmetric=False)
+    # a hub row (> LONG_ROW edges, several segments) and an isolated tail
+    hub = torch.stack([torch.randint(n - 50, (400,), generator=torch.Generator().manual_seed(1)),
+                       torch.full((400,), 3)])
+    ei = torch.cat([ei[:, (ei[0] < n - 50) & (ei[1] < n - 50)], hub], dim=1)
+    h = torch.randn(n, width, generator=torch.Generator().manual_seed(2))
+    plan = ga.GraphPlan(ei.to(dev), n, normalize)
+    assert plan.fwd.n_long >= 1
+    for transpose in (False, True):
+        y = ga.spmm(plan, h.to(dev), transpose=transpose)
+        want = _oracle_spmm(h.double(), ei, n, normalize, transpose)
+        assert_close(y.cpu().double(), want, f"spmm F={width} norm={normalize} T={transpose}")
+
+
+def test_spmm_bias_act_and_prescale_flags(dev):
+    n, f = 257, 16
+    ei = _random_graph(n, 1500, seed=5)
+    h = torch.randn(n, f, generator=torch.Generator().manual_seed(6))
+    b = torch.randn(f, generator=torch.Generator().manual_seed(7))
+    plan = ga.GraphPlan(ei.to(dev), n, True)
+    want = _oracle_spmm(h.double(), ei, n, True) + b.double()
+    for act, fn in (("relu", torch.relu), ("silu", torch.nn.functional.silu), ("none", lambda t: t)):
+        y = ga.spmm(plan, h.to(dev), bias=b.to(dev), act=act)
+        assert_close(y.cpu().double(), fn(want), f"spmm act={act}")
+    # prescaled input / output chaining: dis * S(h) computed from dis*h
+    dis = plan.dis[:n]
+    y = ga.spmm(plan, (h.to(dev) * dis[:, None]), flags=ga._lib.SPMM_IN_PRESCALED | ga._lib.SPMM_OUT_PRESCALE)
+    want2 = _oracle_spmm(h.double(), ei, n, True) * dis.cpu().double()[:, None]
+    assert_close(y.cpu().double(), want2, "spmm prescaled chain")
+
+
+def test_spmm_is_bitwise_deterministic(dev):
+    b, _ = ga.synth.make_workload("pubmed")
+    n = b.num_nodes
+    plan = ga.GraphPlan(b.edge_index.to(dev), n, True)
+    h = torch.randn(n, 16, device=dev)
+    y0 = ga.spmm(plan, h)
+    for _ in range(3):
+        assert torch.equal(ga.spmm(plan, h), y0)
+
+
+# ---------------------------------------------------------------------------
+# K1 / K3 projections
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n,d,r", [(1, 8, 1), (17, 300, 4), (100, 300, 8), (333, 128, 32),
+                                   (64, 32, 16), (50, 64, 64), (1000, 300, 5), (40, 1024, 16)])
+def test_gemm_down_and_up(dev, n, d, r):
+    g = torch.Generator().manual_seed(n * d + r)
+    x = torch.randn(n, d, generator=g)
+    wd = torch.randn(r, d, generator=g) * 0.1
+    wu = torch.randn(d, r, generator=g) * 0.1
+    bu = torch.randn(d, generator=g)
+    scale = torch.rand(n, generator=g) + 0.5
+    s = torch.tensor([0.7])
+    h0 = ga.gemm_down(x.to(dev), wd.to(dev), scale.to(dev))
+    fp = h0.shape[1]
+    want = (x.double() @ wd.double().T) * scale.double()[:, None]
+    assert_close(h0[:, :r].cpu().double(), want, "gemm_down")
+    assert torch.count_nonzero(h0[:, r:]) == 0, "padding columns must be zero"
+    p = torch.zeros(n, fp)
+    p[:, :r] = torch.randn(n, r, generator=g)
+    out = ga.gemm_up_fused(p.to(dev), wu.to(dev), bu.to(dev), s.to(dev), x.to(dev), skip=True)
+    want = 0.7 * (p[:, :r].double() @ wu.double().T + bu.double() + x.double())
+    assert_close(out.cpu().double(), want, "gemm_up_fused")
+    out = ga.gemm_up_fused(p.to(dev), wu.to(dev), None, None, None, skip=False)
+    assert_close(out.cpu().double(), p[:, :r].double() @ wu.double().T, "gemm_up no-bias no-skip")
+
+
+# ---------------------------------------------------------------------------
+# Whole adapter vs golden fixtures (module surface, autograd backward)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["g1_path5_norm.npz", "g1_path5_raw.npz", "g2_molecules.npz",
+                                  "g3_transductive.npz"])
+def test_adapter_golden(dev, name):
+    case = golden_case(load_golden(name))
+    d = case["x"].shape[-1]
+    r = case["params"]["conv_down.lin.weight"].shape[0]
+    mod = build_module(ga, d, r, case["flags"], case["params"], dev)
+    got = run_module(mod, case["x"], case["edge_index"], case["grad_out"], dev)
+    for k, want in case["expected"].items():
+        assert_close(got[k], want, f"{name}:{k}", atol=1e-5 if k in ("out", "x") else grad_atol(want))
+
+
+def test_adapter_golden_flag_grid(dev):
+    rec = load_golden("g4_flags.npz")
+    for i in range(rec["x"].shape[0]):
+        case = golden_case(rec, i)
+        mod = build_module(ga, 16, 4, case["flags"], case["params"], dev)
+        got = run_module(mod, case["x"], case["edge_index"], case["grad_out"], dev)
+        for k, want in case["expected"].items():
+            atol = 1e-5 if k in ("out", "x") else grad_atol(want)
+            if case["flags"].normalization == "batch_norm" and k == "conv_up.bias":
+                # BatchNorm removes the column mean, so this gradient is exactly 0 in exact
+                # arithmetic; what is left is fp32 cancellation noise of torch's own BatchNorm
+                # backward (its output can be O(1e3) when the pre-norm std is small). Bound it
+                # by the noise the fp32 CPU oracle shows on the same case.
+                _, g32 = oracle.adapter_forward_backward(
+                    case["x"].float(), case["edge_index"],
+                    {kk: v.float() for kk, v in case["params"].items()}, case["flags"],
+                    case["grad_out"].float())
+                atol = 1e-5 + 20.0 * float((g32[k].double() - want).abs().max())
+            assert_close(got[k], want, f"g4[{i}] {case['flags']}:{k}", atol=atol)
+
+
+# ---------------------------------------------------------------------------
+# Whole adapter vs the oracle on seeded workloads of the benchmark shapes
+# ---------------------------------------------------------------------------
+def _check_workload(dev, batch, d, r, flags, seed=0, need_dx=True, rtol=1e-5, atol=1e-5):
+    params = {k: v.float().double() for k, v in oracle.init_params(d, r, flags, seed=seed).items()}
+    g = torch.randn(batch.x.shape, generator=torch.Generator().manual_seed(seed + 1))
+    want_out, want_grads = oracle.adapter_forward_backward(batch.x.double(), batch.edge_index, params,
+                                                           flags, g.double(), need_dx=need_dx)
+    mod = build_module(ga, d, r, flags, params, dev)
+    got = run_module(mod, batch.x, batch.edge_index, g, dev, need_dx=need_dx)
+    assert_close(got["out"], want_out, "out", rtol, atol)
+    for k, want in want_grads.items():
+        assert_close(got[k], want, f"grad {k}", rtol, atol if k == "x" else grad_atol(want, atol))
+
+
+@pytest.mark.parametrize("normalize", [True, False])
+def test_adapter_esol_batch(dev, normalize):
+    batch, cfg = ga.synth.make_workload("esol")
+    flags = oracle.AdapterFlags(learnable_scalar=True, normalize=normalize)
+    _check_workload(dev, batch, cfg["d"], cfg["r"], flags)
+
+
+@pytest.mark.parametrize("normalize", [True, False])
+def test_adapter_hiv_shard(dev, normalize):
+    batch, cfg = ga.synth.make_workload("hiv", graphs=128)
+    flags = oracle.AdapterFlags(learnable_scalar=True, normalize=normalize)
+    _check_workload(dev, batch, cfg["d"], cfg["r"], flags)
+
+
+def test_adapter_cora_3d_input(dev):
+    batch, cfg = ga.synth.make_workload("cora")
+    assert batch.x.dim() == 3
+    flags = oracle.AdapterFlags(learnable_scalar=True, normalize=True)
+    _check_workload(dev, batch, cfg["d"], cfg["r"], flags)
+
+
+def test_adapter_power_law_graph_rank32(dev):
+    # scaled-down S-arxiv: hubs with thousands of edges (long-row path), d=128, r=32
+    batch = ga.synth.arxiv_like(num_nodes=20_000, num_pairs=70_000, hidden=128, seed=3)
+    flags = oracle.AdapterFlags(learnable_scalar=True, normalize=True)
+    _check_workload(dev, batch, 128, 32, flags)
+
+
+def test_adapter_asymmetric_graph_uses_transposed_csr(dev):
+    n = 500
+    ei = _random_graph(n, 3000, seed=9, symmetric=False)
+    x = torch.randn(n, 64, generator=torch.Generator().manual_seed(10))
+    batch = ga.synth.GraphBatch(x=x, edge_index=ei, graph_ptr=torch.tensor([0, n]), num_graphs=1)
+    for normalize in (True, False):
+        for act in ("relu", "silu", "none"):
+            flags = oracle.AdapterFlags(non_linearity=act, learnable_scalar=True, normalize=normalize)
+            _check_workload(dev, batch, 64, 12, flags)
+
+
+def test_adapter_without_input_grad_and_without_skip(dev):
+    batch, cfg = ga.synth.make_workload("esol")
+    flags = oracle.AdapterFlags(learnable_scalar=False, skip_connection=False, normalize=True)
+    _check_workload(dev, batch, cfg["d"], cfg["r"], flags, need_dx=False)
+
+
+def test_adapter_edge_cases(dev):
+    # empty edge list, single node, all-isolated nodes
+    for n, ei in ((1, torch.zeros(2, 0, dtype=torch.long)), (6, torch.zeros(2, 0, dtype=torch.long)),
+                  (3, torch.tensor([[0, 0, 1], [0, 0, 1]]))):
+        x = torch.randn(n, 8, generator=torch.Generator().manual_seed(n))
+        batch = ga.synth.GraphBatch(x=x, edge_index=ei, graph_ptr=torch.tensor([0, n]), num_graphs=1)
+        for normalize in (True, False):
+            flags = oracle.AdapterFlags(learnable_scalar=True, normalize=normalize)
+            _check_workload(dev, batch, 8, 2, flags)
+
+
+def test_adapter_near_identity_at_reference_init(dev):
+    # reference init (gconv_adapter.py:65,73-78): W ~ N(0, 1e-5), b = 0, s = 1 -> out ~= x
+    batch, cfg = ga.synth.make_workload("esol")
+    mod = ga.GConvAdapter(cfg["d"], cfg["r"], learnable_scalar=True).to(dev)
+    x = batch.x.to(dev)
+    out = mod(x, batch.edge_index.to(dev))
+    assert (out - x).abs().max().item() < 1e-6
+
+
+def test_adapter_rejects_cpu_and_wrong_dtype(dev):
+    mod = ga.GConvAdapter(8, 2).to(dev)
+    ei = torch.tensor([[0, 1], [1, 0]])
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        mod(torch.randn(2, 8), ei)
+    with pytest.raises(RuntimeError, match="fp32"):
+        mod(torch.randn(2, 8, device=dev).double(), ei.to(dev))
+    with pytest.raises(RuntimeError):
+        ga.GConvAdapter(10, 2).to(dev)(torch.randn(2, 10, device=dev), ei.to(dev))  # d % 4 != 0
+
+
+def test_plan_cache_shared_across_adapters(dev):
+    batch, cfg = ga.synth.make_workload("esol")
+    ga.PLAN_CACHE.clear()
+    h0, m0 = ga.PLAN_CACHE.hits, ga.PLAN_CACHE.misses
+    ei = batch.edge_index.to(dev)
+    x = batch.x.to(dev)
+    mods = [ga.GConvAdapter(cfg["d"], cfg["r"]).to(dev) for _ in range(5)]
+    for m in mods:
+        x = m(x, ei)
+    assert ga.PLAN_CACHE.misses - m0 == 1 and ga.PLAN_CACHE.hits - h0 == 4
+    ei[0, 0] = ei[0, 0]  # in-place write bumps _version -> new plan
+    mods[0](x, ei)
+    assert ga.PLAN_CACHE.misses - m0 == 2
+
+
+# ---------------------------------------------------------------------------
+# Full benchmark size: size-independent properties (oracle too slow / fp64 too big)
+# ---------------------------------------------------------------------------
+def test_arxiv_scale_properties(dev):
+    batch, cfg = ga.synth.make_workload("arxiv")
+    n, d, r = batch.num_nodes, cfg["d"], cfg["r"]
+    ei = batch.edge_index.to(dev)
+    plan = ga.get_plan(ei, n, True)
+    assert plan.symmetric and plan.fwd.n_long > 0
+    g = torch.Generator().manual_seed(0)
+    h1 = torch.randn(n, r, generator=g).to(dev)
+    h2 = torch.randn(n, r, generator=g).to(dev)
+    # linearity of the SpMM
+    lhs = ga.spmm(plan, 2.0 * h1 - 3.0 * h2)
+    rhs = 2.0 * ga.spmm(plan, h1) - 3.0 * ga.spmm(plan, h2)
+    assert torch.allclose(lhs, rhs, rtol=1e-5, atol=1e-5)
+    # S is symmetric for this edge list: <S a, b> == <a, S b>
+    a, b = h1.double(), h2.double()
+    assert abs((ga.spmm(plan, h1).double() * b).sum() - (a * ga.spmm(plan, h2).double()).sum()).item() \
+        < 1e-6 * n
+    # constant vector: S 1 row sums equal dis_i * sum_j dis_j over the looped neighbourhood
+    ones = torch.ones(n, 4, device=dev)
+    rowsum = ga.spmm(plan, ones)[:, 0]
+    dis = plan.dis[:n]
+    dd = dis.double()
+    ref = dd * (torch.zeros(n, device=dev, dtype=torch.float64).index_add_(0, ei[1], dd[ei[0]]) + dd)
+    assert torch.allclose(rowsum.double(), ref, rtol=1e-5, atol=1e-6)
+    # module level: bitwise run-to-run determinism of forward and backward
+    mod = ga.GConvAdapter(d, r, learnable_scalar=True).to(dev)
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.normal_(0, 0.1)
+    x = batch.x.to(dev).requires_grad_(True)
+    gout = torch.randn(n, d, generator=g).to(dev)
+    outs = []
+    for _ in range(2):
+        mod.zero_grad(set_to_none=True)
+        x.grad = None
+        out = mod(x, ei)
+        out.backward(gout)
+        outs.append([out.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in mod.parameters()])
+    for t0, t1 in zip(*outs):
+        assert torch.equal(t0, t1)
+    # fp32 oracle in the reassociated order on the CPU (same math, 1e-5 bar at full size)
+    params = {k: v.detach().cpu() for k, v in mod.named_parameters()}
+    flags = oracle.AdapterFlags(learnable_scalar=True, normalize=True)
+    want = oracle.adapter_forward_reassociated(batch.x.double(), batch.edge_index,
+                                               {k: v.double() for k, v in params.items()}, flags)
+    assert_close(outs[0][0].cpu().double(), want, "arxiv-scale out")
