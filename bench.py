@@ -1,0 +1,319 @@
+#!/usr/bin/env python3
+"""GConv-Adapter hot-path benchmark (contract: see the task's bench.py section).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hiv|esol|...]
+
+One "step" = one pass of the adapter hot path over one collated batch, exactly
+what the adapters of one model forward+backward cost in the reference's train
+loop (`/root/reference/scripts/finetune_inductive_learning.py:43-67`):
+
+    graph prep for the (new) batch's edge_index      (K0, shared by all adapters)
+    A adapters forward, chained                       (A = adapters per model forward)
+    backward through all of them (dX + parameter grads)
+    [N > 1] one flat RCCL all-reduce of the adapter gradients
+
+through the product surface (`GConvAdapter` nn.Module -> autograd.Function ->
+C ABI -> HIP kernels). Inputs are resident in HBM before the timed region.
+
+Default workload: the per-GPU unit of BASELINE.json configs[2] — a 512-molecule
+HIV-like shard (d=300, r=8, 5 pre-adapters); N ranks process N shards (weak
+scaling; N=8 is the 4096-molecule batch of configs[2]). `--workload esol` is
+configs[1]; both are reported at N=1 (the other one under "extra").
+
+The JSON line also carries
+  roofline      the normalized-adjacency SpMM at S-arxiv scale (north_star's
+                roofline subject), timed live with HIP events on the launch stream
+  cpu_baseline  the oracle (PyG op order, fp32, autograd) on the host cores,
+                same workload, bounded sample            (rank 0, N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import gconv_adapter_amd as ga  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X spec (MI355X_MICROARCH.md chip table)
+HBM_MEASURED_GBS = 6290.0   # float4-copy achievable, same table
+
+
+# --------------------------------------------------------------------------- helpers
+def build_adapters(cfg: dict, normalize: bool, device) -> torch.nn.ModuleList:
+    mods = torch.nn.ModuleList([
+        ga.GConvAdapter(cfg["d"], cfg["r"], learnable_scalar=True, skip_connection=True,
+                        normalize=normalize) for _ in range(cfg["adapters"])]).to(device)
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():  # trained-scale weights (init scale would be a near-identity)
+        for p in mods.parameters():
+            p.copy_((torch.randn(p.shape, generator=g) * 0.1).to(device))
+        for m in mods:
+            m.scalar.fill_(1.0)
+    return mods
+
+
+def adapter_step(mods, x, ei, gout, bucket=None, fresh_graph=True):
+    """fwd + bwd of the adapter chain on one batch (+ gradient all-reduce)."""
+    if fresh_graph:
+        ga.PLAN_CACHE.clear()   # a new batch arrives every step in training
+    if bucket is not None:
+        bucket.zero_()
+    else:
+        for p in mods.parameters():
+            p.grad = None
+    h = x
+    for m in mods:
+        h = m(h, ei)
+    h.backward(gout)
+    if bucket is not None:
+        bucket.all_reduce()
+
+
+def timed_steps(fn, steps: int, warmup: int, world: int, device) -> float:
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def event_time_ms(fn, iters: int, warmup: int = 5) -> float:
+    """Average duration of `fn` (kernels on torch's current stream) via HIP events."""
+    for _ in range(warmup):
+        fn()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(iters):
+        fn()
+    stop.record()
+    stop.synchronize()
+    return start.elapsed_time(stop) / iters
+
+
+# --------------------------------------------------------------------------- roofline
+def spmm_algorithmic_bytes(n: int, nnz: int, f: int) -> int:
+    """rowptr + col + dis + read H + write Y, each touched once."""
+    return 4 * (n + 1) + 4 * nnz + 4 * n + 4 * n * f + 4 * n * f
+
+
+def adapter_algorithmic_bytes(n: int, nnz: int, d: int, r: int):
+    idx = 4 * (n + 1) + 4 * nnz + 4 * n
+    fwd = 2 * 4 * n * d + 6 * 4 * n * r + 2 * idx
+    bwd = 3 * 4 * n * d + 8 * 4 * n * r + 2 * idx
+    return fwd, bwd
+
+
+def measure_arxiv(device, iters: int = 50) -> dict:
+    """North-star roofline subject: D^-1/2 (A+I) D^-1/2 SpMM at rank 32 on S-arxiv,
+    plus one whole adapter fwd / bwd at the same scale."""
+    batch, cfg = ga.synth.make_workload("arxiv")
+    n, d, r = batch.num_nodes, cfg["d"], cfg["r"]
+    ei = batch.edge_index.to(device)
+    plan = ga.get_plan(ei, n, True)
+    nnz = plan.fwd.nnz
+    h = torch.randn(n, r, device=device)
+    y = torch.empty_like(h)
+    flags = ga._lib.SPMM_IN_PRESCALED | ga._lib.SPMM_OUT_PRESCALE  # the variant the adapter runs
+    lib = ga._lib.load()
+    ws = torch.empty(max(int(lib.gconv_spmm_workspace_bytes(plan.fwd.ref(), r)), 16),
+                     dtype=torch.uint8, device=device)
+    ms = event_time_ms(lambda: ga.spmm(plan, h, flags=flags, out=y, workspace=ws), iters)
+    b = spmm_algorithmic_bytes(n, nnz, r)
+    achieved = b / (ms * 1e-3) / 1e9
+    roof = {"bound": "hbm", "kernel": "spmm_rows_kernel<32,norm> (+ long-row fix-up)",
+            "workload": f"S-arxiv N={n} nnz={nnz} F={r} normalized",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "frac_of_measured_copy_peak": round(achieved / HBM_MEASURED_GBS, 4),
+            "algorithmic_bytes": b, "avg_launch_us": round(ms * 1e3, 2), "traffic": None}
+
+    mod = build_adapters(dict(d=d, r=r, adapters=1), True, device)[0]
+    x = batch.x.to(device).requires_grad_(True)
+    gout = torch.randn(n, d, device=device)
+    out = mod(x, ei)
+    fwd_ms = event_time_ms(lambda: mod(x, ei), 20)
+
+    def bwd():
+        out.backward(gout, retain_graph=True)
+    bwd_ms = event_time_ms(bwd, 20)
+    fb, bb = adapter_algorithmic_bytes(n, nnz, d, r)
+    extra = {"arxiv_adapter_fwd_us": round(fwd_ms * 1e3, 1), "arxiv_adapter_bwd_us": round(bwd_ms * 1e3, 1),
+             "arxiv_adapter_fwd_GBs": round(fb / (fwd_ms * 1e-3) / 1e9, 1),
+             "arxiv_adapter_bwd_GBs": round(bb / (bwd_ms * 1e-3) / 1e9, 1),
+             "arxiv_adapter_steps_per_s": round(1e3 / (fwd_ms + bwd_ms), 1)}
+    return {"roofline": roof, "extra": extra}
+
+
+# --------------------------------------------------------------------------- CPU baseline
+def host_cores() -> int:
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota
+    (os.cpu_count() reports the whole host and oversubscribes a container's share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(batch, cfg: dict, normalize: bool, budget_s: float = 20.0) -> dict:
+    """The oracle (PyG op order: linear -> gather -> scale -> index_add -> bias, gcn_norm
+    recomputed per conv, autograd backward) on the host cores. Checker code timed as the
+    baseline only — it is never on the product path."""
+    from oracle import pyg_restated as oracle
+    threads = host_cores()
+    torch.set_num_threads(threads)
+    flags = oracle.AdapterFlags(learnable_scalar=True, normalize=normalize)
+    g = torch.Generator().manual_seed(1)
+    params = []
+    for _ in range(cfg["adapters"]):
+        p = oracle.init_params(cfg["d"], cfg["r"], flags, dtype=torch.float32)
+        params.append({k: v.clone().requires_grad_(True) for k, v in p.items()})
+    x, ei = batch.x, batch.edge_index
+    gout = torch.randn(x.shape, generator=g)
+
+    def step():
+        h = x
+        for p in params:
+            h = oracle.adapter_forward(h, ei, p, flags)
+        for p in params:
+            for v in p.values():
+                v.grad = None
+        h.backward(gout)
+
+    step()
+    t0 = time.perf_counter()
+    step()
+    one = time.perf_counter() - t0
+    iters = int(max(3, min(200, budget_s / max(one, 1e-6))))
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": round(batch.num_graphs / dt, 1), "unit": "graphs/s", "cores": threads,
+            "kind": "port", "ms_per_step": round(dt * 1e3, 3),
+            "sample": f"{iters} steps of the same batch ({batch.num_graphs} graphs, "
+                      f"{cfg['adapters']} adapters fwd+bwd, PyG op order, fp32, torch CPU)"}
+
+
+# --------------------------------------------------------------------------- main
+def run_workload(name: str, normalize: bool, steps: int, warmup: int, rank: int, world: int,
+                 device, with_cpu: bool) -> dict:
+    batch, cfg = ga.synth.make_workload(name, seed=rank)
+    mods = build_adapters(cfg, normalize, device)
+    x = batch.x.to(device)
+    ei = batch.edge_index.to(device)
+    gout = torch.randn(x.shape, generator=torch.Generator().manual_seed(2)).to(device)
+    bucket = ga.dist.FlatGradBucket(list(mods.parameters())) if world > 1 else None
+    fresh = cfg["kind"] == "molecule"   # transductive graphs are static across steps
+    dt = timed_steps(lambda: adapter_step(mods, x, ei, gout, bucket, fresh), steps, warmup, world, device)
+    graphs_total = batch.num_graphs * world * steps
+    res = {"value": graphs_total / dt, "ms_per_step": dt / steps * 1e3, "cfg": cfg,
+           "nodes_per_rank": batch.num_nodes, "edges_per_rank": int(batch.edge_index.shape[1]),
+           "graphs_per_rank": batch.num_graphs}
+    if with_cpu:
+        res["cpu"] = cpu_baseline(batch, cfg, normalize)
+    return res
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="hiv", choices=sorted(ga.synth.WORKLOADS))
+    ap.add_argument("--normalize", type=int, default=1,
+                    help="1 = D^-1/2 (A+I) D^-1/2 (north_star subject); 0 = YAML default")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=device)
+    normalize = bool(args.normalize)
+    ga._lib.load()
+
+    solo = world == 1 and rank == 0
+    main_res = run_workload(args.workload, normalize, args.steps, args.warmup, rank, world, device,
+                            with_cpu=solo and not args.no_cpu_baseline)
+    line = {
+        "metric": "adapter fwd+bwd graphs/sec (molecule batches)",
+        "value": round(main_res["value"], 1),
+        "unit": "graphs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(main_res["ms_per_step"], 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"M-{args.workload}: {main_res['graphs_per_rank']} graphs/GPU "
+                               f"({main_res['nodes_per_rank']} nodes, {main_res['edges_per_rank']} edges), "
+                               f"d={main_res['cfg']['d']}, r={main_res['cfg']['r']}, "
+                               f"{main_res['cfg']['adapters']} adapters fwd+bwd incl. graph prep"
+                               + (" + flat RCCL grad all-reduce" if world > 1 else ""),
+                   "normalize": normalize, "sharding": f"by graph, {world} rank(s)",
+                   "surface": "GConvAdapter nn.Module -> C ABI -> HIP"},
+    }
+    if solo:
+        extra = {}
+        if "cpu" in main_res:
+            line["cpu_baseline"] = main_res["cpu"]
+            extra["speedup_vs_cpu"] = round(main_res["value"] / main_res["cpu"]["value"], 1)
+        if not args.no_extra:
+            ax = measure_arxiv(device)
+            line["roofline"] = ax["roofline"]
+            extra.update(ax["extra"])
+            other = "esol" if args.workload != "esol" else "hiv"
+            o = run_workload(other, normalize, max(20, args.steps // 2), args.warmup, rank, world,
+                             device, with_cpu=not args.no_cpu_baseline)
+            extra[f"{other}_graphs_per_s"] = round(o["value"], 1)
+            extra[f"{other}_ms_per_step"] = round(o["ms_per_step"], 4)
+            if "cpu" in o:
+                extra[f"{other}_cpu_graphs_per_s"] = o["cpu"]["value"]
+                extra[f"{other}_speedup_vs_cpu"] = round(o["value"] / o["cpu"]["value"], 1)
+        line["extra"] = extra
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,184 @@
+"""CPU tests of the host side (`-m "not gpu"`): module surface mirrors the reference,
+Hydra-style construction, the C-ABI library loads and exports every declared
+symbol, and the product path refuses to run without a HIP device."""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import gconv_adapter_amd as ga
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- constructor / state_dict surface (reference gconv_adapter.py:23-78) ----------------
+def test_default_kwargs_match_reference():
+    m = ga.GConvAdapter(hidden_size=300, bottleneck_size=16)
+    assert m.normalize is True and m.skip_connection is True
+    assert m.scalar is None and m.normalization is None
+    assert isinstance(m.act_fn, torch.nn.ReLU)
+
+
+def test_state_dict_keys_and_shapes():
+    m = ga.GConvAdapter(300, 8, learnable_scalar=True)
+    sd = m.state_dict()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {
+        "conv_down.lin.weight": (8, 300), "conv_down.bias": (8,),
+        "conv_up.lin.weight": (300, 8), "conv_up.bias": (300,), "scalar": (1,)}
+    assert "scalar" not in ga.GConvAdapter(300, 8).state_dict()
+    ln = ga.GConvAdapter(32, 4, normalization="layer_norm").state_dict()
+    assert "normalization.weight" in ln and "normalization.bias" in ln
+    bn = ga.GConvAdapter(32, 4, normalization="batch_norm").state_dict()
+    assert "normalization.running_mean" in bn
+    # parameter count 2rd + r + d + 1
+    assert sum(p.numel() for p in m.parameters()) == 2 * 8 * 300 + 8 + 300 + 1
+    assert all(isinstance(p, torch.nn.Parameter) for p in m.parameters())
+
+
+def test_near_identity_init():
+    torch.manual_seed(0)
+    m = ga.GConvAdapter(300, 16, learnable_scalar=True)
+    assert m.conv_down.lin.weight.abs().max() < 1e-4 and m.conv_down.lin.weight.std() > 1e-6
+    assert m.conv_up.lin.weight.abs().max() < 1e-4
+    assert torch.count_nonzero(m.conv_down.bias) == 0 and torch.count_nonzero(m.conv_up.bias) == 0
+    assert m.scalar.item() == 1.0
+
+
+def test_invalid_enums_raise_value_error_with_reference_messages():
+    with pytest.raises(ValueError, match="Invalid conv_type"):
+        ga.GConvAdapter(8, 2, conv_type="gin")
+    with pytest.raises(ValueError, match="Invalid non_linearity"):
+        ga.GConvAdapter(8, 2, non_linearity="gelu")
+    with pytest.raises(ValueError, match="Invalid normalization"):
+        ga.GConvAdapter(8, 2, normalization="group_norm")
+    for dead in ("sage", "gat"):        # dead code in the reference
+        with pytest.raises(NotImplementedError):
+            ga.GConvAdapter(8, 2, conv_type=dead)
+
+
+def test_load_state_dict_roundtrip_and_freeze_rule():
+    a = ga.GConvAdapter(32, 4, learnable_scalar=True)
+    b = ga.GConvAdapter(32, 4, learnable_scalar=True)
+    with torch.no_grad():
+        for p in a.parameters():
+            p.normal_()
+    b.load_state_dict(a.state_dict(), strict=True)
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
+    # the reference freezes by parameter NAME containing 'adapter' (gnn.py:230-241)
+    host = torch.nn.Module()
+    host.pre_adapters = torch.nn.ModuleDict({"0": a})
+    host.backbone = torch.nn.Linear(4, 4)
+    for name, p in host.named_parameters():
+        p.requires_grad = "adapter" in name
+    trainable = ga.dist.adapter_trainable_parameters(host)
+    assert len(trainable) == 5 and all(p.requires_grad for p in trainable)
+
+
+# ---- Hydra-style construction (gnn.py:79,82; configs/finetune/gconv_adapter.yaml) -------
+def test_yaml_schema_matches_reference_and_instantiates():
+    cfg = ga.load_finetune_config("gconv_adapter")
+    assert set(cfg) == {"adapter", "positions", "type"}
+    assert set(cfg["adapter"]) == {"_target_", "bottleneck_size", "conv_type", "learnable_scalar",
+                                   "non_linearity", "normalization", "normalize", "skip_connection"}
+    assert cfg["adapter"]["_target_"] == "gconv_adapter_amd.GConvAdapter"
+    assert cfg["positions"] == ["pre"] and cfg["type"] == "sequential"
+    m = ga.instantiate(cfg["adapter"], hidden_size=300)      # call-site kwarg, as add_adapter does
+    assert isinstance(m, ga.GConvAdapter)
+    assert m.hidden_size == 300 and m.bottleneck_size == 16
+    assert m.normalize is False and m.scalar is not None     # YAML overrides the ctor defaults
+
+
+def test_insertion_contract_moduledict_per_layer():
+    cfg = ga.load_finetune_config()
+    pre = torch.nn.ModuleDict()
+    for layer in range(5):
+        pre[str(layer)] = ga.instantiate(cfg["adapter"], hidden_size=300)
+    names = [n for n, _ in pre.named_parameters()]
+    assert "0.conv_down.lin.weight" in names and "4.scalar" in names
+
+
+# ---- no CPU product path ----------------------------------------------------------------
+def test_forward_on_cpu_raises_runtime_error():
+    m = ga.GConvAdapter(8, 2)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(torch.randn(3, 8), torch.tensor([[0, 1], [1, 2]]))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ga.GraphPlan(torch.tensor([[0, 1], [1, 2]]), 3, True)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "gconv-adapter_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f
+                assert "oracle/" not in text or f.endswith(".md"), f
+
+
+# ---- C ABI: library loads, every declared symbol is exported ------------------------------
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "gconv_adapter.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gconv_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    declared = _declared_functions()
+    assert len(declared) >= 16
+    lib = ctypes.CDLL(ga._lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/gconv_adapter.h but not exported"
+    assert sorted(ga._lib.SIGNATURES) == declared, "ctypes binding out of sync with the header"
+
+
+def test_library_host_only_entry_points():
+    lib = ga._lib.load()
+    assert lib.gconv_abi_version() == 1
+    assert [lib.gconv_padded_rank(r) for r in (0, 1, 4, 5, 8, 16, 17, 33, 64, 65)] == \
+        [0, 4, 4, 8, 8, 16, 32, 64, 64, 0]
+    assert b"workspace" in lib.gconv_status_string(-3)
+    assert lib.gconv_graph_max_segments(1000) >= 1000 // ga._lib.SEG_EDGES
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        ga._lib.check(-1, "x")
+
+
+def test_header_constants_match_binding():
+    text = open(os.path.join(ROOT, "include", "gconv_adapter.h")).read()
+    assert int(re.search(r"#define GCONV_LONG_ROW\s+(\d+)", text).group(1)) == ga._lib.LONG_ROW
+    assert int(re.search(r"#define GCONV_SEG_EDGES\s+(\d+)", text).group(1)) == ga._lib.SEG_EDGES
+
+
+# ---- synthetic workloads ---------------------------------------------------------------
+def test_molecule_batches_are_block_diagonal_and_symmetric():
+    b = ga.synth.molecule_batch("hiv", 64, seed=3)
+    ei = b.edge_index
+    sizes = b.graph_ptr[1:] - b.graph_ptr[:-1]
+    gid = torch.repeat_interleave(torch.arange(64), sizes)
+    assert (gid[ei[0]] == gid[ei[1]]).all() and (ei[0] != ei[1]).all()
+    fwd = set(zip(ei[0].tolist(), ei[1].tolist()))
+    assert all((t, s) in fwd for s, t in fwd)
+    assert sizes.min() >= 2 and sizes.max() <= 222
+
+
+def test_shard_graphs_partitions_the_batch():
+    b = ga.synth.molecule_batch("esol", 32, seed=1)
+    shards = [ga.synth.shard_graphs(b, r, 4) for r in range(4)]
+    assert sum(s.num_graphs for s in shards) == 32
+    assert sum(s.num_nodes for s in shards) == b.num_nodes
+    assert sum(s.edge_index.shape[1] for s in shards) == b.edge_index.shape[1]
+    assert torch.equal(torch.cat([s.x for s in shards]), b.x)
+    for s in shards:
+        assert s.edge_index.min() >= 0 and s.edge_index.max() < s.num_nodes
+
+
+def test_workload_shapes():
+    b, cfg = ga.synth.make_workload("esol")
+    assert b.num_graphs == 32 and 300 < b.num_nodes < 600 and cfg["r"] == 4
+    b, cfg = ga.synth.make_workload("cora")
+    assert b.x.shape == (1, 2708, 32) and cfg["r"] == 16
