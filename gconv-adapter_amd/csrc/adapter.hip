@@ -52,6 +52,7 @@ struct BwdWs {
   float* seg;
   float* part_ds1;
   float* part_bd;
+  float* part_bd2;  // stage-1 reduction of part_bd when it is tall
   float* part_wd;
   float* part_wu;
   float* part_cs;
@@ -73,10 +74,11 @@ static BwdWs carve_bwd(void* ws, const gconv_csr_t* gt, int d, int fp) {
   w.seg = c.take<float>(static_cast<size_t>(gt->n_seg) * fp);
   w.part_ds1 = c.take<float>(w.n_ds1);
   w.part_bd = c.take<float>(static_cast<size_t>(w.n_bd) * fp);
+  w.part_bd2 = c.take<float>(static_cast<size_t>(kReduceBlocks) * fp);
   w.part_wd = c.take<float>(static_cast<size_t>(w.geom.nparts) * fp * d);
   w.part_wu = c.take<float>(static_cast<size_t>(w.geom.nparts) * fp * d);
   w.part_cs = c.take<float>(static_cast<size_t>(w.geom.nparts) * d);
-  w.part_dsx = c.take<float>(static_cast<size_t>(w.geom.nparts) * w.geom.nchunks);
+  w.part_dsx = c.take<float>(static_cast<size_t>(w.geom.nparts) * w.geom.nchunks * w.geom.nslots);
   w.cs_tmp = c.take<float>(d);
   w.bytes = c.off;
   return w;
@@ -212,6 +214,10 @@ extern "C" gconv_status_t gconv_adapter_bwd_f32(const gconv_csr_t* graph_t, cons
     b2.act = p->act; b2.rank = r; b2.seg_partial = ws.seg; b2.bias_partial = ws.part_bd;
     st = launch_spmm(graph_t, b2, fp, EPI_BWD1, stream);
     if (st != GCONV_OK) return st;
+    if (ws.n_bd > 2 * kReduceBlocks) {  // tall partial array: parallel stage-1 column sums
+      st = launch_reduce_rows(ws.part_bd, ws.n_bd, fp, ws.part_bd2, stream);
+      if (st != GCONV_OK) return st;
+    }
 
     SpmmArgs b3{};
     b3.dis = dis; b3.H = ws.dh1; b3.Y = ws.dp; b3.rank = r; b3.seg_partial = ws.seg;
@@ -231,9 +237,11 @@ extern "C" gconv_status_t gconv_adapter_bwd_f32(const gconv_csr_t* graph_t, cons
   FinalizeArgs f{};
   f.part_wd = ws.part_wd; f.part_wu = ws.part_wu; f.part_cs = ws.part_cs;
   f.nparts = n > 0 ? ws.geom.nparts : 0;
-  f.part_dsx = ws.part_dsx; f.n_dsx = n > 0 ? ws.geom.nparts * ws.geom.nchunks : 0;
+  f.part_dsx = ws.part_dsx; f.n_dsx = n > 0 ? ws.geom.nparts * ws.geom.nchunks * ws.geom.nslots : 0;
   f.part_ds1 = ws.part_ds1; f.n_ds1 = n > 0 ? ws.n_ds1 : 0;
-  f.part_bd = ws.part_bd; f.n_bd = n > 0 ? ws.n_bd : 0;
+  const bool bd_staged = n > 0 && ws.n_bd > 2 * kReduceBlocks;
+  f.part_bd = bd_staged ? ws.part_bd2 : ws.part_bd;
+  f.n_bd = n > 0 ? (bd_staged ? kReduceBlocks : ws.n_bd) : 0;
   f.scalar = p->scalar; f.b_up = p->b_up; f.cs_tmp = ws.cs_tmp;
   f.g_wd = grad_w_down; f.g_bd = grad_b_down; f.g_wu = grad_w_up; f.g_bu = grad_b_up;
   f.g_s = grad_scalar;

@@ -52,6 +52,13 @@ __device__ __forceinline__ float silu_grad(float h) {
   return sig * (1.f + h * (1.f - sig));
 }
 
+// Wave index inside the workgroup as a provably wave-uniform (SGPR) value. Without the
+// readfirstlane hipcc treats `threadIdx.x >> 6` as divergent, turns every branch that
+// depends on it into an exec-masked one and fences each load under it with vmcnt(0).
+__device__ __forceinline__ int wave_id() {
+  return __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+}
+
 // D(16x16) += A(16x4) * B(4x16), exact fp32.
 //   A: lane l holds A[l & 15][l >> 4];  B: lane l holds B[l >> 4][l & 15]
 //   D: lane l, reg m holds D[4 * (l >> 4) + m][l & 15]

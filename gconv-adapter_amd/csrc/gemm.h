@@ -75,4 +75,9 @@ struct FinalizeArgs {
 };
 gconv_status_t launch_finalize(const FinalizeArgs& a, hipStream_t stream);
 
+// [rows, width] -> [kReduceBlocks, width] column sums in a fixed order (width in 4..64)
+constexpr int kReduceBlocks = 32;
+gconv_status_t launch_reduce_rows(const float* in, int rows, int width, float* out,
+                                  hipStream_t stream);
+
 }  // namespace gconv

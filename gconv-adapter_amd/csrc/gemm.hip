@@ -20,6 +20,8 @@
 //       contract over nodes (dW^T = Z^T M; k-step m, MFMA c uses component c)
 //       and (ii) the element-wise operand of products that output [node, col]
 //       tiles (D register m of MFMA c is element (i0 + 4 t + m, 64 J + 4 jj + c)).
+#include <cstdlib>
+
 #include "gemm.h"
 
 namespace gconv {
@@ -27,63 +29,98 @@ namespace gconv {
 // ===========================================================================
 // K1 / B1: out[N, Fp] = epilogue(X[N, d] * Wt[d, Fp])
 // ===========================================================================
-size_t rowsA_lds_bytes(int d, int fp) {
-  const int nq = ceil_div(d, 16), ncb = fp >= 16 ? fp / 16 : 1;
-  return static_cast<size_t>(nq) * ncb * 64 * sizeof(f32x4);
-}
-
-int rowsA_grid(int n) {
-  const int nblk = ceil_div(n, 16);
-  int g = ceil_div(nblk, 4);
-  return g < 1 ? 1 : (g > 1024 ? 1024 : g);
-}
-
-template <int NCB>
+// NQ = compile-time number of 16-wide k-steps (d <= 16 NQ). The whole 16-node x d tile
+// of a block lives in NQ float4 registers per lane, used as a ring: as soon as k-step q of
+// the current block has fed its MFMAs, the same register is re-loaded with k-step q of the
+// wave's NEXT block, so NQ loads stay in flight per wave under straight-line code (no
+// branch between a load and its use: hipcc can then emit counted vmcnt waits).
+template <int NCB, int NQ>
 __global__ __launch_bounds__(256) void gemm_rowsA_kernel(RowsAArgs a) {
-  extern __shared__ f32x4 wl[];  // [nq][NCB][64] weight fragments
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nq = ceil_div(a.d, 16);
+  extern __shared__ f32x4 wl[];  // [NQ][NCB][64] weight fragments
+  const int lane = threadIdx.x & 63, wave = wave_id();
 
-  for (int idx = threadIdx.x; idx < nq * NCB * 64; idx += 256) {
-    const int ln = idx & 63, cb = (idx >> 6) % NCB, q = (idx >> 6) / NCB;
-    const int c = 16 * cb + (ln & 15), k0 = 16 * q + 4 * (ln >> 4);
-    f32x4 w;
-    for (int t = 0; t < 4; ++t) {
-      const int k = k0 + t;
+  // ---- stage Wt(k, c) into fragment order; global reads walk W in its storage order
+  {
+    float* wlf = reinterpret_cast<float*>(wl);
+    constexpr int kpad = NQ * 16, cpad = NCB * 16;
+    for (int idx = threadIdx.x; idx < kpad * cpad; idx += 256) {
+      int k, c;
+      if (a.mode == ROWSA_DOWN) { c = idx / kpad; k = idx % kpad; }   // W_down[c][k]: k fastest
+      else                      { k = idx / cpad; c = idx % cpad; }   // W_up[k][c]:   c fastest
       float v = 0.f;
       if (k < a.d && c < a.r)
         v = (a.mode == ROWSA_DOWN) ? a.W[static_cast<size_t>(c) * a.d + k]
                                    : a.W[static_cast<size_t>(k) * a.r + c];
-      w[t] = v;
+      const int q = k >> 4, kq = (k >> 2) & 3, t = k & 3, cb = c >> 4, ln = (c & 15) + 16 * kq;
+      wlf[((q * NCB + cb) * 64 + ln) * 4 + t] = v;
     }
-    wl[idx] = w;
   }
   __syncthreads();
 
   const float sval = (a.mode == ROWSA_DP && a.scalar) ? a.scalar[0] : 1.f;
   const int node = lane & 15, kq = lane >> 4;
   const int nblk = ceil_div(a.n, 16);
+  const int stride = gridDim.x * 4;
+  const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
   float ds_acc = 0.f;
 
-  for (int blk = blockIdx.x * 4 + wave; blk < nblk; blk += gridDim.x * 4) {
+  // per-lane column offsets of the NQ k-steps (clamped into the row) and their validity
+  int koff[NQ];
+  bool kok[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    koff[q] = min(16 * q + 4 * kq, a.d - 4);
+    kok[q] = 16 * q + 4 * kq < a.d;
+  }
+
+  // nullable operands: always-valid pointer + index 0, value selected afterwards (no branch)
+  const bool has_rs = a.row_scale != nullptr, has_p = a.P != nullptr;
+  const float* __restrict__ rsp = has_rs ? a.row_scale : a.X;
+  const float* __restrict__ pp = has_p ? a.P : a.X;
+
+  int blk = blockIdx.x * 4 + wave;
+  f32x4 x[NQ];
+  {
+    const float* xb = a.X + static_cast<size_t>(min(min(blk, nblk - 1) * 16 + node, a.n - 1)) * a.d;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) x[q] = ldg4(xb + koff[q]);
+  }
+  while (blk < nblk) {
     const int i0 = blk * 16;
-    const int rowA = min(i0 + node, a.n - 1);
-    const float* __restrict__ xrow = a.X + static_cast<size_t>(rowA) * a.d + 4 * kq;
+    // next block of this wave (clamped: the last prefetch of a wave is redundant, never invalid)
+    const int nb = min(blk + stride, nblk - 1);
+    const float* __restrict__ xn = a.X + static_cast<size_t>(min(nb * 16 + node, a.n - 1)) * a.d;
+    // Epilogue operands of THIS block first: vmcnt retires in order, so a small load issued
+    // after the ring refills could only be waited for by draining the whole prefetch.
+    float rs[4], pv[NCB][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int rowc = min(i0 + 4 * kq + m, a.n - 1);
+      const float v = rsp[has_rs ? rowc : 0];
+      rs[m] = has_rs ? v : 1.f;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const int cc = min(16 * cb + node, a.fp - 1);
+        const float pvv = pp[has_p ? static_cast<size_t>(rowc) * a.fp + cc : 0];
+        pv[cb][m] = has_p ? pvv : 0.f;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep those loads ahead of the ring refills
     f32x4 acc[NCB][2];
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) acc[cb][0] = acc[cb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll 4
-    for (int q = 0; q < nq; ++q) {
-      f32x4 xa = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (16 * q + 4 * kq < a.d) xa = ldg4(xrow + 16 * q);
+    for (int cb = 0; cb < NCB; ++cb) acc[cb][0] = acc[cb][1] = zero;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const f32x4 xv = kok[q] ? x[q] : zero;
+      x[q] = ldg4(xn + koff[q]);  // ring: refill this slot for the next block ...
+      __builtin_amdgcn_sched_barrier(0);  // ... BEFORE this k-step's MFMAs, not after the burst
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
         const f32x4 w = wl[(q * NCB + cb) * 64 + lane];
-        acc[cb][0] = mfma16(xa[0], w[0], acc[cb][0]);
-        acc[cb][1] = mfma16(xa[1], w[1], acc[cb][1]);
-        acc[cb][0] = mfma16(xa[2], w[2], acc[cb][0]);
-        acc[cb][1] = mfma16(xa[3], w[3], acc[cb][1]);
+        acc[cb][0] = mfma16(xv[0], w[0], acc[cb][0]);
+        acc[cb][1] = mfma16(xv[1], w[1], acc[cb][1]);
+        acc[cb][0] = mfma16(xv[2], w[2], acc[cb][0]);
+        acc[cb][1] = mfma16(xv[3], w[3], acc[cb][1]);
       }
     }
 
@@ -92,23 +129,18 @@ __global__ __launch_bounds__(256) void gemm_rowsA_kernel(RowsAArgs a) {
     for (int cb = 0; cb < NCB; ++cb) {
       const f32x4 res = acc[cb][0] + acc[cb][1];
       const int c = 16 * cb + node;
-      if (c < a.fp) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const int row = i0 + 4 * kq + m;
-          if (row < a.n) {
-            float v = res[m];
-            const size_t o = static_cast<size_t>(row) * a.fp + c;
-            if (a.mode == ROWSA_DP) {
-              if (a.P) ds_acc += v * a.P[o];
-              v *= sval;
-            }
-            if (a.row_scale) v *= a.row_scale[row];
-            a.out[o] = v;
-          }
+      for (int m = 0; m < 4; ++m) {
+        const int row = i0 + 4 * kq + m;
+        if (row < a.n && c < a.fp) {
+          float v = res[m];
+          ds_acc += v * pv[cb][m];
+          if (a.mode == ROWSA_DP) v *= sval;
+          a.out[static_cast<size_t>(row) * a.fp + c] = v * rs[m];
         }
       }
     }
+    blk += stride;
   }
 
   if (a.ds_partial) {  // block-wide sum in a fixed order
@@ -120,19 +152,54 @@ __global__ __launch_bounds__(256) void gemm_rowsA_kernel(RowsAArgs a) {
   }
 }
 
-gconv_status_t launch_rowsA(const RowsAArgs& a, hipStream_t stream) {
-  if (a.n == 0) return GCONV_OK;
-  const size_t lds = rowsA_lds_bytes(a.d, a.fp);
-  if (lds > 64 * 1024) return GCONV_E_UNSUPPORTED;
-  const int grid = rowsA_grid(a.n);
-  switch (a.fp >= 16 ? a.fp / 16 : 1) {
-    case 1: gemm_rowsA_kernel<1><<<grid, 256, lds, stream>>>(a); break;
-    case 2: gemm_rowsA_kernel<2><<<grid, 256, lds, stream>>>(a); break;
-    case 4: gemm_rowsA_kernel<4><<<grid, 256, lds, stream>>>(a); break;
+// k-step counts with a compiled kernel: d <= 16 * NQ is served by the next one up
+static int rowsA_nq(int d) {
+  static const int kNq[] = {2, 4, 8, 12, 16, 19, 24, 32, 48, 64};
+  const int need = ceil_div(d, 16);
+  for (int v : kNq)
+    if (need <= v) return v;
+  return 0;
+}
+
+size_t rowsA_lds_bytes(int d, int fp) {
+  const int nq = rowsA_nq(d), ncb = fp >= 16 ? fp / 16 : 1;
+  return static_cast<size_t>(nq) * ncb * 64 * sizeof(f32x4);
+}
+
+int rowsA_grid(int n) {
+  const int nblk = ceil_div(n, 16);
+  int g = ceil_div(nblk, 4);  // persistent: <= 3 workgroups per CU walk the node blocks
+  return g < 1 ? 1 : (g > 3 * kNumCU ? 3 * kNumCU : g);
+}
+
+template <int NCB>
+static gconv_status_t launch_rowsA_ncb(const RowsAArgs& a, int nq, int grid, size_t lds,
+                                       hipStream_t stream) {
+  switch (nq) {
+#define GCONV_ROWSA_CASE(NQ_) \
+    case NQ_: gemm_rowsA_kernel<NCB, NQ_><<<grid, 256, lds, stream>>>(a); break;
+    GCONV_ROWSA_CASE(2) GCONV_ROWSA_CASE(4) GCONV_ROWSA_CASE(8) GCONV_ROWSA_CASE(12)
+    GCONV_ROWSA_CASE(16) GCONV_ROWSA_CASE(19) GCONV_ROWSA_CASE(24) GCONV_ROWSA_CASE(32)
+    GCONV_ROWSA_CASE(48) GCONV_ROWSA_CASE(64)
+#undef GCONV_ROWSA_CASE
     default: return GCONV_E_UNSUPPORTED;
   }
   GCONV_LAUNCH_CHECK();
   return GCONV_OK;
+}
+
+gconv_status_t launch_rowsA(const RowsAArgs& a, hipStream_t stream) {
+  if (a.n == 0) return GCONV_OK;
+  const int nq = rowsA_nq(a.d);
+  const size_t lds = rowsA_lds_bytes(a.d, a.fp);
+  if (nq == 0 || lds > 64 * 1024) return GCONV_E_UNSUPPORTED;
+  const int grid = rowsA_grid(a.n);
+  switch (a.fp >= 16 ? a.fp / 16 : 1) {
+    case 1: return launch_rowsA_ncb<1>(a, nq, grid, lds, stream);
+    case 2: return launch_rowsA_ncb<2>(a, nq, grid, lds, stream);
+    case 4: return launch_rowsA_ncb<4>(a, nq, grid, lds, stream);
+  }
+  return GCONV_E_UNSUPPORTED;
 }
 
 // ===========================================================================
@@ -164,9 +231,24 @@ __device__ __forceinline__ void load_rank_frag(const float* __restrict__ Z, int 
   }
 }
 
-static int chunk_slots(int nchunks) {
-  if (nchunks >= 4) return 1;
-  return 4 / nchunks;  // 1 chunk -> 4 slots, 2 -> 2, 3 -> 1
+// waves of one workgroup = nchunks (64-column chunks of d) x nslots (node-block slots)
+static int chunk_slots(int nchunks, int target_waves) {
+  const int s = target_waves / nchunks;
+  return s < 1 ? 1 : s;
+}
+
+// Loads the four L-layout rows (i0 + 4 t + m, m = 0..3) of a [n, d] matrix.
+__device__ __forceinline__ void load_tile_L(const float* __restrict__ M, int i0, int t, int n,
+                                            int d, int colbase, bool colvalid, f32x4 (&v)[4]) {
+  // clamped address + select instead of a per-lane branch around the load (a branch makes
+  // hipcc wait vmcnt(0) after every load); n == 0 means "operand not used": all zeros.
+  const int col = min(colbase, d - 4);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int row = i0 + 4 * t + m;
+    const f32x4 x = ldg4(M + static_cast<size_t>(min(row, max(n, 1) - 1)) * d + col);
+    v[m] = (colvalid && row < n) ? x : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 }
 
 // ===========================================================================
@@ -175,7 +257,7 @@ static int chunk_slots(int nchunks) {
 template <int FP, int TB>
 __global__ __launch_bounds__(TB) void up_fwd_kernel(UpArgs a, int nchunks, int nslots) {
   constexpr int KS = FP / 4;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = wave_id();
   const int J = w % nchunks, slot = w / nchunks;
   const int jj = lane & 15, t = lane >> 4;
   const int colbase = 64 * J + 4 * jj;
@@ -195,17 +277,24 @@ __global__ __launch_bounds__(TB) void up_fwd_kernel(UpArgs a, int nchunks, int n
   if (colvalid && a.b_up) bu = ldg4(a.b_up + colbase);
 
   const int nblk = ceil_div(a.n, 16);
-  for (int blk = blockIdx.x * nslots + slot; blk < nblk; blk += gridDim.x * nslots) {
-    const int i0 = blk * 16;
-    f32x4 xv[4];
+  const int stride = gridDim.x * nslots;
+  int blk = blockIdx.x * nslots + slot;
+  f32x4 xv[4], xn[4];
+  float pa[KS], pn[KS];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int row = i0 + 4 * t + m;
-      xv[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (a.skip && colvalid && row < a.n) xv[m] = ldg4(a.X + static_cast<size_t>(row) * a.d + colbase);
+  for (int m = 0; m < 4; ++m) xv[m] = xn[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (blk < nblk) {
+    if (a.skip) load_tile_L(a.X, blk * 16, t, a.n, a.d, colbase, colvalid, xv);  // uniform branch
+    load_rank_frag<FP>(a.P, min(blk * 16 + jj, a.n - 1), t, pa);
+  }
+  while (blk < nblk) {
+    const int i0 = blk * 16, nxt = blk + stride;
+    {  // next block's operands fly while this block computes. Unconditional with a clamped
+       // block index: a conditional prefetch would force vmcnt(0) at every use.
+      const int nc = min(nxt, nblk - 1);
+      if (a.skip) load_tile_L(a.X, nc * 16, t, a.n, a.d, colbase, colvalid, xn);
+      load_rank_frag<FP>(a.P, min(nc * 16 + jj, a.n - 1), t, pn);
     }
-    float pa[KS];
-    load_rank_frag<FP>(a.P, min(i0 + jj, a.n - 1), t, pa);
     f32x4 acc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -224,6 +313,11 @@ __global__ __launch_bounds__(TB) void up_fwd_kernel(UpArgs a, int nchunks, int n
         stg4(a.out + static_cast<size_t>(row) * a.d + colbase, o);
       }
     }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) xv[m] = xn[m];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) pa[s] = pn[s];
+    blk = nxt;
   }
 }
 
@@ -244,10 +338,11 @@ gconv_status_t launch_up_fwd(const UpArgs& a, hipStream_t stream) {
   if (a.n == 0) return GCONV_OK;
   const int nchunks = ceil_div(a.d, 64);
   if (nchunks > 16) return GCONV_E_UNSUPPORTED;
-  const int nslots = chunk_slots(nchunks);
+  const int nslots = chunk_slots(nchunks, 4);
   const int nblk = ceil_div(a.n, 16);
+  // persistent: ~4 workgroups per CU, each wave slot walks node blocks with a 1-deep prefetch
   int grid = ceil_div(nblk, nslots);
-  if (grid > 2048) grid = 2048;
+  if (grid > 4 * kNumCU) grid = 4 * kNumCU;
   const int threads = 64 * nchunks * nslots;
   switch (a.fp) {
     case 4:  return launch_up_fwd_fp<4>(a, grid, threads, nchunks, nslots, stream);
@@ -262,27 +357,36 @@ gconv_status_t launch_up_fwd(const UpArgs& a, hipStream_t stream) {
 // ===========================================================================
 // B4: dX = T W_down + s G ; partials of dW_down^T = T^T X, dW_up^T = P^T G,
 //     colsum(G), sum(G . X)
+// One workgroup = nchunks x nslots waves (8 waves when d <= 512). Every wave keeps its
+// dW^T tiles in registers over all the node blocks it walks; at the end the slots of a
+// chunk are added through LDS in slot order (deterministic) and ONE partial per
+// workgroup goes to HBM.
 // ===========================================================================
+static size_t bwd_main_lds_bytes(int nchunks, int nslots, int fp) {
+  if (nslots == 1) return 0;
+  return (static_cast<size_t>(2) * fp + 1) * nchunks * 64 * sizeof(float);
+}
+
 BwdMainGeom bwd_main_geom(int n, int d) {
   BwdMainGeom g;
   g.nchunks = ceil_div(d, 64);
-  g.nslots = chunk_slots(g.nchunks);
+  g.nslots = chunk_slots(g.nchunks, 8);
   const int nblk = ceil_div(n, 16);
-  // >= 4 node blocks per wave slot amortise the partial write-out; <= 256 partials
+  // >= 4 node blocks per wave slot amortise the partial write-out; <= 2 workgroups per CU
   int grid = ceil_div(nblk, 4 * g.nslots);
-  const int cap = 256 / g.nslots;
-  if (grid > cap) grid = cap;
+  if (grid > 2 * kNumCU) grid = 2 * kNumCU;
   if (grid < 1) grid = 1;
   g.grid = grid;
-  g.nparts = grid * g.nslots;
+  g.nparts = grid;
   return g;
 }
 
 template <int FP, bool NEED_DX, int TB>
 __global__ __launch_bounds__(TB) void bwd_main_kernel(BwdMainArgs a, int nchunks, int nslots) {
+  extern __shared__ float red[];  // [2 FP + 1][nchunks][64] when nslots > 1
   constexpr int KS = FP / 4;
   constexpr int NCB = FP >= 16 ? FP / 16 : 1;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = wave_id();
   const int J = w % nchunks, slot = w / nchunks;
   const int jj = lane & 15, t = lane >> 4;
   const int colbase = 64 * J + 4 * jj;
@@ -311,35 +415,50 @@ __global__ __launch_bounds__(TB) void bwd_main_kernel(BwdMainArgs a, int nchunks
   float dsx = 0.f;
 
   const int nblk = ceil_div(a.n, 16);
-  for (int blk = blockIdx.x * nslots + slot; blk < nblk; blk += gridDim.x * nslots) {
-    const int i0 = blk * 16;
-    f32x4 gv[4], xv[4];
+  const int stride = gridDim.x * nslots;
+  int blk = blockIdx.x * nslots + slot;
+  f32x4 gv[4], xv[4], gn[4], xn[4];
+  if (blk < nblk) {
+    load_tile_L(a.G, blk * 16, t, a.n, a.d, colbase, colvalid, gv);
+    load_tile_L(a.X, blk * 16, t, a.n, a.d, colbase, colvalid, xv);
+  }
+  while (blk < nblk) {
+    const int i0 = blk * 16, nxt = blk + stride;
+    // Rank-width operands of THIS block first (L2-resident, small), the prefetch of the next
+    // block's G / X tiles after them: vmcnt retires in order, so the other way round every
+    // use of a fragment would drain the prefetch.
+    float at[4][NCB], ap[4][NCB];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int row = i0 + 4 * t + m;
-      gv[m] = xv[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (colvalid && row < a.n) {
-        gv[m] = ldg4(a.G + static_cast<size_t>(row) * a.d + colbase);
-        xv[m] = ldg4(a.X + static_cast<size_t>(row) * a.d + colbase);
+      const size_t rb = static_cast<size_t>(min(row, a.n - 1)) * FP;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const int rc = 16 * cb + jj;  // rank column this lane feeds as the A row
+        const float vt = a.T[rb + min(rc, FP - 1)], vp = a.P[rb + min(rc, FP - 1)];
+        const bool ok = row < a.n && rc < FP;
+        at[m][cb] = ok ? vt : 0.f;
+        ap[m][cb] = ok ? vp : 0.f;
       }
+    }
+    float ta[KS];
+    if constexpr (NEED_DX) load_rank_frag<FP>(a.T, min(i0 + jj, a.n - 1), t, ta);
+    __builtin_amdgcn_sched_barrier(0);  // keep the fragment loads ahead of the prefetch
+    {  // prefetch the next block's G and X tiles (unconditional, clamped block index)
+      const int nc = min(nxt, nblk - 1);
+      load_tile_L(a.G, nc * 16, t, a.n, a.d, colbase, colvalid, gn);
+      load_tile_L(a.X, nc * 16, t, a.n, a.d, colbase, colvalid, xn);
     }
 
     // contraction over the 16 nodes: k-step m covers nodes i0 + 4 t + m
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      const int row = i0 + 4 * t + m;
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
-        const int rc = 16 * cb + jj;  // rank column this lane feeds as the A row
-        float at = 0.f, ap = 0.f;
-        if (row < a.n && rc < FP) {
-          at = a.T[static_cast<size_t>(row) * FP + rc];
-          ap = a.P[static_cast<size_t>(row) * FP + rc];
-        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          awd[cb][c] = mfma16(at, xv[m][c], awd[cb][c]);
-          awu[cb][c] = mfma16(ap, gv[m][c], awu[cb][c]);
+          awd[cb][c] = mfma16(at[m][cb], xv[m][c], awd[cb][c]);
+          awu[cb][c] = mfma16(ap[m][cb], gv[m][c], awu[cb][c]);
         }
       }
       cs += gv[m];
@@ -347,8 +466,6 @@ __global__ __launch_bounds__(TB) void bwd_main_kernel(BwdMainArgs a, int nchunks
     }
 
     if (NEED_DX) {
-      float ta[KS];
-      load_rank_frag<FP>(a.T, min(i0 + jj, a.n - 1), t, ta);
       f32x4 acc[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -368,41 +485,100 @@ __global__ __launch_bounds__(TB) void bwd_main_kernel(BwdMainArgs a, int nchunks
         }
       }
     }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { gv[m] = gn[m]; xv[m] = xn[m]; }
+    blk = nxt;
   }
 
-  // ---- write this wave's partials
-  const int pid = blockIdx.x * nslots + slot;
-  if (colvalid) {
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) {
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int rk = 16 * cb + 4 * t + m;  // D row = rank index
-        if (rk < FP) {
-          const size_t o = (static_cast<size_t>(pid) * FP + rk) * a.d + colbase;
-          stg4(a.part_wd + o, f32x4{awd[cb][0][m], awd[cb][1][m], awd[cb][2][m], awd[cb][3][m]});
-          stg4(a.part_wu + o, f32x4{awu[cb][0][m], awu[cb][1][m], awu[cb][2][m], awu[cb][3][m]});
-        }
-      }
-    }
-  }
-  // colsum(G): add the four lane quarters (fixed order), quarter 0 stores
+  // colsum(G): add the four lane quarters (fixed order); every quarter then holds the sum
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     cs[c] += __shfl_xor(cs[c], 16);
     cs[c] += __shfl_xor(cs[c], 32);
   }
-  if (colvalid && t == 0) stg4(a.part_cs + static_cast<size_t>(pid) * a.d + colbase, cs);
   for (int off = 32; off > 0; off >>= 1) dsx += __shfl_xor(dsx, off);
-  if (lane == 0) a.part_dsx[static_cast<size_t>(pid) * nchunks + J] = dsx;
+  if (lane == 0) a.part_dsx[static_cast<size_t>(blockIdx.x) * nchunks * nslots + w] = dsx;
+
+  // ---- add the slots of each chunk in slot order, then one partial per workgroup
+  const int pid = blockIdx.x;
+  if (nslots > 1) {
+    float* rwd = red;                                   // [FP][nchunks * 64]
+    float* rwu = red + static_cast<size_t>(FP) * nchunks * 64;
+    float* rcs = red + static_cast<size_t>(2) * FP * nchunks * 64;
+    const int lc = J * 64 + 4 * jj;                     // column inside the LDS row
+    for (int s = 0; s < nslots; ++s) {
+      if (slot == s) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const int rk = 16 * cb + 4 * t + m;
+            if (rk < FP) {
+              float* pd = rwd + static_cast<size_t>(rk) * nchunks * 64 + lc;
+              float* pu = rwu + static_cast<size_t>(rk) * nchunks * 64 + lc;
+              f32x4 vd = f32x4{awd[cb][0][m], awd[cb][1][m], awd[cb][2][m], awd[cb][3][m]};
+              f32x4 vu = f32x4{awu[cb][0][m], awu[cb][1][m], awu[cb][2][m], awu[cb][3][m]};
+              if (s > 0) {
+                vd += *reinterpret_cast<f32x4*>(pd);
+                vu += *reinterpret_cast<f32x4*>(pu);
+              }
+              *reinterpret_cast<f32x4*>(pd) = vd;
+              *reinterpret_cast<f32x4*>(pu) = vu;
+            }
+          }
+        if (t == 0) {
+          f32x4 v = cs;
+          if (s > 0) v += *reinterpret_cast<f32x4*>(rcs + lc);
+          *reinterpret_cast<f32x4*>(rcs + lc) = v;
+        }
+      }
+      __syncthreads();
+    }
+    // cooperative, coalesced write-out of the reduced tiles
+    const int width = nchunks * 64;
+    for (int idx = threadIdx.x; idx < FP * width; idx += blockDim.x) {
+      const int rk = idx / width, col = idx % width;
+      if (col < a.d) {
+        const size_t o = (static_cast<size_t>(pid) * FP + rk) * a.d + col;
+        a.part_wd[o] = rwd[idx];
+        a.part_wu[o] = rwu[idx];
+      }
+    }
+    for (int col = threadIdx.x; col < width; col += blockDim.x)
+      if (col < a.d) a.part_cs[static_cast<size_t>(pid) * a.d + col] = rcs[col];
+  } else {
+    if (colvalid) {
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int rk = 16 * cb + 4 * t + m;  // D row = rank index
+          if (rk < FP) {
+            const size_t o = (static_cast<size_t>(pid) * FP + rk) * a.d + colbase;
+            stg4(a.part_wd + o, f32x4{awd[cb][0][m], awd[cb][1][m], awd[cb][2][m], awd[cb][3][m]});
+            stg4(a.part_wu + o, f32x4{awu[cb][0][m], awu[cb][1][m], awu[cb][2][m], awu[cb][3][m]});
+          }
+        }
+      }
+      if (t == 0) stg4(a.part_cs + static_cast<size_t>(pid) * a.d + colbase, cs);
+    }
+  }
 }
 
 template <int FP>
 static gconv_status_t launch_bwd_main_fp(const BwdMainArgs& a, const BwdMainGeom& g,
                                          hipStream_t stream) {
   const int threads = 64 * g.nchunks * g.nslots;
-#define GCONV_BWD_LAUNCH(DX, TB_) \
-  bwd_main_kernel<FP, DX, TB_><<<g.grid, threads, 0, stream>>>(a, g.nchunks, g.nslots)
+  const size_t lds = bwd_main_lds_bytes(g.nchunks, g.nslots, FP);
+  if (lds > 160 * 1024) return GCONV_E_UNSUPPORTED;
+#define GCONV_BWD_LAUNCH(DX, TB_)                                                           \
+  do {                                                                                      \
+    if (lds > 48 * 1024)                                                                    \
+      GCONV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_main_kernel<FP, DX, TB_>), \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,             \
+                                    static_cast<int>(lds)));                                \
+    bwd_main_kernel<FP, DX, TB_><<<g.grid, threads, lds, stream>>>(a, g.nchunks, g.nslots); \
+  } while (0)
   if (a.dX) {
     if (threads <= 256) GCONV_BWD_LAUNCH(true, 256);
     else if (threads <= 512) GCONV_BWD_LAUNCH(true, 512);
@@ -491,6 +667,38 @@ __global__ __launch_bounds__(256) void finalize_scalar_kernel(FinalizeArgs a) {
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) a.g_s[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// Stage 1 for tall partial arrays: [rows, width] -> [kReduceBlocks, width], fixed order.
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ in, int rows,
+                                                          int width, float* __restrict__ out) {
+  __shared__ float red[256];
+  const int c = threadIdx.x % width, lr = threadIdx.x / width, nlr = 256 / width;
+  const int per = ceil_div(rows, static_cast<int>(gridDim.x));
+  const int r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int r = r0 + lr;
+  for (; r + 3 * nlr < r1; r += 4 * nlr) {
+    a0 += in[static_cast<size_t>(r) * width + c];
+    a1 += in[static_cast<size_t>(r + nlr) * width + c];
+    a2 += in[static_cast<size_t>(r + 2 * nlr) * width + c];
+    a3 += in[static_cast<size_t>(r + 3 * nlr) * width + c];
+  }
+  for (; r < r1; r += nlr) a0 += in[static_cast<size_t>(r) * width + c];
+  red[threadIdx.x] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (lr == 0) {
+    float v = 0.f;
+    for (int k = 0; k < nlr; ++k) v += red[k * width + c];
+    out[static_cast<size_t>(blockIdx.x) * width + c] = v;
+  }
+}
+
+gconv_status_t launch_reduce_rows(const float* in, int rows, int width, float* out,
+                                  hipStream_t stream) {
+  reduce_rows_kernel<<<kReduceBlocks, 256, 0, stream>>>(in, rows, width, out);
+  GCONV_LAUNCH_CHECK();
+  return GCONV_OK;
 }
 
 gconv_status_t launch_finalize(const FinalizeArgs& a, hipStream_t stream) {

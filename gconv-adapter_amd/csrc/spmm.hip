@@ -84,7 +84,7 @@ template <int F>
 __device__ __forceinline__ void block_bias_partial(f32x4 bias_grad, float* part_row) {
   constexpr int LPR = RowShape<F>::LPR;
   __shared__ float red[4][F];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
 #pragma unroll
   for (int off = LPR; off < kWave; off <<= 1) {
     for (int k = 0; k < 4; ++k) bias_grad[k] += __shfl_xor(bias_grad[k], off);
@@ -107,7 +107,7 @@ template <int F, bool NORM, int EPI>
 __global__ __launch_bounds__(256) void spmm_rows_kernel(SpmmArgs a) {
   constexpr int LPR = RowShape<F>::LPR;
   constexpr int RPW = RowShape<F>::RPW;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
   const int sub = lane % LPR, grp = lane / LPR;
   const bool gather_scale = NORM && EPI == EPI_GENERIC && !(a.flags & GCONV_SPMM_IN_PRESCALED);
   const float* __restrict__ H = a.H;
@@ -180,7 +180,7 @@ template <int F, bool NORM, int EPI>
 __global__ __launch_bounds__(256) void spmm_fixup_kernel(SpmmArgs a) {
   constexpr int LPR = RowShape<F>::LPR;
   constexpr int RPW = RowShape<F>::RPW;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
   const int sub = lane % LPR, grp = lane / LPR;
   const int lr = blockIdx.x * 4 + wave;
   f32x4 bias_grad = zero4();
