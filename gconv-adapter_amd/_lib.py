@@ -18,6 +18,7 @@ SPMM_IN_PRESCALED = 1
 SPMM_OUT_PRESCALE = 2
 LONG_ROW = 64
 SEG_EDGES = 128
+TILE_NODES = 64
 
 _i32p = C.POINTER(C.c_int32)
 
@@ -37,15 +38,19 @@ class CsrStruct(C.Structure):
     ]
 
 
-class GraphInfo(C.Structure):
-    """``gconv_graph_info_t``"""
+class GraphStruct(C.Structure):
+    """``gconv_graph_t``"""
     _fields_ = [
-        ("nnz", C.c_int32),
-        ("n_long", C.c_int32),
-        ("n_seg", C.c_int32),
+        ("fwd", CsrStruct),
+        ("bwd", CsrStruct),
+        ("dis", C.c_void_p),
+        ("tile_ptr", C.c_void_p),
+        ("n_tiles", C.c_int32),
+        ("tile_nodes_max", C.c_int32),
+        ("symmetric", C.c_int32),
+        ("normalize", C.c_int32),
         ("max_degree", C.c_int32),
         ("bad_index", C.c_int32),
-        ("reserved", C.c_int32 * 3),
     ]
 
 
@@ -66,27 +71,24 @@ class AdapterParams(C.Structure):
 
 _vp, _sz, _i32, _i64, _u32 = C.c_void_p, C.c_size_t, C.c_int32, C.c_int64, C.c_uint32
 _csr_p = C.POINTER(CsrStruct)
+_graph_p = C.POINTER(GraphStruct)
 
 #: name -> (restype, argtypes); must list every function declared in include/gconv_adapter.h
 SIGNATURES = {
     "gconv_abi_version": (_i32, []),
     "gconv_status_string": (C.c_char_p, [_i32]),
     "gconv_padded_rank": (_i32, [_i32]),
-    "gconv_graph_max_long_rows": (_i64, [_i64]),
-    "gconv_graph_max_segments": (_i64, [_i64]),
-    "gconv_graph_prep_workspace_bytes": (_sz, [_i64, _i32]),
-    "gconv_graph_prep": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
-                                _vp, _sz, C.POINTER(GraphInfo), _vp]),
-    "gconv_csr_equal": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32p, _vp]),
+    "gconv_graph_build_bytes": (_sz, [_i64, _i32]),
+    "gconv_graph_build": (_i32, [_vp, _i64, _i32, _i32, _vp, _sz, _graph_p, _vp]),
     "gconv_spmm_workspace_bytes": (_sz, [_csr_p, _i32]),
     "gconv_spmm_csr_f32": (_i32, [_csr_p, _vp, _vp, _vp, _i32, _vp, _i32, _u32, _vp, _sz, _vp]),
     "gconv_gemm_down_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "gconv_gemm_up_fused_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
-    "gconv_adapter_fwd_workspace_bytes": (_sz, [_csr_p, _i32, _i32]),
-    "gconv_adapter_bwd_workspace_bytes": (_sz, [_csr_p, _i32, _i32]),
-    "gconv_adapter_fwd_f32": (_i32, [_csr_p, _vp, C.POINTER(AdapterParams), _vp, _vp, _vp, _vp,
+    "gconv_adapter_fwd_workspace_bytes": (_sz, [_graph_p, _i32, _i32]),
+    "gconv_adapter_bwd_workspace_bytes": (_sz, [_graph_p, _i32, _i32]),
+    "gconv_adapter_fwd_f32": (_i32, [_graph_p, C.POINTER(AdapterParams), _vp, _vp, _vp, _vp,
                                      _vp, _vp, _sz, _vp]),
-    "gconv_adapter_bwd_f32": (_i32, [_csr_p, _vp, C.POINTER(AdapterParams), _vp, _vp, _vp, _vp,
+    "gconv_adapter_bwd_f32": (_i32, [_graph_p, C.POINTER(AdapterParams), _vp, _vp, _vp, _vp,
                                      _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 

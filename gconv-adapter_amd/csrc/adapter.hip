@@ -15,6 +15,7 @@
 //             parameter gradients                          B5  finalize
 // (dis . = row scaling by deg^-1/2; without normalisation dis == 1 and the
 // implicit self-loop term disappears.)
+#include "fused_tile.h"
 #include "gemm.h"
 #include "spmm.h"
 
@@ -84,6 +85,27 @@ static BwdWs carve_bwd(void* ws, const gconv_csr_t* gt, int d, int fp) {
   return w;
 }
 
+// backward workspace of the fused tile path: one partial row per tile
+struct TileBwdWs {
+  float *part_wd, *part_wu, *part_cs, *part_bd, *part_ds1, *part_dsx, *cs_tmp, *part_bd2;
+  size_t bytes;
+};
+static TileBwdWs carve_bwd_tile(void* ws, int n_tiles, int d, int fp) {
+  Carver c(ws);
+  TileBwdWs w;
+  const size_t t = n_tiles;
+  w.part_wd = c.take<float>(t * fp * d);
+  w.part_wu = c.take<float>(t * fp * d);
+  w.part_cs = c.take<float>(t * d);
+  w.part_bd = c.take<float>(t * fp);
+  w.part_ds1 = c.take<float>(t);
+  w.part_dsx = c.take<float>(t);
+  w.cs_tmp = c.take<float>(d);
+  w.part_bd2 = c.take<float>(static_cast<size_t>(kReduceBlocks) * fp);
+  w.bytes = c.off;
+  return w;
+}
+
 static gconv_status_t check_common(const gconv_csr_t* g, const gconv_adapter_params_t* p) {
   if (!g || !p || !g->rowptr || (g->nnz > 0 && !g->col) || g->num_nodes < 0)
     return GCONV_E_INVALID_ARG;
@@ -119,26 +141,31 @@ extern "C" const char* gconv_status_string(gconv_status_t status) {
   return "unknown gconv status";
 }
 
-extern "C" size_t gconv_adapter_fwd_workspace_bytes(const gconv_csr_t* graph, int32_t hidden,
+extern "C" size_t gconv_adapter_fwd_workspace_bytes(const gconv_graph_t* graph, int32_t hidden,
                                                     int32_t rank) {
   (void)hidden;
   const int fp = padded_rank(rank);
   if (!graph || fp == 0) return 0;
-  return carve_fwd(nullptr, graph, fp).bytes;
+  if (tile_path_ok(graph, hidden, fp)) return 256;
+  return carve_fwd(nullptr, &graph->fwd, fp).bytes;
 }
 
-extern "C" size_t gconv_adapter_bwd_workspace_bytes(const gconv_csr_t* graph_t, int32_t hidden,
+extern "C" size_t gconv_adapter_bwd_workspace_bytes(const gconv_graph_t* graph, int32_t hidden,
                                                     int32_t rank) {
   const int fp = padded_rank(rank);
-  if (!graph_t || fp == 0 || hidden <= 0) return 0;
-  return carve_bwd(nullptr, graph_t, hidden, fp).bytes;
+  if (!graph || fp == 0 || hidden <= 0) return 0;
+  if (tile_path_ok(graph, hidden, fp)) return carve_bwd_tile(nullptr, graph->n_tiles, hidden, fp).bytes;
+  return carve_bwd(nullptr, &graph->bwd, hidden, fp).bytes;
 }
 
-extern "C" gconv_status_t gconv_adapter_fwd_f32(const gconv_csr_t* graph, const float* dis,
+extern "C" gconv_status_t gconv_adapter_fwd_f32(const gconv_graph_t* gr,
                                                 const gconv_adapter_params_t* p, const float* x,
                                                 float* out, float* saved_h, float* saved_h1,
                                                 float* saved_p, void* workspace,
                                                 size_t workspace_bytes, gconv_stream_t stream_) {
+  if (!gr) return GCONV_E_INVALID_ARG;
+  const gconv_csr_t* graph = &gr->fwd;
+  const float* dis = gr->dis;
   gconv_status_t st = check_common(graph, p);
   if (st != GCONV_OK) return st;
   const int n = graph->num_nodes, d = p->hidden, r = p->rank, fp = padded_rank(r);
@@ -149,9 +176,17 @@ extern "C" gconv_status_t gconv_adapter_fwd_f32(const gconv_csr_t* graph, const 
       (saved_h1 && !aligned16(saved_h1)) || !aligned16(workspace) ||
       (p->b_up && !aligned16(p->b_up)) || !aligned16(p->w_down))
     return GCONV_E_ALIGNMENT;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (tile_path_ok(gr, d, fp)) {  // block-diagonal batch: one fused launch
+    TileFwdArgs t{};
+    t.tile_ptr = gr->tile_ptr; t.rowptr = graph->rowptr; t.col = graph->col; t.dis = dis;
+    t.x = x; t.out = out; t.saved_h = saved_h; t.saved_h1 = saved_h1; t.saved_p = saved_p;
+    t.w_down = p->w_down; t.b_down = p->b_down; t.w_up = p->w_up; t.b_up = p->b_up;
+    t.scalar = p->scalar; t.d = d; t.r = r; t.fp = fp; t.act = p->act; t.skip = p->skip;
+    return launch_tile_fwd(t, gr->n_tiles, gr->tile_nodes_max, stream);
+  }
   const FwdWs ws = carve_fwd(workspace, graph, fp);
   if (workspace_bytes < ws.bytes) return GCONV_E_WORKSPACE;
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
 
   RowsAArgs k1{};
   k1.X = x; k1.W = p->w_down; k1.row_scale = dis; k1.out = ws.h0;
@@ -176,7 +211,7 @@ extern "C" gconv_status_t gconv_adapter_fwd_f32(const gconv_csr_t* graph, const 
   return launch_up_fwd(k3, stream);
 }
 
-extern "C" gconv_status_t gconv_adapter_bwd_f32(const gconv_csr_t* graph_t, const float* dis,
+extern "C" gconv_status_t gconv_adapter_bwd_f32(const gconv_graph_t* gr,
                                                 const gconv_adapter_params_t* p, const float* x,
                                                 const float* grad_out, const float* saved_h,
                                                 const float* saved_h1, const float* saved_p,
@@ -185,6 +220,9 @@ extern "C" gconv_status_t gconv_adapter_bwd_f32(const gconv_csr_t* graph_t, cons
                                                 float* grad_b_up, float* grad_scalar,
                                                 void* workspace, size_t workspace_bytes,
                                                 gconv_stream_t stream_) {
+  if (!gr) return GCONV_E_INVALID_ARG;
+  const gconv_csr_t* graph_t = &gr->bwd;
+  const float* dis = gr->dis;
   gconv_status_t st = check_common(graph_t, p);
   if (st != GCONV_OK) return st;
   const int n = graph_t->num_nodes, d = p->hidden, r = p->rank, fp = padded_rank(r);
@@ -195,9 +233,37 @@ extern "C" gconv_status_t gconv_adapter_bwd_f32(const gconv_csr_t* graph_t, cons
       (saved_h1 && !aligned16(saved_h1)) || (grad_x && !aligned16(grad_x)) ||
       !aligned16(workspace) || !aligned16(p->w_down))
     return GCONV_E_ALIGNMENT;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (n > 0 && tile_path_ok(gr, d, fp)) {  // block-diagonal batch: fused launch + finalize
+    const TileBwdWs tw = carve_bwd_tile(workspace, gr->n_tiles, d, fp);
+    if (workspace_bytes < tw.bytes) return GCONV_E_WORKSPACE;
+    TileBwdArgs t{};
+    t.tile_ptr = gr->tile_ptr; t.rowptr = graph_t->rowptr; t.col = graph_t->col; t.dis = dis;
+    t.x = x; t.g = grad_out; t.saved_h = saved_h; t.saved_h1 = saved_h1; t.saved_p = saved_p;
+    t.w_down = p->w_down; t.w_up = p->w_up; t.scalar = p->scalar; t.dx = grad_x;
+    t.part_wd = tw.part_wd; t.part_wu = tw.part_wu; t.part_cs = tw.part_cs;
+    t.part_bd = tw.part_bd; t.part_ds1 = tw.part_ds1; t.part_dsx = tw.part_dsx;
+    t.d = d; t.r = r; t.fp = fp; t.act = p->act; t.skip = p->skip;
+    t.want_ds = grad_scalar != nullptr;
+    st = launch_tile_bwd(t, gr->n_tiles, gr->tile_nodes_max, stream);
+    if (st != GCONV_OK) return st;
+    FinalizeArgs f{};
+    f.part_wd = tw.part_wd; f.part_wu = tw.part_wu; f.part_cs = tw.part_cs; f.nparts = gr->n_tiles;
+    f.part_dsx = tw.part_dsx; f.n_dsx = gr->n_tiles;
+    f.part_ds1 = tw.part_ds1; f.n_ds1 = gr->n_tiles;
+    f.part_bd = tw.part_bd; f.n_bd = gr->n_tiles;
+    if (gr->n_tiles > 2 * kReduceBlocks) {
+      st = launch_reduce_rows(tw.part_bd, gr->n_tiles, fp, tw.part_bd2, stream);
+      if (st != GCONV_OK) return st;
+      f.part_bd = tw.part_bd2; f.n_bd = kReduceBlocks;
+    }
+    f.scalar = p->scalar; f.b_up = p->b_up; f.cs_tmp = tw.cs_tmp;
+    f.g_wd = grad_w_down; f.g_bd = grad_b_down; f.g_wu = grad_w_up; f.g_bu = grad_b_up;
+    f.g_s = grad_scalar; f.d = d; f.r = r; f.fp = fp; f.skip = p->skip;
+    return launch_finalize(f, stream);
+  }
   const BwdWs ws = carve_bwd(workspace, graph_t, d, fp);
   if (workspace_bytes < ws.bytes) return GCONV_E_WORKSPACE;
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
 
   if (n > 0) {
     RowsAArgs b1{};

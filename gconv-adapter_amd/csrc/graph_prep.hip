@@ -1,61 +1,94 @@
-// K0 — graph preparation: COO edge list -> CSR (+ deg^-1/2, long-row segments).
+// K0 — graph build: COO edge list -> everything the kernels need, in one call.
 //
 // Replaces what PyG's gcn_norm recomputes on every GCNConv call
 // (add_remaining_self_loops, degree scatter, deg^-1/2; reached from
 // /root/reference/src/finetune/gconv_adapter.py:92) with a one-off build per
 // batch that all adapters of a model forward share.
 //
-// Pipeline (all on `stream`):
-//   1. make_keys   : key = (row << 32) | col, dropped / invalid edges -> row = N
-//   2. radix sort  : hipCUB DeviceRadixSort over 32 + bits(N) key bits
-//   3. build_csr   : rowptr from key run boundaries, col = low key word
+// Pipeline (all on `stream`, one host sync for symmetric edge lists):
+//   1. make_keys   : key = (row << b) | col, dropped / invalid edges -> row = N;
+//                    also marks, per node boundary, how many edges span it (+1/-1 diff)
+//   2. radix sort  : hipCUB, 32-bit keys when 2 bits(N) <= 32 (molecule batches), else 64-bit
+//   3. build_csr   : rowptr from key run boundaries, col = low key field
 //   4. row_stats   : dis = (deg + 1)^-1/2, long-row / segment lists, max degree
-//   5. one D2H copy of the counters + stream sync
+//   5. sym_check   : exact multiset test S == S^T by ranked binary search in the CSR
+//   6. tiles       : inclusive scan of the span diff -> edge-free boundaries -> tile starts
+//   7. D2H of the counters, sync; S^T (second sort) only when the test failed
 #include <hipcub/hipcub.hpp>
 
 #include "common.h"
 
 namespace gconv {
 
-enum { INFO_NNZ = 0, INFO_NLONG = 1, INFO_NSEG = 2, INFO_MAXDEG = 3, INFO_BAD = 4, INFO_WORDS = 8 };
+enum {
+  INFO_NNZ = 0, INFO_NLONG = 1, INFO_NSEG = 2, INFO_MAXDEG = 3, INFO_BAD = 4,
+  INFO_ASYM = 5, INFO_NOTILE = 6, INFO_TILEMAX = 7, INFO_WORDS = 8
+};
 
+template <typename K>
+struct KeyOps {
+  int shift;
+  __host__ __device__ K make(uint32_t row, uint32_t col) const {
+    return (static_cast<K>(row) << shift) | static_cast<K>(col);
+  }
+  __host__ __device__ uint32_t row(K k) const { return static_cast<uint32_t>(k >> shift); }
+  __host__ __device__ uint32_t col(K k) const {
+    return static_cast<uint32_t>(k & ((static_cast<K>(1) << shift) - 1));
+  }
+};
+
+static int index_bits(int32_t n) {  // bits needed to represent the values 0 .. n
+  int b = 1;
+  while ((static_cast<int64_t>(1) << b) <= n) ++b;
+  return b;
+}
+
+template <typename K>
 __global__ void make_keys_kernel(const int64_t* __restrict__ ei, int64_t E, int32_t n,
-                                 int normalize, int transpose, uint64_t* __restrict__ keys,
+                                 int normalize, int transpose, KeyOps<K> ko,
+                                 K* __restrict__ keys, int32_t* __restrict__ span,
                                  int32_t* __restrict__ info) {
   int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (e >= E) return;
-  int64_t s = ei[e], d = ei[E + e];
-  uint64_t key;
+  const int64_t s = ei[e], d = ei[E + e];
+  K key;
   if (s < 0 || s >= n || d < 0 || d >= n) {
     atomicOr(&info[INFO_BAD], 1);
-    key = static_cast<uint64_t>(n) << 32;
+    key = ko.make(n, 0);
   } else if (normalize && s == d) {
-    key = static_cast<uint64_t>(n) << 32;  // add_remaining_self_loops drops it
+    key = ko.make(n, 0);  // add_remaining_self_loops drops it
   } else {
-    uint64_t row = transpose ? s : d, col = transpose ? d : s;
-    key = (row << 32) | col;
+    key = transpose ? ko.make(static_cast<uint32_t>(s), static_cast<uint32_t>(d))
+                    : ko.make(static_cast<uint32_t>(d), static_cast<uint32_t>(s));
+    if (span && s != d) {  // boundaries lo+1 .. hi are crossed by this edge
+      const int lo = static_cast<int>(s < d ? s : d), hi = static_cast<int>(s < d ? d : s);
+      atomicAdd(&span[lo + 1], 1);
+      atomicAdd(&span[hi + 1], -1);
+    }
   }
   keys[e] = key;
 }
 
 // One thread per sorted position p in [0, E]: closes the rowptr entries of all
 // rows that start between key[p-1] and key[p]; copies the column.
-__global__ void build_csr_kernel(const uint64_t* __restrict__ keys, int64_t E, int32_t n,
+template <typename K>
+__global__ void build_csr_kernel(const K* __restrict__ keys, int64_t E, int32_t n, KeyOps<K> ko,
                                  int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
-                                 int32_t* __restrict__ info) {
+                                 int32_t* __restrict__ nnz_out) {
   int64_t p = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (p > E) return;
-  int64_t r_prev = (p == 0) ? -1 : static_cast<int64_t>(keys[p - 1] >> 32);
-  int64_t r_cur = (p == E) ? n : static_cast<int64_t>(keys[p] >> 32);
+  const int64_t r_prev = (p == 0) ? -1 : static_cast<int64_t>(ko.row(keys[p - 1]));
+  const int64_t r_cur = (p == E) ? n : static_cast<int64_t>(ko.row(keys[p]));
   for (int64_t r = r_prev + 1; r <= r_cur; ++r) rowptr[r] = static_cast<int32_t>(p);
-  if (p < E && r_cur < n) col[p] = static_cast<int32_t>(keys[p] & 0xffffffffu);
-  if (r_cur == n && r_prev < n) info[INFO_NNZ] = static_cast<int32_t>(p);
+  if (p < E && r_cur < n) col[p] = static_cast<int32_t>(ko.col(keys[p]));
+  if (r_cur == n && r_prev < n) *nnz_out = static_cast<int32_t>(p);
 }
 
 __global__ void row_stats_kernel(const int32_t* __restrict__ rowptr, int32_t n,
                                  float* __restrict__ dis, int32_t* __restrict__ long_rows,
                                  int32_t* __restrict__ long_seg_base,
-                                 int32_t* __restrict__ seg_long, int32_t* __restrict__ info) {
+                                 int32_t* __restrict__ seg_long, int32_t* __restrict__ counters) {
+  // counters: [0] n_long, [1] n_seg, [2] max degree
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int deg = 0;
   if (i < n) {
@@ -63,145 +96,254 @@ __global__ void row_stats_kernel(const int32_t* __restrict__ rowptr, int32_t n,
     if (dis) dis[i] = 1.0f / sqrtf(static_cast<float>(deg + 1));
     if (deg > GCONV_LONG_ROW) {
       int nseg = (deg + GCONV_SEG_EDGES - 1) / GCONV_SEG_EDGES;
-      int lr = atomicAdd(&info[INFO_NLONG], 1);
-      int base = atomicAdd(&info[INFO_NSEG], nseg);
+      int lr = atomicAdd(&counters[0], 1);
+      int base = atomicAdd(&counters[1], nseg);
       long_rows[lr] = i;
       long_seg_base[lr] = base;
       for (int k = 0; k < nseg; ++k) seg_long[base + k] = lr;
     }
   }
-  // wave-level max, one atomic per wave
   int m = deg;
   for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
-  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(&info[INFO_MAXDEG], m);
+  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(&counters[2], m);
 }
 
-__global__ void csr_equal_kernel(const int32_t* __restrict__ ra, const int32_t* __restrict__ ca,
-                                 const int32_t* __restrict__ rb, const int32_t* __restrict__ cb,
-                                 int32_t n, int32_t nnz, int32_t* __restrict__ differ) {
-  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  bool bad = false;
-  if (i <= n) bad |= ra[i] != rb[i];
-  if (i < nnz) bad |= ca[i] != cb[i];
-  if (bad) atomicOr(differ, 1);
+__device__ __forceinline__ int lower_bound_row(const int32_t* __restrict__ col, int lo, int hi,
+                                               int v) {
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (col[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
 }
 
-static int key_bits(int32_t n) {
-  int b = 1;
-  while ((static_cast<int64_t>(1) << b) <= n) ++b;
-  return 32 + b;
+// Exact test that the stored edge multiset equals its transpose: the k-th copy of
+// (i <- j) must be matched by the k-th copy of (j <- i). With equal cardinality on both
+// sides (same array) an injective match for every entry is a bijection.
+__global__ void sym_check_kernel(const int32_t* __restrict__ rowptr,
+                                 const int32_t* __restrict__ col, int32_t n,
+                                 const int32_t* __restrict__ nnz_p, int32_t* __restrict__ asym) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= *nnz_p) return;
+  // row of entry p: upper_bound in rowptr
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (rowptr[mid + 1] <= p) lo = mid + 1; else hi = mid;
+  }
+  const int i = lo, j = col[p];
+  const int k = p - lower_bound_row(col, rowptr[i], rowptr[i + 1], j);  // rank among duplicates
+  const int q = lower_bound_row(col, rowptr[j], rowptr[j + 1], i) + k;
+  if (q >= rowptr[j + 1] || col[q] != i) atomicOr(asym, 1);
 }
 
-struct PrepLayout {
-  size_t keys_a, keys_b, info, cub, total, cub_bytes;
+// tile_ptr[t] = last boundary q <= t * B that no edge spans (span_ps[q] == 0).
+__global__ void tile_start_kernel(const int32_t* __restrict__ span_ps, int32_t n, int ntiles,
+                                  int32_t* __restrict__ tile_ptr, int32_t* __restrict__ info) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > ntiles) return;
+  if (t == ntiles) { tile_ptr[t] = n; return; }
+  int q = t * GCONV_TILE_NODES, steps = 0;
+  while (q > 0 && span_ps[q] != 0 && steps < GCONV_TILE_BACK) { --q; ++steps; }
+  if (q > 0 && span_ps[q] != 0) atomicOr(&info[INFO_NOTILE], 1);
+  tile_ptr[t] = q;
+}
+
+__global__ void tile_max_kernel(const int32_t* __restrict__ tile_ptr, int ntiles,
+                                int32_t* __restrict__ info) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  int sz = (t < ntiles) ? tile_ptr[t + 1] - tile_ptr[t] : 0;
+  for (int off = 32; off > 0; off >>= 1) sz = max(sz, __shfl_xor(sz, off));
+  if ((threadIdx.x & 63) == 0 && sz > 0) atomicMax(&info[INFO_TILEMAX], sz);
+}
+
+// ---------------------------------------------------------------------------
+// arena layout
+// ---------------------------------------------------------------------------
+struct CsrSlots {
+  size_t rowptr, col, long_rows, long_seg_base, seg_long;
+};
+struct BuildLayout {
+  CsrSlots f, b;
+  size_t dis, tile_ptr, span, span_ps, keys_a, keys_b, info, cub, total, cub_bytes;
+  int ntiles;
 };
 
-static PrepLayout prep_layout(int64_t E, int32_t n) {
-  PrepLayout L{};
+static int64_t max_long_rows(int64_t E) { return E / (GCONV_LONG_ROW + 1) + 1; }
+static int64_t max_segments(int64_t E) { return E / GCONV_SEG_EDGES + max_long_rows(E) + 1; }
+
+static size_t cub_bytes_for(int64_t E, int32_t n) {
+  const int cnt = static_cast<int>(E > 0 ? E : 1);
+  size_t s64 = 0, s32 = 0, sc = 0;
+  hipcub::DeviceRadixSort::SortKeys(nullptr, s64, static_cast<const uint64_t*>(nullptr),
+                                    static_cast<uint64_t*>(nullptr), cnt, 0, 64, nullptr);
+  hipcub::DeviceRadixSort::SortKeys(nullptr, s32, static_cast<const uint32_t*>(nullptr),
+                                    static_cast<uint32_t*>(nullptr), cnt, 0, 32, nullptr);
+  hipcub::DeviceScan::InclusiveSum(nullptr, sc, static_cast<const int32_t*>(nullptr),
+                                   static_cast<int32_t*>(nullptr), n + 2, nullptr);
+  size_t m = s64 > s32 ? s64 : s32;
+  return m > sc ? m : sc;
+}
+
+static BuildLayout build_layout(int64_t E, int32_t n) {
+  BuildLayout L{};
   size_t off = 0;
-  size_t kb = align_up(static_cast<size_t>(E > 0 ? E : 1) * sizeof(uint64_t), 256);
-  L.keys_a = off; off += kb;
-  L.keys_b = off; off += kb;
-  L.info = off; off += 256;
-  size_t cub_bytes = 0;
-  hipcub::DeviceRadixSort::SortKeys(nullptr, cub_bytes, static_cast<const uint64_t*>(nullptr),
-                                    static_cast<uint64_t*>(nullptr), static_cast<int>(E > 0 ? E : 1),
-                                    0, key_bits(n), nullptr);
-  L.cub = off; L.cub_bytes = cub_bytes; off += align_up(cub_bytes + 256, 256);
+  auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes + 16, 256); return o; };
+  const size_t e1 = static_cast<size_t>(E > 0 ? E : 1);
+  auto csr = [&](CsrSlots& c) {
+    c.rowptr = take((static_cast<size_t>(n) + 1) * 4);
+    c.col = take(e1 * 4);
+    c.long_rows = take(static_cast<size_t>(max_long_rows(E)) * 4);
+    c.long_seg_base = take(static_cast<size_t>(max_long_rows(E)) * 4);
+    c.seg_long = take(static_cast<size_t>(max_segments(E)) * 4);
+  };
+  csr(L.f);
+  csr(L.b);
+  L.ntiles = ceil_div(n > 0 ? n : 1, GCONV_TILE_NODES);
+  L.dis = take((static_cast<size_t>(n) + 1) * 4);
+  L.tile_ptr = take((static_cast<size_t>(L.ntiles) + 1) * 4);
+  L.span = take((static_cast<size_t>(n) + 2) * 4);
+  L.span_ps = take((static_cast<size_t>(n) + 2) * 4);
+  L.keys_a = take(e1 * 8);
+  L.keys_b = take(e1 * 8);
+  L.info = take(64 * 4);
+  L.cub_bytes = cub_bytes_for(E, n);
+  L.cub = take(L.cub_bytes + 256);
   L.total = off;
   return L;
+}
+
+struct CsrOut {
+  int32_t *rowptr, *col, *long_rows, *long_seg_base, *seg_long;
+};
+
+// sort + CSR + row statistics for one direction; counters land in info[base .. base + 3]
+template <typename K>
+static gconv_status_t build_direction(const int64_t* ei, int64_t E, int32_t n, int normalize,
+                                      int transpose, int shift, char* arena, const BuildLayout& L,
+                                      const CsrOut& o, float* dis, int32_t* span, int32_t* info,
+                                      int base, hipStream_t stream) {
+  KeyOps<K> ko{shift};
+  K* keys_a = reinterpret_cast<K*>(arena + L.keys_a);
+  K* keys_b = reinterpret_cast<K*>(arena + L.keys_b);
+  const int T = 256;
+  const K* sorted = keys_a;
+  if (E > 0) {
+    make_keys_kernel<K><<<static_cast<unsigned>((E + T - 1) / T), T, 0, stream>>>(
+        ei, E, n, normalize, transpose, ko, keys_a, span, info);
+    GCONV_LAUNCH_CHECK();
+    size_t cub_bytes = L.cub_bytes;
+    GCONV_HIP(hipcub::DeviceRadixSort::SortKeys(arena + L.cub, cub_bytes, keys_a, keys_b,
+                                                static_cast<int>(E), 0, 2 * shift, stream));
+    sorted = keys_b;
+  }
+  build_csr_kernel<K><<<static_cast<unsigned>((E + 1 + T - 1) / T), T, 0, stream>>>(
+      sorted, E, n, ko, o.rowptr, o.col, info + base);
+  GCONV_LAUNCH_CHECK();
+  if (n > 0) {
+    row_stats_kernel<<<(n + T - 1) / T, T, 0, stream>>>(o.rowptr, n, dis, o.long_rows,
+                                                        o.long_seg_base, o.seg_long,
+                                                        info + base + 1);
+    GCONV_LAUNCH_CHECK();
+  }
+  return GCONV_OK;
 }
 
 }  // namespace gconv
 
 using namespace gconv;
 
-extern "C" int64_t gconv_graph_max_long_rows(int64_t num_edges) {
-  return num_edges / (GCONV_LONG_ROW + 1) + 1;
-}
-
-extern "C" int64_t gconv_graph_max_segments(int64_t num_edges) {
-  // every long row wastes at most one partially filled segment
-  return num_edges / GCONV_SEG_EDGES + gconv_graph_max_long_rows(num_edges) + 1;
-}
-
-extern "C" size_t gconv_graph_prep_workspace_bytes(int64_t num_edges, int32_t num_nodes) {
+extern "C" size_t gconv_graph_build_bytes(int64_t num_edges, int32_t num_nodes) {
   if (num_edges < 0 || num_nodes < 0) return 0;
-  return prep_layout(num_edges, num_nodes).total;
+  return build_layout(num_edges, num_nodes).total;
 }
 
-extern "C" gconv_status_t gconv_graph_prep(const int64_t* edge_index, int64_t num_edges,
-                                           int32_t num_nodes, int32_t normalize,
-                                           int32_t transpose, int32_t* rowptr_out,
-                                           int32_t* col_out, float* dis_out,
-                                           int32_t* long_rows_out, int32_t* long_seg_base_out,
-                                           int32_t* seg_long_out, void* workspace,
-                                           size_t workspace_bytes, gconv_graph_info_t* info_host,
-                                           gconv_stream_t stream_) {
+extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t num_edges,
+                                            int32_t num_nodes, int32_t normalize, void* arena_,
+                                            size_t arena_bytes, gconv_graph_t* g,
+                                            gconv_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (num_edges < 0 || num_nodes < 0 || !rowptr_out || !info_host || !workspace ||
-      !long_rows_out || !long_seg_base_out || !seg_long_out)
-    return GCONV_E_INVALID_ARG;
-  if (num_edges > 0 && (!edge_index || !col_out)) return GCONV_E_INVALID_ARG;
+  if (num_edges < 0 || num_nodes < 0 || !arena_ || !g) return GCONV_E_INVALID_ARG;
+  if (num_edges > 0 && !edge_index) return GCONV_E_INVALID_ARG;
   if (num_edges >= (static_cast<int64_t>(1) << 31) - 1) return GCONV_E_UNSUPPORTED;
-  PrepLayout L = prep_layout(num_edges, num_nodes);
-  if (workspace_bytes < L.total) return GCONV_E_WORKSPACE;
+  if (!aligned16(arena_)) return GCONV_E_ALIGNMENT;
+  const BuildLayout L = build_layout(num_edges, num_nodes);
+  if (arena_bytes < L.total) return GCONV_E_WORKSPACE;
+  char* arena = static_cast<char*>(arena_);
+  const int32_t n = num_nodes;
+  const int64_t E = num_edges;
 
-  char* ws = static_cast<char*>(workspace);
-  uint64_t* keys_a = reinterpret_cast<uint64_t*>(ws + L.keys_a);
-  uint64_t* keys_b = reinterpret_cast<uint64_t*>(ws + L.keys_b);
-  int32_t* info = reinterpret_cast<int32_t*>(ws + L.info);
-  void* cub_tmp = ws + L.cub;
+  auto slots = [&](const CsrSlots& c) {
+    return CsrOut{reinterpret_cast<int32_t*>(arena + c.rowptr), reinterpret_cast<int32_t*>(arena + c.col),
+                  reinterpret_cast<int32_t*>(arena + c.long_rows),
+                  reinterpret_cast<int32_t*>(arena + c.long_seg_base),
+                  reinterpret_cast<int32_t*>(arena + c.seg_long)};
+  };
+  const CsrOut of = slots(L.f), ob = slots(L.b);
+  float* dis = normalize ? reinterpret_cast<float*>(arena + L.dis) : nullptr;
+  int32_t* tile_ptr = reinterpret_cast<int32_t*>(arena + L.tile_ptr);
+  int32_t* span = reinterpret_cast<int32_t*>(arena + L.span);
+  int32_t* span_ps = reinterpret_cast<int32_t*>(arena + L.span_ps);
+  int32_t* info = reinterpret_cast<int32_t*>(arena + L.info);
+  // info words: [0..7] flags (enum above); forward counters at 16.., transposed at 24..
+  const int FWD = 16, BWD = 24;
 
-  GCONV_HIP(hipMemsetAsync(info, 0, INFO_WORDS * sizeof(int32_t), stream));
+  GCONV_HIP(hipMemsetAsync(info, 0, 64 * sizeof(int32_t), stream));
+  GCONV_HIP(hipMemsetAsync(span, 0, (static_cast<size_t>(n) + 2) * sizeof(int32_t), stream));
+  const int b = index_bits(n);
+  const bool k32 = 2 * b <= 32;
+  gconv_status_t st =
+      k32 ? build_direction<uint32_t>(edge_index, E, n, normalize, 0, b, arena, L, of, dis, span, info, FWD, stream)
+          : build_direction<uint64_t>(edge_index, E, n, normalize, 0, b, arena, L, of, dis, span, info, FWD, stream);
+  if (st != GCONV_OK) return st;
+
   const int T = 256;
-  const uint64_t* sorted = keys_a;
-  if (num_edges > 0) {
-    make_keys_kernel<<<static_cast<unsigned>((num_edges + T - 1) / T), T, 0, stream>>>(
-        edge_index, num_edges, num_nodes, normalize, transpose, keys_a, info);
+  if (E > 0) {
+    sym_check_kernel<<<static_cast<unsigned>((E + T - 1) / T), T, 0, stream>>>(
+        of.rowptr, of.col, n, info + FWD, info + INFO_ASYM);
     GCONV_LAUNCH_CHECK();
+  }
+  // component tiles
+  {
     size_t cub_bytes = L.cub_bytes;
-    GCONV_HIP(hipcub::DeviceRadixSort::SortKeys(cub_tmp, cub_bytes, keys_a, keys_b,
-                                                static_cast<int>(num_edges), 0,
-                                                key_bits(num_nodes), stream));
-    sorted = keys_b;
-  }
-  build_csr_kernel<<<static_cast<unsigned>((num_edges + 1 + T - 1) / T), T, 0, stream>>>(
-      sorted, num_edges, num_nodes, rowptr_out, col_out, info);
-  GCONV_LAUNCH_CHECK();
-  if (num_nodes > 0) {
-    row_stats_kernel<<<(num_nodes + T - 1) / T, T, 0, stream>>>(
-        rowptr_out, num_nodes, dis_out, long_rows_out, long_seg_base_out, seg_long_out, info);
+    GCONV_HIP(hipcub::DeviceScan::InclusiveSum(arena + L.cub, cub_bytes, span, span_ps, n + 2, stream));
+    tile_start_kernel<<<(L.ntiles + 1 + T - 1) / T, T, 0, stream>>>(span_ps, n, L.ntiles, tile_ptr, info);
+    GCONV_LAUNCH_CHECK();
+    tile_max_kernel<<<(L.ntiles + T - 1) / T, T, 0, stream>>>(tile_ptr, L.ntiles, info);
     GCONV_LAUNCH_CHECK();
   }
-  int32_t h[INFO_WORDS];
+  int32_t h[64];
   GCONV_HIP(hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, stream));
   GCONV_HIP(hipStreamSynchronize(stream));
-  info_host->nnz = h[INFO_NNZ];
-  info_host->n_long = h[INFO_NLONG];
-  info_host->n_seg = h[INFO_NSEG];
-  info_host->max_degree = h[INFO_MAXDEG];
-  info_host->bad_index = h[INFO_BAD];
-  info_host->reserved[0] = info_host->reserved[1] = info_host->reserved[2] = 0;
-  return h[INFO_BAD] ? GCONV_E_BAD_INDEX : GCONV_OK;
-}
+  if (h[INFO_BAD]) {
+    g->bad_index = 1;
+    return GCONV_E_BAD_INDEX;
+  }
 
-extern "C" gconv_status_t gconv_csr_equal(const int32_t* rowptr_a, const int32_t* col_a,
-                                          const int32_t* rowptr_b, const int32_t* col_b,
-                                          int32_t num_nodes, int32_t nnz, int32_t* flag_dev,
-                                          int32_t* equal_host, gconv_stream_t stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (!rowptr_a || !rowptr_b || !flag_dev || !equal_host || num_nodes < 0 || nnz < 0)
-    return GCONV_E_INVALID_ARG;
-  if (nnz > 0 && (!col_a || !col_b)) return GCONV_E_INVALID_ARG;
-  GCONV_HIP(hipMemsetAsync(flag_dev, 0, sizeof(int32_t), stream));
-  int64_t work = (static_cast<int64_t>(num_nodes) + 1 > nnz) ? num_nodes + 1 : nnz;
-  csr_equal_kernel<<<static_cast<unsigned>((work + 255) / 256), 256, 0, stream>>>(
-      rowptr_a, col_a, rowptr_b, col_b, num_nodes, nnz, flag_dev);
-  GCONV_LAUNCH_CHECK();
-  int32_t differ = 1;
-  GCONV_HIP(hipMemcpyAsync(&differ, flag_dev, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-  GCONV_HIP(hipStreamSynchronize(stream));
-  *equal_host = differ ? 0 : 1;
+  auto fill = [&](gconv_csr_t& c, const CsrOut& o, const int32_t* cnt) {
+    c.num_nodes = n; c.nnz = cnt[0];
+    c.rowptr = o.rowptr; c.col = o.col;
+    c.n_long = cnt[1]; c.n_seg = cnt[2];
+    c.long_rows = o.long_rows; c.long_seg_base = o.long_seg_base; c.seg_long = o.seg_long;
+  };
+  fill(g->fwd, of, h + FWD);
+  g->max_degree = h[FWD + 3];
+  g->symmetric = h[INFO_ASYM] ? 0 : 1;
+  if (g->symmetric) {
+    g->bwd = g->fwd;
+  } else {  // rare path (directed edge lists): second sort for S^T, second sync
+    st = k32 ? build_direction<uint32_t>(edge_index, E, n, normalize, 1, b, arena, L, ob, nullptr, nullptr, info, BWD, stream)
+             : build_direction<uint64_t>(edge_index, E, n, normalize, 1, b, arena, L, ob, nullptr, nullptr, info, BWD, stream);
+    if (st != GCONV_OK) return st;
+    GCONV_HIP(hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, stream));
+    GCONV_HIP(hipStreamSynchronize(stream));
+    fill(g->bwd, ob, h + BWD);
+  }
+  g->dis = dis;
+  g->tile_ptr = tile_ptr;
+  g->n_tiles = (h[INFO_NOTILE] || n == 0) ? 0 : L.ntiles;
+  g->tile_nodes_max = h[INFO_TILEMAX];
+  g->normalize = normalize ? 1 : 0;
+  g->bad_index = 0;
   return GCONV_OK;
 }

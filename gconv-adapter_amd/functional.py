@@ -54,9 +54,9 @@ class GConvAdapterFunction(torch.autograd.Function):
         saved_h1 = torch.empty(n, fp, dtype=torch.float32, device=x.device) if act == 2 else None
         params = _params_struct(w_down, b_down, w_up, b_up, scalar, act, skip)
         with torch.cuda.device(x.device):
-            ws_bytes = int(lib.gconv_adapter_fwd_workspace_bytes(plan.fwd.ref(), d, r))
+            ws_bytes = int(lib.gconv_adapter_fwd_workspace_bytes(plan.ref(), d, r))
             ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
-            st = lib.gconv_adapter_fwd_f32(plan.fwd.ref(), plan.dis_ptr, C.byref(params),
+            st = lib.gconv_adapter_fwd_f32(plan.ref(), C.byref(params),
                                            x.data_ptr(), out.data_ptr(), saved_h.data_ptr(),
                                            _lib.ptr(saved_h1), saved_p.data_ptr(), ws.data_ptr(),
                                            ws.numel(), _stream())
@@ -84,9 +84,9 @@ class GConvAdapterFunction(torch.autograd.Function):
         gs = torch.empty_like(scalar) if scalar is not None else None
         params = _params_struct(w_down, b_down, w_up, b_up, scalar, ctx.act, ctx.skip)
         with torch.cuda.device(dev):
-            ws_bytes = int(lib.gconv_adapter_bwd_workspace_bytes(plan.bwd.ref(), d, r))
+            ws_bytes = int(lib.gconv_adapter_bwd_workspace_bytes(plan.ref(), d, r))
             ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
-            st = lib.gconv_adapter_bwd_f32(plan.bwd.ref(), plan.dis_ptr, C.byref(params),
+            st = lib.gconv_adapter_bwd_f32(plan.ref(), C.byref(params),
                                            x.data_ptr(), g.data_ptr(), saved_h.data_ptr(),
                                            _lib.ptr(saved_h1), saved_p.data_ptr(), _lib.ptr(gx),
                                            gwd.data_ptr(), _lib.ptr(gbd), gwu.data_ptr(),

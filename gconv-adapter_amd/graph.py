@@ -20,46 +20,39 @@ from . import _lib
 
 
 class CsrView:
-    """Device arrays of one CSR direction + the ``gconv_csr_t`` that points at them."""
+    """Read-only view of one CSR direction inside a plan's arena (tensors are
+    materialised lazily: the kernels only need the ``gconv_csr_t``)."""
 
-    def __init__(self, num_nodes: int, info: _lib.GraphInfo, rowptr, col, long_rows,
-                 long_seg_base, seg_long):
-        self.rowptr, self.col = rowptr, col
-        self.long_rows, self.long_seg_base, self.seg_long = long_rows, long_seg_base, seg_long
-        self.nnz, self.n_long, self.n_seg = info.nnz, info.n_long, info.n_seg
-        self.max_degree = info.max_degree
-        self.struct = _lib.CsrStruct(
-            num_nodes, info.nnz, rowptr.data_ptr(), col.data_ptr(), info.n_long, info.n_seg,
-            long_rows.data_ptr(), long_seg_base.data_ptr(), seg_long.data_ptr())
+    def __init__(self, plan: "GraphPlan", struct: _lib.CsrStruct):
+        self._plan, self.struct = plan, struct
+        self.nnz, self.n_long, self.n_seg = struct.nnz, struct.n_long, struct.n_seg
 
     def ref(self):
         return C.byref(self.struct)
 
+    def _view(self, ptr: int, count: int, dtype=torch.int32) -> torch.Tensor:
+        return self._plan.arena_view(ptr, count, dtype)
 
-def _build_direction(lib, ei: torch.Tensor, n: int, normalize: bool, transpose: bool,
-                     want_dis: bool, ws: torch.Tensor, stream: int
-                     ) -> Tuple[CsrView, Optional[torch.Tensor]]:
-    dev, e = ei.device, ei.shape[1]
-    rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
-    col = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
-    n_long_cap = int(lib.gconv_graph_max_long_rows(e))
-    n_seg_cap = int(lib.gconv_graph_max_segments(e))
-    long_rows = torch.empty(n_long_cap, dtype=torch.int32, device=dev)
-    long_seg_base = torch.empty(n_long_cap, dtype=torch.int32, device=dev)
-    seg_long = torch.empty(n_seg_cap, dtype=torch.int32, device=dev)
-    dis = torch.empty(max(n, 1), dtype=torch.float32, device=dev) if want_dis else None
-    info = _lib.GraphInfo()
-    st = lib.gconv_graph_prep(ei.data_ptr(), e, n, int(normalize), int(transpose),
-                              rowptr.data_ptr(), col.data_ptr(), _lib.ptr(dis),
-                              long_rows.data_ptr(), long_seg_base.data_ptr(),
-                              seg_long.data_ptr(), ws.data_ptr(), ws.numel(),
-                              C.byref(info), stream)
-    _lib.check(st, "graph_prep")
-    return CsrView(n, info, rowptr, col, long_rows, long_seg_base, seg_long), dis
+    @property
+    def rowptr(self) -> torch.Tensor:
+        return self._view(self.struct.rowptr, self._plan.num_nodes + 1)
+
+    @property
+    def col(self) -> torch.Tensor:
+        return self._view(self.struct.col, self.nnz)
+
+    @property
+    def long_rows(self) -> torch.Tensor:
+        return self._view(self.struct.long_rows, self.n_long)
+
+    @property
+    def max_degree(self) -> int:
+        return self._plan.struct.max_degree
 
 
 class GraphPlan:
-    """Everything the kernels need to apply S and S^T for one ``edge_index``."""
+    """Everything the kernels need to apply S and S^T for one ``edge_index``:
+    ONE ``gconv_graph_build`` call, ONE device allocation (the arena)."""
 
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, normalize: bool):
         if edge_index.dim() != 2 or edge_index.size(0) != 2:
@@ -69,35 +62,47 @@ class GraphPlan:
         if not edge_index.is_cuda:
             raise RuntimeError("gconv_adapter_amd has no CPU path: edge_index must live on a HIP device")
         lib = _lib.load()
-        ei = edge_index.contiguous()
+        ei = edge_index if edge_index.is_contiguous() else edge_index.contiguous()
         self.num_nodes, self.normalize = int(num_nodes), bool(normalize)
         self.num_edges = int(ei.shape[1])
         self.device = ei.device
+        self.struct = _lib.GraphStruct()
         with torch.cuda.device(ei.device):
-            stream = torch.cuda.current_stream().cuda_stream
-            ws_bytes = int(lib.gconv_graph_prep_workspace_bytes(self.num_edges, self.num_nodes))
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=ei.device)
-            self.fwd, self.dis = _build_direction(lib, ei, self.num_nodes, self.normalize, False,
-                                                  self.normalize, ws, stream)
-            bwd, _ = _build_direction(lib, ei, self.num_nodes, self.normalize, True, False, ws,
-                                      stream)
-            self.symmetric = False
-            if bwd.nnz == self.fwd.nnz:
-                flag = torch.empty(1, dtype=torch.int32, device=ei.device)
-                equal = C.c_int32(0)
-                st = lib.gconv_csr_equal(self.fwd.rowptr.data_ptr(), self.fwd.col.data_ptr(),
-                                         bwd.rowptr.data_ptr(), bwd.col.data_ptr(),
-                                         self.num_nodes, self.fwd.nnz, flag.data_ptr(),
-                                         C.byref(equal), stream)
-                _lib.check(st, "csr_equal")
-                self.symmetric = bool(equal.value)
-            # S^T == S for symmetric edge lists (molecules emit both bond directions,
-            # the transductive script calls to_undirected): reuse the forward CSR.
-            self.bwd = self.fwd if self.symmetric else bwd
+            nbytes = int(lib.gconv_graph_build_bytes(self.num_edges, self.num_nodes))
+            self.arena = torch.empty(nbytes, dtype=torch.uint8, device=ei.device)
+            st = lib.gconv_graph_build(ei.data_ptr(), self.num_edges, self.num_nodes,
+                                       int(self.normalize), self.arena.data_ptr(), nbytes,
+                                       C.byref(self.struct), torch.cuda.current_stream().cuda_stream)
+        _lib.check(st, "graph_build")
+        self.symmetric = bool(self.struct.symmetric)
+        self.fwd = CsrView(self, self.struct.fwd)
+        # S^T == S for symmetric edge lists (molecules emit both bond directions, the
+        # transductive script calls to_undirected): the backward reuses the forward CSR.
+        self.bwd = self.fwd if self.symmetric else CsrView(self, self.struct.bwd)
+        self.n_tiles, self.tile_nodes_max = self.struct.n_tiles, self.struct.tile_nodes_max
+        self._ref = C.byref(self.struct)
+
+    def ref(self):
+        return self._ref
+
+    def arena_view(self, ptr: int, count: int, dtype) -> torch.Tensor:
+        off = ptr - self.arena.data_ptr()
+        nbytes = count * torch.empty((), dtype=dtype).element_size()
+        return self.arena[off:off + nbytes].view(dtype)
+
+    @property
+    def dis(self) -> Optional[torch.Tensor]:
+        if not self.normalize:
+            return None
+        return self.arena_view(self.struct.dis, max(self.num_nodes, 1), torch.float32)
+
+    @property
+    def tile_ptr(self) -> torch.Tensor:
+        return self.arena_view(self.struct.tile_ptr, self.n_tiles + 1, torch.int32)
 
     @property
     def dis_ptr(self) -> Optional[int]:
-        return _lib.ptr(self.dis) if self.normalize else None
+        return self.struct.dis if self.normalize else None
 
 
 class PlanCache:

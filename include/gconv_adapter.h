@@ -15,8 +15,8 @@
  *   - the caller owns every buffer; nothing is allocated or freed here, and no
  *     pointer is retained after a call returns.
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*). Only
- *     gconv_graph_prep() and gconv_csr_equal() synchronise that stream (they
- *     read a few counters back to the host); everything else is asynchronous
+ *     gconv_graph_build() synchronises that stream (it
+ *     reads a few counters back to the host); everything else is asynchronous
  *     and hipGraph-capturable.
  *   - return value: 0 = success, > 0 = a hipError_t, < 0 = GCONV_E_*.
  *     No exceptions cross this boundary and no entry point aborts.
@@ -91,41 +91,42 @@ typedef struct gconv_csr {
   const int32_t* seg_long;      /* [n_seg]  segment -> index into long_rows   */
 } gconv_csr_t;
 
-typedef struct gconv_graph_info {
-  int32_t nnz;
-  int32_t n_long;
-  int32_t n_seg;
-  int32_t max_degree;
-  int32_t bad_index;   /* 1 if any edge endpoint was outside [0, num_nodes)   */
-  int32_t reserved[3];
-} gconv_graph_info_t;
+/* Component tiles: molecule batches are block-diagonal, so the node range splits into
+ * contiguous tiles that no edge crosses. A tile is handled end-to-end by ONE workgroup
+ * (rank-width intermediates never leave LDS). Tiles start at the last edge-free boundary
+ * at or below every multiple of GCONV_TILE_NODES. */
+#define GCONV_TILE_NODES 64
+#define GCONV_TILE_BACK  448   /* how far a tile start may be pulled back to find a cut */
 
-/* Upper bounds for the caller-allocated outputs of gconv_graph_prep(). */
-int64_t gconv_graph_max_long_rows(int64_t num_edges);
-int64_t gconv_graph_max_segments(int64_t num_edges);
-size_t  gconv_graph_prep_workspace_bytes(int64_t num_edges, int32_t num_nodes);
+/* Everything the kernels need to apply S and S^T for one edge list. All pointers
+ * point into the caller's arena (see gconv_graph_build). */
+typedef struct gconv_graph {
+  gconv_csr_t    fwd;            /* rows = targets: the forward operator S              */
+  gconv_csr_t    bwd;            /* rows = sources: S^T (a copy of `fwd` if symmetric)  */
+  const float*   dis;            /* [num_nodes] (in-degree + 1)^-1/2; NULL if !normalize */
+  const int32_t* tile_ptr;       /* [n_tiles + 1] node offsets of the component tiles   */
+  int32_t        n_tiles;        /* 0: not tileable (an edge-free boundary was not found) */
+  int32_t        tile_nodes_max; /* nodes in the largest tile                           */
+  int32_t        symmetric;      /* edge multiset equals its transpose                  */
+  int32_t        normalize;
+  int32_t        max_degree;     /* of `fwd`                                            */
+  int32_t        bad_index;      /* 1 if an edge endpoint was outside [0, num_nodes)    */
+} gconv_graph_t;
 
-/* Builds one CSR direction from a COO edge list.
- *   transpose = 0: rows = targets (the forward operator S)
- *   transpose = 1: rows = sources (S^T, used by the backward pass)
- *   dis_out (nullable): deg^-1/2 of the looped in-degree, [num_nodes]; only
- *     meaningful with normalize = 1 and transpose = 0 (S^T reuses it).
- * Synchronises `stream` once to fill `info_host`. Returns GCONV_E_BAD_INDEX
- * (outputs undefined) if an endpoint is out of range — never a device fault. */
-gconv_status_t gconv_graph_prep(const int64_t* edge_index, int64_t num_edges,
-                                int32_t num_nodes, int32_t normalize, int32_t transpose,
-                                int32_t* rowptr_out, int32_t* col_out, float* dis_out,
-                                int32_t* long_rows_out, int32_t* long_seg_base_out,
-                                int32_t* seg_long_out,
-                                void* workspace, size_t workspace_bytes,
-                                gconv_graph_info_t* info_host, gconv_stream_t stream);
+/* Bytes of device memory gconv_graph_build needs (outputs + scratch, upper bound). */
+size_t gconv_graph_build_bytes(int64_t num_edges, int32_t num_nodes);
 
-/* *equal_host = 1 iff both CSRs describe the same matrix (S == S^T test that
- * lets the backward reuse the forward CSR). Synchronises `stream`. */
-gconv_status_t gconv_csr_equal(const int32_t* rowptr_a, const int32_t* col_a,
-                               const int32_t* rowptr_b, const int32_t* col_b,
-                               int32_t num_nodes, int32_t nnz,
-                               int32_t* flag_dev, int32_t* equal_host, gconv_stream_t stream);
+/* Builds the whole graph plan from a COO edge list in ONE call:
+ *   key build -> radix sort -> CSR (+ deg^-1/2, long-row segments) -> exact symmetry
+ *   test on device -> S^T only if the edge list is not symmetric -> component tiles.
+ * `arena` (device, >= gconv_graph_build_bytes, 256-B aligned) receives every output
+ * array; it must stay alive as long as `graph_host_out` is used.
+ * Synchronises `stream` once (twice for asymmetric edge lists) to return the counters.
+ * Returns GCONV_E_BAD_INDEX if an endpoint is out of range — never a device fault. */
+gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t num_edges,
+                                 int32_t num_nodes, int32_t normalize,
+                                 void* arena, size_t arena_bytes,
+                                 gconv_graph_t* graph_host_out, gconv_stream_t stream);
 
 /* ------------------------------------------------------------------------- */
 /* K2 SpMM                                                                   */
@@ -184,16 +185,17 @@ typedef struct gconv_adapter_params {
   int32_t skip;         /* skip_connection                                    */
 } gconv_adapter_params_t;
 
-size_t gconv_adapter_fwd_workspace_bytes(const gconv_csr_t* graph, int32_t hidden, int32_t rank);
-size_t gconv_adapter_bwd_workspace_bytes(const gconv_csr_t* graph_t, int32_t hidden, int32_t rank);
+size_t gconv_adapter_fwd_workspace_bytes(const gconv_graph_t* graph, int32_t hidden, int32_t rank);
+size_t gconv_adapter_bwd_workspace_bytes(const gconv_graph_t* graph, int32_t hidden, int32_t rank);
 
 /* replaces: `GConvAdapter.forward` (`gconv_adapter.py:80-108`) for
  * normalization='none':  out = s * (S act(S X Wd^T + bd) Wu^T + bu + X).
- *   dis == NULL selects normalize=False.
+ *   graph->dis == NULL selects normalize=False. Block-diagonal graphs whose tiles fit
+ *   LDS run as ONE fused launch (tile-local), everything else as four launches.
  *   saved_h  [N, Fp]: act output (row-scaled by dis when normalised), kept for backward
  *   saved_h1 [N, Fp]: pre-activation, written only for GCONV_ACT_SILU (else may be NULL)
  *   saved_p  [N, Fp]: P = S act(...), kept for backward                       */
-gconv_status_t gconv_adapter_fwd_f32(const gconv_csr_t* graph, const float* dis,
+gconv_status_t gconv_adapter_fwd_f32(const gconv_graph_t* graph,
                                      const gconv_adapter_params_t* params, const float* x,
                                      float* out, float* saved_h, float* saved_h1, float* saved_p,
                                      void* workspace, size_t workspace_bytes,
@@ -202,10 +204,10 @@ gconv_status_t gconv_adapter_fwd_f32(const gconv_csr_t* graph, const float* dis,
 /* replaces: the autograd backward of the same ops, entered from
  * `loss.backward()` (`scripts/finetune_inductive_learning.py:66`,
  * `scripts/finetune_transductive_learning.py:229`).
- *   graph_t: CSR of S^T (the forward CSR when the edge list is symmetric)
+ *   uses graph->bwd (S^T; identical to graph->fwd for symmetric edge lists)
  *   grad_x nullable (skipped when x needs no gradient); grad_scalar nullable.
  *   All grad outputs are overwritten (not accumulated).                      */
-gconv_status_t gconv_adapter_bwd_f32(const gconv_csr_t* graph_t, const float* dis,
+gconv_status_t gconv_adapter_bwd_f32(const gconv_graph_t* graph,
                                      const gconv_adapter_params_t* params, const float* x,
                                      const float* grad_out, const float* saved_h,
                                      const float* saved_h1, const float* saved_p,

@@ -76,6 +76,29 @@ def test_graph_prep_long_rows_and_segments(dev):
     assert plan.fwd.n_seg == -(-1499 // ga._lib.SEG_EDGES)
     assert plan.fwd.long_rows.cpu()[0].item() == 0
     assert not plan.symmetric and plan.bwd.n_long == 0
+    assert plan.n_tiles == 0          # a 1499-edge hub spans more than a tile can be pulled back
+
+
+def test_graph_build_component_tiles(dev):
+    batch = ga.synth.molecule_batch("hiv", 96, seed=4)
+    n = batch.num_nodes
+    plan = ga.GraphPlan(batch.edge_index.to(dev), n, True)
+    assert plan.symmetric and plan.n_tiles == -(-n // ga._lib.TILE_NODES)
+    tp = plan.tile_ptr.cpu().numpy()
+    assert tp[0] == 0 and tp[-1] == n and (np.diff(tp) >= 0).all()
+    assert plan.tile_nodes_max == np.diff(tp).max()
+    # every tile boundary is a graph boundary, and it is the LAST one at or below t * 64
+    gptr = batch.graph_ptr.numpy()
+    for t, q in enumerate(tp[:-1]):
+        assert q in gptr and q <= t * 64
+        assert gptr[gptr <= t * 64].max() == q
+    # no edge crosses a tile boundary
+    ei = batch.edge_index.numpy()
+    tile_of = np.searchsorted(tp, np.arange(n), side="right") - 1
+    assert (tile_of[ei[0]] == tile_of[ei[1]]).all()
+    # a connected graph much larger than a tile is not tileable
+    big = ga.synth.planetoid_like(3000, 9000, seed=2)
+    assert ga.GraphPlan(big.edge_index.to(dev), 3000, True).n_tiles == 0
 
 
 def test_graph_prep_rejects_bad_index(dev):
