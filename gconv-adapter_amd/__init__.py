@@ -6,12 +6,12 @@ repo-root module ``gconv_adapter_amd.py`` aliases it, so
 """
 from .adapter import GConvAdapter, GCNConvParams
 from .functional import GConvAdapterFunction, gconv_adapter, spmm, gemm_down, gemm_up_fused
-from .graph import GraphPlan, PlanCache, PLAN_CACHE, get_plan
+from .graph import GraphPlan, PlanCache, PLAN_CACHE, get_plan, prefetch_plan
 from .hydra_compat import instantiate, load_finetune_config
 from . import synth, dist, _lib
 
 __all__ = [
     "GConvAdapter", "GCNConvParams", "GConvAdapterFunction", "gconv_adapter", "spmm",
-    "gemm_down", "gemm_up_fused", "GraphPlan", "PlanCache", "PLAN_CACHE", "get_plan",
+    "gemm_down", "gemm_up_fused", "GraphPlan", "PlanCache", "PLAN_CACHE", "get_plan", "prefetch_plan",
     "instantiate", "load_finetune_config", "synth", "dist",
 ]

@@ -18,7 +18,7 @@ SPMM_IN_PRESCALED = 1
 SPMM_OUT_PRESCALE = 2
 LONG_ROW = 64
 SEG_EDGES = 128
-TILE_NODES = 64
+TILE_NODES = 32
 
 _i32p = C.POINTER(C.c_int32)
 

@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .functional import gconv_adapter
+from .functional import GConvAdapterFunction
 from .graph import get_plan
 
 
@@ -112,12 +112,14 @@ class GConvAdapter(nn.Module):
         nn.init.zeros_(self.conv_up.bias)
 
     def _forward_2d(self, x2d: torch.Tensor, edge_index: torch.Tensor, fuse_scalar: bool) -> torch.Tensor:
-        plan = get_plan(edge_index, x2d.size(0), self.normalize)
-        return gconv_adapter(x2d, plan,
-                             self.conv_down.lin.weight, self.conv_down.bias,
-                             self.conv_up.lin.weight, self.conv_up.bias,
-                             self.scalar if fuse_scalar else None,
-                             act=self.non_linearity, skip=self.skip_connection)
+        plan = get_plan(edge_index, x2d.shape[0], self.normalize)
+        p = self.__dict__.get("_flat_params")
+        if p is None:   # Parameter objects are stable across .to() / load_state_dict()
+            p = (self.conv_down.lin.weight, self.conv_down.bias, self.conv_up.lin.weight,
+                 self.conv_up.bias, self.scalar, _lib.ACT_CODES[self.non_linearity])
+            self.__dict__["_flat_params"] = p
+        return GConvAdapterFunction.apply(x2d, p[0], p[1], p[2], p[3], p[4] if fuse_scalar else None,
+                                          plan, p[5], bool(self.skip_connection))
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor,
                 edge_attr: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -87,21 +87,21 @@ static BwdWs carve_bwd(void* ws, const gconv_csr_t* gt, int d, int fp) {
 
 // backward workspace of the fused tile path: one partial row per tile
 struct TileBwdWs {
-  float *part_wd, *part_wu, *part_cs, *part_bd, *part_ds1, *part_dsx, *cs_tmp, *part_bd2;
+  float *part_wd, *part_wu, *part_cs, *part_bd, *part_ds, *cs_tmp;
+  int nparts;
   size_t bytes;
 };
 static TileBwdWs carve_bwd_tile(void* ws, int n_tiles, int d, int fp) {
   Carver c(ws);
   TileBwdWs w;
-  const size_t t = n_tiles;
+  w.nparts = tile_grid(n_tiles);
+  const size_t t = w.nparts;
   w.part_wd = c.take<float>(t * fp * d);
   w.part_wu = c.take<float>(t * fp * d);
   w.part_cs = c.take<float>(t * d);
   w.part_bd = c.take<float>(t * fp);
-  w.part_ds1 = c.take<float>(t);
-  w.part_dsx = c.take<float>(t);
+  w.part_ds = c.take<float>(t);
   w.cs_tmp = c.take<float>(d);
-  w.part_bd2 = c.take<float>(static_cast<size_t>(kReduceBlocks) * fp);
   w.bytes = c.off;
   return w;
 }
@@ -240,23 +240,18 @@ extern "C" gconv_status_t gconv_adapter_bwd_f32(const gconv_graph_t* gr,
     TileBwdArgs t{};
     t.tile_ptr = gr->tile_ptr; t.rowptr = graph_t->rowptr; t.col = graph_t->col; t.dis = dis;
     t.x = x; t.g = grad_out; t.saved_h = saved_h; t.saved_h1 = saved_h1; t.saved_p = saved_p;
-    t.w_down = p->w_down; t.w_up = p->w_up; t.scalar = p->scalar; t.dx = grad_x;
+    t.w_down = p->w_down; t.w_up = p->w_up; t.b_up = p->b_up; t.scalar = p->scalar;
+    t.dx = grad_x;
     t.part_wd = tw.part_wd; t.part_wu = tw.part_wu; t.part_cs = tw.part_cs;
-    t.part_bd = tw.part_bd; t.part_ds1 = tw.part_ds1; t.part_dsx = tw.part_dsx;
+    t.part_bd = tw.part_bd; t.part_ds = tw.part_ds;
     t.d = d; t.r = r; t.fp = fp; t.act = p->act; t.skip = p->skip;
     t.want_ds = grad_scalar != nullptr;
     st = launch_tile_bwd(t, gr->n_tiles, gr->tile_nodes_max, stream);
     if (st != GCONV_OK) return st;
-    FinalizeArgs f{};
-    f.part_wd = tw.part_wd; f.part_wu = tw.part_wu; f.part_cs = tw.part_cs; f.nparts = gr->n_tiles;
-    f.part_dsx = tw.part_dsx; f.n_dsx = gr->n_tiles;
-    f.part_ds1 = tw.part_ds1; f.n_ds1 = gr->n_tiles;
-    f.part_bd = tw.part_bd; f.n_bd = gr->n_tiles;
-    if (gr->n_tiles > 2 * kReduceBlocks) {
-      st = launch_reduce_rows(tw.part_bd, gr->n_tiles, fp, tw.part_bd2, stream);
-      if (st != GCONV_OK) return st;
-      f.part_bd = tw.part_bd2; f.n_bd = kReduceBlocks;
-    }
+    FinalizeArgs f{};   // ONE launch: every partial (d(scalar) included) is complete per workgroup
+    f.part_wd = tw.part_wd; f.part_wu = tw.part_wu; f.part_cs = tw.part_cs; f.nparts = tw.nparts;
+    f.part_ds1 = tw.part_ds; f.n_ds1 = tw.nparts; f.ds_complete = 1;
+    f.part_bd = tw.part_bd; f.n_bd = tw.nparts;
     f.scalar = p->scalar; f.b_up = p->b_up; f.cs_tmp = tw.cs_tmp;
     f.g_wd = grad_w_down; f.g_bd = grad_b_down; f.g_wu = grad_w_up; f.g_bu = grad_b_up;
     f.g_s = grad_scalar; f.d = d; f.r = r; f.fp = fp; f.skip = p->skip;

@@ -10,23 +10,27 @@ struct TileFwdArgs {
   const float* x; float* out; float* saved_h; float* saved_h1; float* saved_p;
   const float* w_down; const float* b_down; const float* w_up; const float* b_up;
   const float* scalar;
-  int d, r, fp, act, skip, cap;
+  int d, r, fp, act, skip, cap, n_tiles;
 };
 
 struct TileBwdArgs {
   const int32_t* tile_ptr; const int32_t* rowptr; const int32_t* col; const float* dis;  // S^T
   const float* x; const float* g; const float* saved_h; const float* saved_h1;
   const float* saved_p;
-  const float* w_down; const float* w_up; const float* scalar;
+  const float* w_down; const float* w_up; const float* b_up; const float* scalar;
   float* dx;        // nullable
-  float* part_wd; float* part_wu; float* part_cs;   // [n_tiles, Fp, d] x2, [n_tiles, d]
-  float* part_bd; float* part_ds1; float* part_dsx; // [n_tiles, Fp], [n_tiles], [n_tiles]
-  int d, r, fp, act, skip, cap, want_ds;
+  // one partial row per (persistent) workgroup: [grid, Fp, d] x2, [grid, d], [grid, Fp], [grid]
+  float* part_wd; float* part_wu; float* part_cs; float* part_bd;
+  float* part_ds;   // complete scalar-gradient partial: (G Wu).P + [skip] G.X + b_up.colsum(G)
+  int d, r, fp, act, skip, cap, want_ds, n_tiles;
 };
 
 // true if the graph is tiled and one tile's rank-width state fits the LDS budget
 bool tile_path_ok(const gconv_graph_t* g, int d, int fp);
 size_t tile_lds_bytes(int d, int fp, int tile_nodes_max);
+
+// workgroups the tile kernels are launched with (= partial rows of the backward)
+int tile_grid(int n_tiles);
 
 gconv_status_t launch_tile_fwd(TileFwdArgs a, int n_tiles, int tile_nodes_max, hipStream_t stream);
 gconv_status_t launch_tile_bwd(TileBwdArgs a, int n_tiles, int tile_nodes_max, hipStream_t stream);

@@ -152,7 +152,7 @@ __device__ __forceinline__ f32x4 tile_row_sum(const float* src, const int32_t* _
 }  // namespace
 
 // ===========================================================================
-// forward
+// forward — persistent workgroups walk the tiles (weights staged / loaded once)
 // ===========================================================================
 template <int FP, int NQ, bool NORM>
 __global__ __launch_bounds__(512) void tile_fwd_kernel(TileFwdArgs a) {
@@ -166,97 +166,121 @@ __global__ __launch_bounds__(512) void tile_fwd_kernel(TileFwdArgs a) {
 
   const int lane = threadIdx.x & 63, wave = wave_id();
   const int nwaves = blockDim.x >> 6;
-  const int ts = a.tile_ptr[blockIdx.x], nt = a.tile_ptr[blockIdx.x + 1] - ts;
-  if (nt <= 0) return;  // uniform
+  const int jj = lane & 15, t = lane >> 4;
+  const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR, ngrp = blockDim.x / LPR;
+  const float sval = a.scalar ? a.scalar[0] : 1.f;
 
   stage_weights<NCB, NQ>(wl, a.w_down, a.d, a.r, true);
-  __syncthreads();
 
-  // ---- phase 1: H0' -> bufA
-  tile_rowsA<FP, NQ>(a.x, wl, bufA, a.dis, nullptr, 1.f, ts, nt, a.d, nwaves, wave, lane);
-  __syncthreads();
-
-  // ---- phase 2: H2' -> bufB (+ saved_h, saved_h1)
-  const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR, ngrp = blockDim.x / LPR;
-  for (int lr = grp; lr < nt; lr += ngrp) {
-    f32x4 v = tile_row_sum<FP, NORM>(bufA, a.rowptr, a.col, a.dis, ts, lr, sub);
+  // phase-4 ownership: a wave owns ONE 64-column chunk (W_up fragments in registers) and
+  // every nslots-th node block of a tile (nchunks <= nwaves is guaranteed by the launcher)
+  const int nchunks = ceil_div(a.d, 64);
+  const int nslots = nwaves / nchunks;
+  const int J = wave % nchunks, slot = wave / nchunks;
+  const bool active = slot < nslots;
+  const int colbase = 64 * J + 4 * jj;
+  const bool colvalid = colbase < a.d;
+  const int colc = min(colbase, a.d - 4);
+  float wb[KS][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int c = 4 * sub + k;
-      if (a.b_down && c < a.r) v[k] += a.b_down[c];
+  for (int s = 0; s < KS; ++s) {
+    const int k = rank_k_<FP>(s, t);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float w = a.w_up[static_cast<size_t>(colc + c) * a.r + min(k, a.r - 1)];
+      wb[s][c] = (colvalid && k < a.r) ? w : 0.f;
     }
-    const size_t off = static_cast<size_t>(ts + lr) * FP + 4 * sub;
-    if (a.act == GCONV_ACT_SILU) stg4(a.saved_h1 + off, v);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = act_fwd(a.act, v[k]);
-    if (NORM) v *= a.dis[ts + lr];
-    *reinterpret_cast<f32x4*>(bufB + lr * FP + 4 * sub) = v;
-    stg4(a.saved_h + off, v);
   }
+  f32x4 bu = zero4f();
+  if (a.b_up) { const f32x4 bv = ldg4(a.b_up + colc); bu = colvalid ? bv : zero4f(); }
   __syncthreads();
 
-  // ---- phase 3: P -> bufA (+ saved_p)
-  for (int lr = grp; lr < nt; lr += ngrp) {
-    const f32x4 v = tile_row_sum<FP, NORM>(bufB, a.rowptr, a.col, a.dis, ts, lr, sub);
-    *reinterpret_cast<f32x4*>(bufA + lr * FP + 4 * sub) = v;
-    stg4(a.saved_p + static_cast<size_t>(ts + lr) * FP + 4 * sub, v);
-  }
-  __syncthreads();
+  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const int ts = a.tile_ptr[tile], nt = a.tile_ptr[tile + 1] - ts;
+    if (nt <= 0) continue;  // uniform
 
-  // ---- phase 4: out = s (P Wu^T + bu + X): every wave walks all column chunks, node
-  // blocks are dealt round-robin over the waves
-  const int jj = lane & 15, t = lane >> 4;
-  const float sval = a.scalar ? a.scalar[0] : 1.f;
-  const int nb = ceil_div(nt, 16), nchunks = ceil_div(a.d, 64);
-  for (int J = 0; J < nchunks; ++J) {
-    const int colbase = 64 * J + 4 * jj;
-    const bool colvalid = colbase < a.d;
-    const int colc = min(colbase, a.d - 4);
-    float wb[KS][4];
+    // ---- phase 1: H0' -> bufA
+    tile_rowsA<FP, NQ>(a.x, wl, bufA, a.dis, nullptr, 1.f, ts, nt, a.d, nwaves, wave, lane);
+    __syncthreads();
+
+    // ---- phase 2: H2' -> bufB (+ saved_h, saved_h1)
+    for (int lr = grp; lr < nt; lr += ngrp) {
+      f32x4 v = tile_row_sum<FP, NORM>(bufA, a.rowptr, a.col, a.dis, ts, lr, sub);
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int k = rank_k_<FP>(s, t);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float w = a.w_up[static_cast<size_t>(colc + c) * a.r + min(k, a.r - 1)];
-        wb[s][c] = (colvalid && k < a.r) ? w : 0.f;
+      for (int k = 0; k < 4; ++k) {
+        const int c = 4 * sub + k;
+        if (a.b_down && c < a.r) v[k] += a.b_down[c];
       }
+      const size_t off = static_cast<size_t>(ts + lr) * FP + 4 * sub;
+      if (a.act == GCONV_ACT_SILU) stg4(a.saved_h1 + off, v);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = act_fwd(a.act, v[k]);
+      if (NORM) v *= a.dis[ts + lr];
+      *reinterpret_cast<f32x4*>(bufB + lr * FP + 4 * sub) = v;
+      stg4(a.saved_h + off, v);
     }
-    f32x4 bu = zero4f();
-    if (a.b_up) { const f32x4 bv = ldg4(a.b_up + colc); bu = colvalid ? bv : zero4f(); }
-    for (int b = wave; b < nb; b += nwaves) {
-      f32x4 xv[4];
+    __syncthreads();
+
+    // ---- phase 3: P -> bufA (+ saved_p)
+    for (int lr = grp; lr < nt; lr += ngrp) {
+      const f32x4 v = tile_row_sum<FP, NORM>(bufB, a.rowptr, a.col, a.dis, ts, lr, sub);
+      *reinterpret_cast<f32x4*>(bufA + lr * FP + 4 * sub) = v;
+      stg4(a.saved_p + static_cast<size_t>(ts + lr) * FP + 4 * sub, v);
+    }
+    __syncthreads();
+
+    // ---- phase 4: out = s (P Wu^T + bu + X); the X tile of the wave's next node block is
+    // in flight while the current one computes (unconditional, clamped prefetch)
+    if (active) {
+      const int nb = ceil_div(nt, 16);
+      auto load_x = [&](int b, f32x4 (&xq)[4]) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int lr = min(16 * b + 4 * t + m, nt - 1);
-        xv[m] = a.skip ? ldg4(a.x + static_cast<size_t>(ts + lr) * a.d + colc) : zero4f();
-      }
-      float pa[KS];
-      lds_rank_frag<FP>(bufA, min(16 * b + jj, nt - 1), t, 16 * b + jj < nt, pa);
-      f32x4 acc[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) acc[c] = zero4f();
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = mfma16(pa[s], wb[s][c], acc[c]);
-      }
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int lr = 16 * b + 4 * t + m;
-        if (colvalid && lr < nt) {
-          f32x4 o;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) o[c] = sval * (acc[c][m] + bu[c] + xv[m][c]);
-          stg4(a.out + static_cast<size_t>(ts + lr) * a.d + colbase, o);
+        for (int m = 0; m < 4; ++m) {
+          const int lr = min(16 * b + 4 * t + m, nt - 1);
+          xq[m] = ldg4(a.x + static_cast<size_t>(ts + lr) * a.d + colc);
         }
+      };
+      f32x4 xv[4], xn[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) xv[m] = xn[m] = zero4f();
+      int b = slot;
+      if (b < nb && a.skip) load_x(b, xv);
+      while (b < nb) {
+        const int nxt = b + nslots;
+        float pa[KS];
+        lds_rank_frag<FP>(bufA, min(16 * b + jj, nt - 1), t, 16 * b + jj < nt, pa);
+        if (a.skip) load_x(min(nxt, nb - 1), xn);
+        f32x4 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = zero4f();
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] = mfma16(pa[s], wb[s][c], acc[c]);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int lr = 16 * b + 4 * t + m;
+          if (colvalid && lr < nt) {
+            f32x4 o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = sval * (acc[c][m] + bu[c] + xv[m][c]);
+            stg4(a.out + static_cast<size_t>(ts + lr) * a.d + colbase, o);
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) xv[m] = xn[m];
+        b = nxt;
       }
     }
+    __syncthreads();  // bufA / bufB are reused by the next tile
   }
 }
 
 // ===========================================================================
-// backward
+// backward — persistent workgroups; the dW^T tiles, colsum(G), bias gradient and the
+// scalar-gradient pieces stay in registers across all tiles of a workgroup, so ONE
+// partial row per workgroup reaches HBM and B5 is a single launch.
 // ===========================================================================
 template <int FP, int NQ, bool NORM, bool NEED_DX>
 __global__ __launch_bounds__(512) void tile_bwd_kernel(TileBwdArgs a) {
@@ -271,200 +295,206 @@ __global__ __launch_bounds__(512) void tile_bwd_kernel(TileBwdArgs a) {
 
   const int lane = threadIdx.x & 63, wave = wave_id();
   const int nwaves = blockDim.x >> 6;
-  const int tile = blockIdx.x;
-  const int ts = a.tile_ptr[tile], nt = a.tile_ptr[tile + 1] - ts;
+  const int pid = blockIdx.x;
   const float sval = a.scalar ? a.scalar[0] : 1.f;
   const int nchunks = ceil_div(a.d, 64);
   const int jj = lane & 15, t = lane >> 4;
-
-  if (nt <= 0) {  // empty tile (uniform): its partial rows must still be defined
-    for (int idx = threadIdx.x; idx < FP * a.d; idx += blockDim.x) {
-      a.part_wd[static_cast<size_t>(tile) * FP * a.d + idx] = 0.f;
-      a.part_wu[static_cast<size_t>(tile) * FP * a.d + idx] = 0.f;
-    }
-    for (int idx = threadIdx.x; idx < a.d; idx += blockDim.x)
-      a.part_cs[static_cast<size_t>(tile) * a.d + idx] = 0.f;
-    if (threadIdx.x < FP) a.part_bd[static_cast<size_t>(tile) * FP + threadIdx.x] = 0.f;
-    if (threadIdx.x == 0) { a.part_ds1[tile] = 0.f; a.part_dsx[tile] = 0.f; }
-    return;
-  }
+  const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR, ngrp = blockDim.x / LPR;
 
   stage_weights<NCB, NQ>(wl, a.w_up, a.d, a.r, false);
-  __syncthreads();
 
-  // ---- phase 1: dP' = dis . s (G Wu) -> bufA ; ds1 = sum (G Wu) . P
-  float ds1 = tile_rowsA<FP, NQ>(a.g, wl, bufA, a.dis, a.want_ds ? a.saved_p : nullptr, sval, ts, nt,
-                                 a.d, nwaves, wave, lane);
-  __syncthreads();
-
-  // ---- phase 2: dH1' = dis . (S^T dP . act') -> bufB ; bias gradient
-  const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR, ngrp = blockDim.x / LPR;
-  f32x4 bgrad = zero4f();
-  for (int lr = grp; lr < nt; lr += ngrp) {
-    f32x4 v = tile_row_sum<FP, NORM>(bufA, a.rowptr, a.col, a.dis, ts, lr, sub);
-    const size_t off = static_cast<size_t>(ts + lr) * FP + 4 * sub;
-    if (a.act == GCONV_ACT_RELU) {
-      const f32x4 h2 = ldg4(a.saved_h + off);
+  // phase-4 ownership: wave J owns column chunk J (nchunks <= nwaves)
+  const bool owner = wave < nchunks;
+  const int colbase = 64 * (owner ? wave : 0) + 4 * jj;
+  const bool colvalid = owner && colbase < a.d;
+  const int colc = min(colbase, a.d - 4);
+  float wd[NEED_DX ? KS : 1][4];
+  if constexpr (NEED_DX) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = h2[k] > 0.f ? v[k] : 0.f;
-    } else if (a.act == GCONV_ACT_SILU) {
-      const f32x4 h1 = ldg4(a.saved_h1 + off);
+    for (int s = 0; s < KS; ++s) {
+      const int k = rank_k_<FP>(s, t);
+      const f32x4 v = ldg4(a.w_down + static_cast<size_t>(min(k, a.r - 1)) * a.d + colc);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] *= silu_grad(h1[k]);
+      for (int c = 0; c < 4; ++c) wd[s][c] = (colvalid && k < a.r) ? v[c] : 0.f;
     }
-    bgrad += v;
-    if (NORM) v *= a.dis[ts + lr];
-    *reinterpret_cast<f32x4*>(bufB + lr * FP + 4 * sub) = v;
   }
+  f32x4 awd[NCB][4], awu[NCB][4];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) awd[cb][c] = awu[cb][c] = zero4f();
+  f32x4 cs = zero4f(), bgrad = zero4f();
+  float ds1 = 0.f, dsx = 0.f;
   __syncthreads();
 
-  // ---- phase 3: T = S^T dH1 -> bufA
-  for (int lr = grp; lr < nt; lr += ngrp) {
-    const f32x4 v = tile_row_sum<FP, NORM>(bufB, a.rowptr, a.col, a.dis, ts, lr, sub);
-    *reinterpret_cast<f32x4*>(bufA + lr * FP + 4 * sub) = v;
+  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const int ts = a.tile_ptr[tile], nt = a.tile_ptr[tile + 1] - ts;
+    if (nt <= 0) continue;  // uniform
+
+    // ---- phase 1: dP' = dis . s (G Wu) -> bufA ; ds1 += sum (G Wu) . P
+    ds1 += tile_rowsA<FP, NQ>(a.g, wl, bufA, a.dis, a.want_ds ? a.saved_p : nullptr, sval, ts, nt,
+                              a.d, nwaves, wave, lane);
+    __syncthreads();
+
+    // ---- phase 2: dH1' = dis . (S^T dP . act') -> bufB ; bias gradient
+    for (int lr = grp; lr < nt; lr += ngrp) {
+      f32x4 v = tile_row_sum<FP, NORM>(bufA, a.rowptr, a.col, a.dis, ts, lr, sub);
+      const size_t off = static_cast<size_t>(ts + lr) * FP + 4 * sub;
+      if (a.act == GCONV_ACT_RELU) {
+        const f32x4 h2 = ldg4(a.saved_h + off);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = h2[k] > 0.f ? v[k] : 0.f;
+      } else if (a.act == GCONV_ACT_SILU) {
+        const f32x4 h1 = ldg4(a.saved_h1 + off);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] *= silu_grad(h1[k]);
+      }
+      bgrad += v;
+      if (NORM) v *= a.dis[ts + lr];
+      *reinterpret_cast<f32x4*>(bufB + lr * FP + 4 * sub) = v;
+    }
+    __syncthreads();
+
+    // ---- phase 3: T = S^T dH1 -> bufA
+    for (int lr = grp; lr < nt; lr += ngrp) {
+      const f32x4 v = tile_row_sum<FP, NORM>(bufB, a.rowptr, a.col, a.dis, ts, lr, sub);
+      *reinterpret_cast<f32x4*>(bufA + lr * FP + 4 * sub) = v;
+    }
+    __syncthreads();
+
+    // ---- phase 4 (owner waves): dX = T Wd + s G ; dWd^T += T^T X ; dWu^T += P^T G ;
+    //      colsum(G) ; sum G.X — next block's G / X tiles prefetched
+    if (owner) {
+      const int nb = ceil_div(nt, 16);
+      auto load_gx = [&](int b, f32x4 (&gq)[4], f32x4 (&xq)[4]) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int lrc = min(16 * b + 4 * t + m, nt - 1);
+          gq[m] = ldg4(a.g + static_cast<size_t>(ts + lrc) * a.d + colc);
+          xq[m] = ldg4(a.x + static_cast<size_t>(ts + lrc) * a.d + colc);
+        }
+      };
+      f32x4 gr[4], xr[4], gn[4], xn[4];
+      load_gx(0, gr, xr);
+      for (int b = 0; b < nb; ++b) {
+        // rank-width operands of this block first (vmcnt retires in order), then the
+        // unconditional prefetch of the next block's tiles
+        float at[4][NCB], ap[4][NCB];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int lr = 16 * b + 4 * t + m, lrc = min(lr, nt - 1);
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) {
+            const int rc = 16 * cb + jj, rcc = min(rc, FP - 1);
+            const float vt = bufA[lrc * FP + rcc];
+            const float vp = a.saved_p[static_cast<size_t>(ts + lrc) * FP + rcc];
+            const bool ok = lr < nt && rc < FP;
+            at[m][cb] = ok ? vt : 0.f;
+            ap[m][cb] = ok ? vp : 0.f;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_gx(min(b + 1, nb - 1), gn, xn);
+        f32x4 gv[4], xv[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const bool ok = colvalid && 16 * b + 4 * t + m < nt;
+          gv[m] = ok ? gr[m] : zero4f();
+          xv[m] = ok ? xr[m] : zero4f();
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              awd[cb][c] = mfma16(at[m][cb], xv[m][c], awd[cb][c]);
+              awu[cb][c] = mfma16(ap[m][cb], gv[m][c], awu[cb][c]);
+            }
+          }
+          cs += gv[m];
+          if (a.skip) dsx += gv[m][0] * xv[m][0] + gv[m][1] * xv[m][1] + gv[m][2] * xv[m][2] + gv[m][3] * xv[m][3];
+        }
+        if constexpr (NEED_DX) {
+          float ta[KS];
+          lds_rank_frag<FP>(bufA, min(16 * b + jj, nt - 1), t, 16 * b + jj < nt, ta);
+          f32x4 acc[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] = zero4f();
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = mfma16(ta[s], wd[s][c], acc[c]);
+          }
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const int lr = 16 * b + 4 * t + m;
+            if (colvalid && lr < nt) {
+              f32x4 o;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) o[c] = acc[c][m] + (a.skip ? sval * gv[m][c] : 0.f);
+              stg4(a.dx + static_cast<size_t>(ts + lr) * a.d + colbase, o);
+            }
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { gr[m] = gn[m]; xr[m] = xn[m]; }
+      }
+    }
+    __syncthreads();  // bufA / bufB are reused by the next tile
   }
-  // block-wide bias-gradient and ds1 sums (fixed order), while T settles
+
+  // ---- one partial row per workgroup
+  // colsum(G): add the four lane quarters (fixed order); quarter 0 stores
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    cs[c] += __shfl_xor(cs[c], 16);
+    cs[c] += __shfl_xor(cs[c], 32);
+  }
+  // b_up . colsum(G) of this wave's chunk joins the scalar-gradient partial
+  float bdot = 0.f;
+  if (colvalid && t == 0 && a.b_up) {
+    const f32x4 bv = ldg4(a.b_up + colbase);
+    bdot = bv[0] * cs[0] + bv[1] * cs[1] + bv[2] * cs[2] + bv[3] * cs[3];
+  }
+  if (colvalid) {
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int rk = 16 * cb + 4 * t + m;
+        if (rk < FP) {
+          const size_t o = (static_cast<size_t>(pid) * FP + rk) * a.d + colbase;
+          stg4(a.part_wd + o, f32x4{awd[cb][0][m], awd[cb][1][m], awd[cb][2][m], awd[cb][3][m]});
+          stg4(a.part_wu + o, f32x4{awu[cb][0][m], awu[cb][1][m], awu[cb][2][m], awu[cb][3][m]});
+        }
+      }
+    }
+    if (t == 0) stg4(a.part_cs + static_cast<size_t>(pid) * a.d + colbase, cs);
+  }
+  // bias gradient and d(scalar): lanes -> wave -> workgroup, fixed order
 #pragma unroll
   for (int off = LPR; off < kWave; off <<= 1) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) bgrad[k] += __shfl_xor(bgrad[k], off);
   }
-  for (int off = 32; off > 0; off >>= 1) ds1 += __shfl_xor(ds1, off);
+  float dsum = ds1 + (a.skip ? dsx : 0.f) + bdot;
+  for (int off = 32; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off);
   if (lane < LPR) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) red[wave * (FP + 2) + 4 * lane + k] = bgrad[k];
   }
-  if (lane == 0) red[wave * (FP + 2) + FP] = ds1;
+  if (lane == 0) red[wave * (FP + 2) + FP] = dsum;
   __syncthreads();
   if (threadIdx.x < FP) {
     float v = 0.f;
     for (int w = 0; w < nwaves; ++w) v += red[w * (FP + 2) + threadIdx.x];
-    a.part_bd[static_cast<size_t>(tile) * FP + threadIdx.x] = v;
+    a.part_bd[static_cast<size_t>(pid) * FP + threadIdx.x] = v;
   }
   if (threadIdx.x == 0) {
     float v = 0.f;
     for (int w = 0; w < nwaves; ++w) v += red[w * (FP + 2) + FP];
-    a.part_ds1[tile] = v;
-  }
-
-  // ---- phase 4: one wave per column chunk (chunks dealt round-robin), all node blocks:
-  //      dX = T Wd + s G ; dWd^T += T^T X ; dWu^T += P^T G ; colsum(G) ; sum G.X
-  const int nb = ceil_div(nt, 16);
-  float dsx = 0.f;
-  for (int J = wave; J < nchunks; J += nwaves) {
-    const int colbase = 64 * J + 4 * jj;
-    const bool colvalid = colbase < a.d;
-    const int colc = min(colbase, a.d - 4);
-    float wd[NEED_DX ? KS : 1][4];
-    if constexpr (NEED_DX) {
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const int k = rank_k_<FP>(s, t);
-        const f32x4 v = ldg4(a.w_down + static_cast<size_t>(min(k, a.r - 1)) * a.d + colc);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) wd[s][c] = (colvalid && k < a.r) ? v[c] : 0.f;
-      }
-    }
-    f32x4 awd[NCB][4], awu[NCB][4];
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) awd[cb][c] = awu[cb][c] = zero4f();
-    f32x4 cs = zero4f();
-
-    for (int b = 0; b < nb; ++b) {
-      float at[4][NCB], ap[4][NCB];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int lr = 16 * b + 4 * t + m, lrc = min(lr, nt - 1);
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) {
-          const int rc = 16 * cb + jj, rcc = min(rc, FP - 1);
-          const float vt = bufA[lrc * FP + rcc];
-          const float vp = a.saved_p[static_cast<size_t>(ts + lrc) * FP + rcc];
-          const bool ok = lr < nt && rc < FP;
-          at[m][cb] = ok ? vt : 0.f;
-          ap[m][cb] = ok ? vp : 0.f;
-        }
-      }
-      f32x4 gv[4], xv[4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int lr = 16 * b + 4 * t + m, lrc = min(lr, nt - 1);
-        const f32x4 g4 = ldg4(a.g + static_cast<size_t>(ts + lrc) * a.d + colc);
-        const f32x4 x4 = ldg4(a.x + static_cast<size_t>(ts + lrc) * a.d + colc);
-        const bool ok = colvalid && lr < nt;
-        gv[m] = ok ? g4 : zero4f();
-        xv[m] = ok ? x4 : zero4f();
-      }
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            awd[cb][c] = mfma16(at[m][cb], xv[m][c], awd[cb][c]);
-            awu[cb][c] = mfma16(ap[m][cb], gv[m][c], awu[cb][c]);
-          }
-        }
-        cs += gv[m];
-        if (a.skip) dsx += gv[m][0] * xv[m][0] + gv[m][1] * xv[m][1] + gv[m][2] * xv[m][2] + gv[m][3] * xv[m][3];
-      }
-      if constexpr (NEED_DX) {
-        float ta[KS];
-        lds_rank_frag<FP>(bufA, min(16 * b + jj, nt - 1), t, 16 * b + jj < nt, ta);
-        f32x4 acc[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = zero4f();
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) acc[c] = mfma16(ta[s], wd[s][c], acc[c]);
-        }
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const int lr = 16 * b + 4 * t + m;
-          if (colvalid && lr < nt) {
-            f32x4 o;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) o[c] = acc[c][m] + (a.skip ? sval * gv[m][c] : 0.f);
-            stg4(a.dx + static_cast<size_t>(ts + lr) * a.d + colbase, o);
-          }
-        }
-      }
-    }
-
-    // this wave owns chunk J of the tile's partials: no cross-wave reduction needed
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      cs[c] += __shfl_xor(cs[c], 16);
-      cs[c] += __shfl_xor(cs[c], 32);
-    }
-    if (colvalid) {
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const int rk = 16 * cb + 4 * t + m;
-          if (rk < FP) {
-            const size_t o = (static_cast<size_t>(tile) * FP + rk) * a.d + colbase;
-            stg4(a.part_wd + o, f32x4{awd[cb][0][m], awd[cb][1][m], awd[cb][2][m], awd[cb][3][m]});
-            stg4(a.part_wu + o, f32x4{awu[cb][0][m], awu[cb][1][m], awu[cb][2][m], awu[cb][3][m]});
-          }
-        }
-      }
-      if (t == 0) stg4(a.part_cs + static_cast<size_t>(tile) * a.d + colbase, cs);
-    }
-  }
-  // sum(G . X): wave sums, then the waves in order
-  for (int off = 32; off > 0; off >>= 1) dsx += __shfl_xor(dsx, off);
-  __syncthreads();  // `red` is reused
-  if (lane == 0) red[wave] = dsx;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float v = 0.f;
-    for (int w = 0; w < nwaves; ++w) v += red[w];
-    a.part_dsx[tile] = v;
+    a.part_ds[pid] = v;
   }
 }
 
@@ -494,7 +524,7 @@ size_t tile_lds_bytes(int d, int fp, int tile_nodes_max) {
 }
 
 bool tile_path_ok(const gconv_graph_t* g, int d, int fp) {
-  if (g->n_tiles <= 0 || tile_nq(d) == 0 || fp > 32) return false;
+  if (g->n_tiles <= 0 || tile_nq(d) == 0 || fp > 32 || ceil_div(d, 64) > 8) return false;
   static const bool off = getenv("GCONV_NO_TILE_PATH") != nullptr;  // debugging / A-B knob
   if (off) return false;
   return tile_lds_bytes(d, fp, g->tile_nodes_max) <= 64 * 1024;
@@ -536,9 +566,15 @@ static gconv_status_t launch_tile_bwd_t(const TileBwdArgs& a, int grid, int thre
   case FP_ * 100 + 16: return FN<FP_, 16> ARGS; case FP_ * 100 + 19: return FN<FP_, 19> ARGS;  \
   case FP_ * 100 + 24: return FN<FP_, 24> ARGS; case FP_ * 100 + 32: return FN<FP_, 32> ARGS;
 
+int tile_grid(int n_tiles) {  // persistent: <= 2 workgroups per CU
+  return n_tiles < 2 * kNumCU ? (n_tiles > 0 ? n_tiles : 1) : 2 * kNumCU;
+}
+
 gconv_status_t launch_tile_fwd(TileFwdArgs a, int n_tiles, int tile_nodes_max,
                                hipStream_t stream) {
   const int nq = tile_nq(a.d);
+  a.n_tiles = n_tiles;
+  n_tiles = tile_grid(n_tiles);
   a.cap = ceil_div(tile_nodes_max > 0 ? tile_nodes_max : 1, 16) * 16;
   const size_t lds = tile_lds_bytes(a.d, a.fp, tile_nodes_max);
   const int threads = tile_threads(a.d);
@@ -548,6 +584,8 @@ gconv_status_t launch_tile_fwd(TileFwdArgs a, int n_tiles, int tile_nodes_max,
 gconv_status_t launch_tile_bwd(TileBwdArgs a, int n_tiles, int tile_nodes_max,
                                hipStream_t stream) {
   const int nq = tile_nq(a.d);
+  a.n_tiles = n_tiles;
+  n_tiles = tile_grid(n_tiles);
   a.cap = ceil_div(tile_nodes_max > 0 ? tile_nodes_max : 1, 16) * 16;
   const size_t lds = tile_lds_bytes(a.d, a.fp, tile_nodes_max);
   const int threads = tile_threads(a.d);

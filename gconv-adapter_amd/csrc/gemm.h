@@ -72,6 +72,7 @@ struct FinalizeArgs {
   float* cs_tmp;                       // [d] scratch: colsum(G)
   float* g_wd; float* g_bd; float* g_wu; float* g_bu; float* g_s;
   int d, r, fp, skip;
+  int ds_complete;   // part_ds1 already holds the whole d(scalar) partial (fused tile path)
 };
 gconv_status_t launch_finalize(const FinalizeArgs& a, hipStream_t stream);
 

@@ -615,7 +615,7 @@ gconv_status_t launch_bwd_main(const BwdMainArgs& a, hipStream_t stream) {
 __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
   __shared__ float red[8][32];
   const int e = blockIdx.x * 32 + (threadIdx.x & 31), ps = threadIdx.x >> 5;
-  const int rd = a.r * a.d, total = 2 * rd + a.d + a.r;
+  const int rd = a.r * a.d, total = 2 * rd + a.d + a.r + (a.ds_complete ? 1 : 0);
   float sum = 0.f;
   if (e < total) {
     if (e < 2 * rd) {
@@ -627,9 +627,11 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
     } else if (e < 2 * rd + a.d) {
       const int j = e - 2 * rd;
       for (int p = ps; p < a.nparts; p += 8) sum += a.part_cs[static_cast<size_t>(p) * a.d + j];
-    } else {
+    } else if (e < 2 * rd + a.d + a.r) {
       const int c = e - 2 * rd - a.d;
       for (int p = ps; p < a.n_bd; p += 8) sum += a.part_bd[static_cast<size_t>(p) * a.fp + c];
+    } else {
+      for (int p = ps; p < a.n_ds1; p += 8) sum += a.part_ds1[p];
     }
   }
   red[ps][threadIdx.x & 31] = sum;
@@ -648,8 +650,10 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
       const int j = e - 2 * rd;
       a.cs_tmp[j] = v;
       if (a.g_bu) a.g_bu[j] = sval * v;
-    } else {
+    } else if (e < 2 * rd + a.d + a.r) {
       if (a.g_bd) a.g_bd[e - 2 * rd - a.d] = v;
+    } else {
+      if (a.g_s) a.g_s[0] = v;
     }
   }
 }
@@ -702,10 +706,10 @@ gconv_status_t launch_reduce_rows(const float* in, int rows, int width, float* o
 }
 
 gconv_status_t launch_finalize(const FinalizeArgs& a, hipStream_t stream) {
-  const int total = 2 * a.r * a.d + a.d + a.r;
+  const int total = 2 * a.r * a.d + a.d + a.r + (a.ds_complete ? 1 : 0);
   finalize_kernel<<<ceil_div(total, 32), 256, 0, stream>>>(a);
   GCONV_LAUNCH_CHECK();
-  if (a.g_s) {
+  if (a.g_s && !a.ds_complete) {
     finalize_scalar_kernel<<<1, 256, 0, stream>>>(a);
     GCONV_LAUNCH_CHECK();
   }

@@ -11,7 +11,9 @@ propagation operator (and of its transpose for the backward pass), the
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from collections import OrderedDict
+from concurrent.futures import ThreadPoolExecutor
 from typing import Optional, Tuple
 
 import torch
@@ -81,6 +83,20 @@ class GraphPlan:
         self.bwd = self.fwd if self.symmetric else CsrView(self, self.struct.bwd)
         self.n_tiles, self.tile_nodes_max = self.struct.n_tiles, self.struct.tile_nodes_max
         self._ref = C.byref(self.struct)
+        self._sizes = {}
+
+    def sizes(self, lib, d: int, r: int):
+        """(padded rank, forward workspace bytes, backward workspace bytes) for hidden d and
+        rank r — cached: every adapter of the step asks for the same pair."""
+        hit = self._sizes.get((d, r))
+        if hit is None:
+            fp = int(lib.gconv_padded_rank(r))
+            if fp == 0:
+                raise RuntimeError(f"bottleneck_size={r} is unsupported (1..64)")
+            hit = (fp, max(int(lib.gconv_adapter_fwd_workspace_bytes(self._ref, d, r)), 16),
+                   max(int(lib.gconv_adapter_bwd_workspace_bytes(self._ref, d, r)), 16))
+            self._sizes[(d, r)] = hit
+        return hit
 
     def ref(self):
         return self._ref
@@ -110,18 +126,34 @@ class PlanCache:
 
     The cached entry keeps a reference to the tensor, so its memory cannot be
     recycled for a different edge list while the key is alive; an in-place edit
-    bumps ``_version`` and misses."""
+    bumps ``_version`` and misses.
+
+    ``prefetch`` builds a plan for a FUTURE batch on a side stream from a worker thread
+    (ctypes releases the GIL inside the C ABI), the way the reference's DataLoader workers
+    collate the next batch while the current step runs: the graph build then overlaps the
+    adapters of the current step instead of preceding those of the next one."""
 
     def __init__(self, capacity: int = 8):
         self.capacity = capacity
         self._entries: "OrderedDict[tuple, Tuple[torch.Tensor, GraphPlan]]" = OrderedDict()
+        self._pending = {}
+        self._lock = threading.Lock()
+        self._pool: Optional[ThreadPoolExecutor] = None
+        self._side_streams = {}
         self.hits = 0
         self.misses = 0
 
     @staticmethod
     def _key(edge_index: torch.Tensor, num_nodes: int, normalize: bool) -> tuple:
-        return (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape),
-                tuple(edge_index.stride()), str(edge_index.device), int(num_nodes), bool(normalize))
+        # data_ptr is unique among live allocations of all devices; the entry keeps the
+        # tensor alive, so the pointer cannot be recycled while the key exists
+        return (edge_index.data_ptr(), edge_index._version, edge_index.shape[1],
+                edge_index.stride(0), num_nodes, normalize)
+
+    def _store(self, key, edge_index, plan) -> None:
+        self._entries[key] = (edge_index, plan)
+        while len(self._entries) > self.capacity:
+            self._entries.popitem(last=False)
 
     def get(self, edge_index: torch.Tensor, num_nodes: int, normalize: bool) -> GraphPlan:
         key = self._key(edge_index, num_nodes, normalize)
@@ -130,14 +162,50 @@ class PlanCache:
             self._entries.move_to_end(key)
             self.hits += 1
             return hit[1]
-        self.misses += 1
-        plan = GraphPlan(edge_index, num_nodes, normalize)
-        self._entries[key] = (edge_index, plan)
-        while len(self._entries) > self.capacity:
-            self._entries.popitem(last=False)
+        fut = self._pending.pop(key, None)
+        if fut is not None:                       # built (or being built) by the prefetcher
+            plan = fut.result()
+            # the arena was allocated on the side stream but is consumed on this one
+            plan.arena.record_stream(torch.cuda.current_stream(plan.device))
+            self.hits += 1
+        else:
+            self.misses += 1
+            plan = GraphPlan(edge_index, num_nodes, normalize)
+        self._store(key, edge_index, plan)
         return plan
 
+    def prefetch(self, edge_index: torch.Tensor, num_nodes: int, normalize: bool) -> None:
+        """Starts building the plan of a future batch; returns immediately."""
+        key = self._key(edge_index, num_nodes, normalize)
+        if key in self._entries or key in self._pending:
+            return
+        if not edge_index.is_cuda:
+            raise RuntimeError("gconv_adapter_amd has no CPU path: edge_index must live on a HIP device")
+        dev = edge_index.device
+        with self._lock:
+            if self._pool is None:
+                self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="gconv-plan")
+            side = self._side_streams.get(dev)
+            if side is None:
+                side = self._side_streams[dev] = torch.cuda.Stream(device=dev)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))   # edge_index is complete after this point
+
+        def build():
+            with torch.cuda.device(dev), torch.cuda.stream(side):
+                side.wait_event(ready)
+                return GraphPlan(edge_index, num_nodes, normalize)
+
+        self._pending[key] = self._pool.submit(build)
+
+    def discard(self, edge_index: torch.Tensor, num_nodes: int, normalize: bool) -> None:
+        """Drops the plan of a batch that will not be seen again."""
+        self._entries.pop(self._key(edge_index, num_nodes, normalize), None)
+
     def clear(self) -> None:
+        for fut in list(self._pending.values()):
+            fut.result()
+        self._pending.clear()
         self._entries.clear()
 
 
@@ -147,3 +215,8 @@ PLAN_CACHE = PlanCache()
 
 def get_plan(edge_index: torch.Tensor, num_nodes: int, normalize: bool) -> GraphPlan:
     return PLAN_CACHE.get(edge_index, num_nodes, normalize)
+
+
+def prefetch_plan(edge_index: torch.Tensor, num_nodes: int, normalize: bool = True) -> None:
+    """Overlap the graph build of the NEXT batch with the current step (see PlanCache)."""
+    PLAN_CACHE.prefetch(edge_index, num_nodes, normalize)

@@ -90,8 +90,8 @@ def test_graph_build_component_tiles(dev):
     # every tile boundary is a graph boundary, and it is the LAST one at or below t * 64
     gptr = batch.graph_ptr.numpy()
     for t, q in enumerate(tp[:-1]):
-        assert q in gptr and q <= t * 64
-        assert gptr[gptr <= t * 64].max() == q
+        assert q in gptr and q <= t * ga._lib.TILE_NODES
+        assert gptr[gptr <= t * ga._lib.TILE_NODES].max() == q
     # no edge crosses a tile boundary
     ei = batch.edge_index.numpy()
     tile_of = np.searchsorted(tp, np.arange(n), side="right") - 1
