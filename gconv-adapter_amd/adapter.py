@@ -20,8 +20,8 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from . import _lib
-from .functional import GConvAdapterFunction
+from . import _lib, _torch_ext
+from .functional import GConvAdapterFunction, _stream
 from .graph import get_plan
 
 
@@ -118,8 +118,18 @@ class GConvAdapter(nn.Module):
             p = (self.conv_down.lin.weight, self.conv_down.bias, self.conv_up.lin.weight,
                  self.conv_up.bias, self.scalar, _lib.ACT_CODES[self.non_linearity])
             self.__dict__["_flat_params"] = p
-        return GConvAdapterFunction.apply(x2d, p[0], p[1], p[2], p[3], p[4] if fuse_scalar else None,
-                                          plan, p[5], bool(self.skip_connection))
+        ext = _torch_ext.get()
+        if ext is None:   # pure-Python binding of the same C ABI
+            return GConvAdapterFunction.apply(x2d, p[0], p[1], p[2], p[3],
+                                              p[4] if fuse_scalar else None, plan, p[5],
+                                              bool(self.skip_connection))
+        dev = x2d.device
+        if dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        fp, ws_fwd, ws_bwd = plan.sizes(_lib.load(), self.hidden_size, self.bottleneck_size)
+        return ext.adapter_apply(x2d, p[0], p[1], p[2], p[3], p[4] if fuse_scalar else None,
+                                 plan.arena, plan.struct_addr, fp, ws_fwd, ws_bwd, p[5],
+                                 bool(self.skip_connection), _stream(dev.index))
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor,
                 edge_attr: Optional[torch.Tensor] = None) -> torch.Tensor:

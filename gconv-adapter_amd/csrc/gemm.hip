@@ -622,8 +622,16 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
       const float* part = e < rd ? a.part_wd : a.part_wu;
       const int idx = e < rd ? e : e - rd;
       const int c = idx / a.d, j = idx % a.d;
-      for (int p = ps; p < a.nparts; p += 8)
-        sum += part[(static_cast<size_t>(p) * a.fp + c) * a.d + j];
+      const size_t stride = static_cast<size_t>(a.fp) * a.d;
+      const float* q = part + static_cast<size_t>(c) * a.d + j;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // 4 loads in flight, fixed order
+      int p = ps;
+      for (; p + 24 < a.nparts; p += 32) {
+        s0 += q[p * stride]; s1 += q[(p + 8) * stride];
+        s2 += q[(p + 16) * stride]; s3 += q[(p + 24) * stride];
+      }
+      for (; p < a.nparts; p += 8) s0 += q[p * stride];
+      sum = (s0 + s1) + (s2 + s3);
     } else if (e < 2 * rd + a.d) {
       const int j = e - 2 * rd;
       for (int p = ps; p < a.nparts; p += 8) sum += a.part_cs[static_cast<size_t>(p) * a.d + j];

@@ -62,8 +62,14 @@ __global__ void make_keys_kernel(const int64_t* __restrict__ ei, int64_t E, int3
                     : ko.make(static_cast<uint32_t>(d), static_cast<uint32_t>(s));
     if (span && s != d) {  // boundaries lo+1 .. hi are crossed by this edge
       const int lo = static_cast<int>(s < d ? s : d), hi = static_cast<int>(s < d ? d : s);
-      atomicAdd(&span[lo + 1], 1);
-      atomicAdd(&span[hi + 1], -1);
+      if (hi - lo > GCONV_TILE_NODES + GCONV_TILE_BACK) {
+        // wider than any tile: the graph is not tileable; skip the atomics (on power-law
+        // graphs thousands of them would pile up on the hub's counter)
+        if (info[INFO_NOTILE] == 0) atomicOr(&info[INFO_NOTILE], 1);
+      } else {
+        atomicAdd(&span[lo + 1], 1);
+        atomicAdd(&span[hi + 1], -1);
+      }
     }
   }
   keys[e] = key;

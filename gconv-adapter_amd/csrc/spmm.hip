@@ -140,35 +140,48 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(SpmmArgs a) {
 
   f32x4 bias_grad = zero4();
   const int row = (blockIdx.x * 4 + wave) * RPW + grp;
-  if (row < a.n) {
-    const int e0 = a.rowptr[row], e1 = a.rowptr[row + 1];
-    if (e1 - e0 <= GCONV_LONG_ROW) {
-      f32x4 acc0 = zero4(), acc1 = zero4();
-      int e = e0;
-      for (; e + 8 <= e1; e += 8) {
-        int c[8];
+  const int rowc = min(row, a.n - 1);
+  const int e0 = a.rowptr[rowc], e1 = a.rowptr[rowc + 1];
+  const bool mine = row < a.n && (e1 - e0) <= GCONV_LONG_ROW;  // long rows: segment path
+  const int deg = mine ? e1 - e0 : 0;
+
+  // The loop over 8-edge batches is WAVE-UNIFORM (trip count = longest row of the wave), so
+  // it can be software-pipelined without hipcc fencing every load: the 8 column indices of a
+  // batch are fetched by the row's own lanes (8 / LPR coalesced loads, the next batch's are
+  // in flight during the gathers) and broadcast by lane shuffle; edges past the end of a
+  // row gather the row's own line instead (an L1 hit) and are masked out of the sum.
+  constexpr int CPL = (8 + LPR - 1) / LPR;  // column loads per lane per batch
+  int nbat = (deg + 7) >> 3;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) c[u] = col[e + u];
-        f32x4 h[8];
+  for (int off = 32; off > 0; off >>= 1) nbat = max(nbat, __shfl_xor(nbat, off));
+  nbat = __builtin_amdgcn_readfirstlane(nbat);
+  const int elast = max(e1 - 1, 0);
+  int cn[CPL];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) h[u] = ldg4(H + static_cast<size_t>(c[u]) * F + 4 * sub);
-        if (gather_scale) {
+  for (int j = 0; j < CPL; ++j) cn[j] = col[min(e0 + sub + j * LPR, elast)];
+  f32x4 acc0 = zero4(), acc1 = zero4();
+  for (int it = 0; it < nbat; ++it) {
+    int cc[CPL];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) h[u] *= a.dis[c[u]];
-        }
-        // fixed association order: ((h0+h1)+(h2+h3)) + ((h4+h5)+(h6+h7))
-        acc0 += (h[0] + h[1]) + (h[2] + h[3]);
-        acc1 += (h[4] + h[5]) + (h[6] + h[7]);
-      }
-      for (; e < e1; ++e) {
-        int c = col[e];
-        f32x4 h = ldg4(H + static_cast<size_t>(c) * F + 4 * sub);
-        if (gather_scale) h *= a.dis[c];
-        acc0 += h;
-      }
-      spmm_epilogue<F, NORM, EPI>(a, row, sub, acc0 + acc1, bias_grad);
+    for (int j = 0; j < CPL; ++j) cc[j] = cn[j];
+    const int eb = e0 + 8 * it;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) cn[j] = col[min(eb + 8 + sub + j * LPR, elast)];
+    f32x4 h[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int c = __shfl(cc[u / LPR], grp * LPR + (u % LPR));
+      c = (eb + u < e0 + deg) ? c : rowc;
+      h[u] = ldg4(H + static_cast<size_t>(c) * F + 4 * sub);
+      if (gather_scale) h[u] *= a.dis[c];
     }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) h[u] = (eb + u < e0 + deg) ? h[u] : zero4();
+    // fixed association order: ((h0+h1)+(h2+h3)) + ((h4+h5)+(h6+h7))
+    acc0 += (h[0] + h[1]) + (h[2] + h[3]);
+    acc1 += (h[4] + h[5]) + (h[6] + h[7]);
   }
+  if (mine) spmm_epilogue<F, NORM, EPI>(a, row, sub, acc0 + acc1, bias_grad);
   if (EPI == EPI_BWD1) block_bias_partial<F>(bias_grad, a.bias_partial + static_cast<size_t>(blockIdx.x) * F);
 }
 

@@ -83,6 +83,7 @@ class GraphPlan:
         self.bwd = self.fwd if self.symmetric else CsrView(self, self.struct.bwd)
         self.n_tiles, self.tile_nodes_max = self.struct.n_tiles, self.struct.tile_nodes_max
         self._ref = C.byref(self.struct)
+        self.struct_addr = C.addressof(self.struct)
         self._sizes = {}
 
     def sizes(self, lib, d: int, r: int):

@@ -183,3 +183,13 @@ def test_workload_shapes():
     assert b.num_graphs == 32 and 300 < b.num_nodes < 600 and cfg["r"] == 4
     b, cfg = ga.synth.make_workload("cora")
     assert b.x.shape == (1, 2708, 32) and cfg["r"] == 16
+
+
+def test_cpp_autograd_binding_loads_and_binds_the_same_c_abi():
+    ext = ga._torch_ext.get()
+    assert ext is not None, "lib/_gconv_torch.so missing: run __graft_entry__.build()"
+    assert hasattr(ext, "adapter_apply") and hasattr(ext, "load_library")
+    # CPU tensors are refused by the binding as well (RuntimeError, no compute fallback)
+    with pytest.raises(RuntimeError):
+        ext.adapter_apply(torch.randn(2, 8), torch.randn(2, 8), None, torch.randn(8, 2), None, None,
+                          torch.zeros(1, dtype=torch.uint8), 0, 4, 16, 16, 1, True, 0)
