@@ -47,6 +47,7 @@ class GraphStruct(C.Structure):
         ("tile_ptr", C.c_void_p),
         ("n_tiles", C.c_int32),
         ("tile_nodes_max", C.c_int32),
+        ("tile_edges_max", C.c_int32),
         ("symmetric", C.c_int32),
         ("normalize", C.c_int32),
         ("max_degree", C.c_int32),

@@ -183,7 +183,7 @@ extern "C" gconv_status_t gconv_adapter_fwd_f32(const gconv_graph_t* gr,
     t.x = x; t.out = out; t.saved_h = saved_h; t.saved_h1 = saved_h1; t.saved_p = saved_p;
     t.w_down = p->w_down; t.b_down = p->b_down; t.w_up = p->w_up; t.b_up = p->b_up;
     t.scalar = p->scalar; t.d = d; t.r = r; t.fp = fp; t.act = p->act; t.skip = p->skip;
-    return launch_tile_fwd(t, gr->n_tiles, gr->tile_nodes_max, stream);
+    return launch_tile_fwd(t, gr->n_tiles, gr->tile_nodes_max, gr->tile_edges_max, stream);
   }
   const FwdWs ws = carve_fwd(workspace, graph, fp);
   if (workspace_bytes < ws.bytes) return GCONV_E_WORKSPACE;
@@ -246,7 +246,7 @@ extern "C" gconv_status_t gconv_adapter_bwd_f32(const gconv_graph_t* gr,
     t.part_bd = tw.part_bd; t.part_ds = tw.part_ds;
     t.d = d; t.r = r; t.fp = fp; t.act = p->act; t.skip = p->skip;
     t.want_ds = grad_scalar != nullptr;
-    st = launch_tile_bwd(t, gr->n_tiles, gr->tile_nodes_max, stream);
+    st = launch_tile_bwd(t, gr->n_tiles, gr->tile_nodes_max, gr->tile_edges_max, stream);
     if (st != GCONV_OK) return st;
     FinalizeArgs f{};   // ONE launch: every partial (d(scalar) included) is complete per workgroup
     f.part_wd = tw.part_wd; f.part_wu = tw.part_wu; f.part_cs = tw.part_cs; f.nparts = tw.nparts;

@@ -27,12 +27,14 @@ struct TileBwdArgs {
 
 // true if the graph is tiled and one tile's rank-width state fits the LDS budget
 bool tile_path_ok(const gconv_graph_t* g, int d, int fp);
-size_t tile_lds_bytes(int d, int fp, int tile_nodes_max);
+size_t tile_lds_bytes(int d, int fp, int tile_nodes_max, int tile_edges_max);
 
 // workgroups the tile kernels are launched with (= partial rows of the backward)
 int tile_grid(int n_tiles);
 
-gconv_status_t launch_tile_fwd(TileFwdArgs a, int n_tiles, int tile_nodes_max, hipStream_t stream);
-gconv_status_t launch_tile_bwd(TileBwdArgs a, int n_tiles, int tile_nodes_max, hipStream_t stream);
+gconv_status_t launch_tile_fwd(TileFwdArgs a, int n_tiles, int tile_nodes_max, int tile_edges_max,
+                               hipStream_t stream);
+gconv_status_t launch_tile_bwd(TileBwdArgs a, int n_tiles, int tile_nodes_max, int tile_edges_max,
+                               hipStream_t stream);
 
 }  // namespace gconv

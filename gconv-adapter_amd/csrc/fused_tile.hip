@@ -130,23 +130,30 @@ __device__ __forceinline__ float tile_rowsA(const float* __restrict__ M, const f
 
 // Phases 2 / 3: one lane group (FP/4 lanes) per tile row, neighbour rows gathered from LDS.
 //   sum = sum over stored edges of src[col - ts]; v = NORM ? dis * (sum + src[row]) : sum
+// `rp` / `cl`: the tile's CSR slice staged in LDS (local row offsets, local column ids)
 template <int FP, bool NORM>
-__device__ __forceinline__ f32x4 tile_row_sum(const float* src, const int32_t* __restrict__ rowptr,
-                                              const int32_t* __restrict__ col,
-                                              const float* __restrict__ dis, int ts, int lrow,
-                                              int sub) {
-  const int row = ts + lrow;
-  const int e0 = rowptr[row], e1 = rowptr[row + 1];
+__device__ __forceinline__ f32x4 tile_row_sum(const float* src, const int32_t* rp,
+                                              const int32_t* cl, const float* __restrict__ dis,
+                                              int ts, int lrow, int sub) {
+  const int e0 = rp[lrow], e1 = rp[lrow + 1];
   f32x4 acc = zero4f();
-  for (int e = e0; e < e1; ++e) {
-    const int c = col[e] - ts;
-    acc += *reinterpret_cast<const f32x4*>(src + c * FP + 4 * sub);
-  }
+  for (int e = e0; e < e1; ++e)
+    acc += *reinterpret_cast<const f32x4*>(src + cl[e] * FP + 4 * sub);
   if (NORM) {
     acc += *reinterpret_cast<const f32x4*>(src + lrow * FP + 4 * sub);
-    acc *= dis[row];
+    acc *= dis[ts + lrow];
   }
   return acc;
+}
+
+// Stages the CSR slice of tile rows [ts, ts + nt) into LDS (issued at tile start, so its
+// latency hides under phase 1's X loads; the barrier after phase 1 publishes it).
+__device__ __forceinline__ void stage_tile_csr(const int32_t* __restrict__ rowptr,
+                                               const int32_t* __restrict__ col, int ts, int nt,
+                                               int32_t* rp, int32_t* cl) {
+  const int e0 = rowptr[ts], ne = rowptr[ts + nt] - e0;
+  for (int i = threadIdx.x; i <= nt; i += blockDim.x) rp[i] = rowptr[ts + i] - e0;
+  for (int e = threadIdx.x; e < ne; e += blockDim.x) cl[e] = col[e0 + e] - ts;
 }
 
 }  // namespace
@@ -155,7 +162,7 @@ __device__ __forceinline__ f32x4 tile_row_sum(const float* src, const int32_t* _
 // forward — persistent workgroups walk the tiles (weights staged / loaded once)
 // ===========================================================================
 template <int FP, int NQ, bool NORM>
-__global__ __launch_bounds__(512) void tile_fwd_kernel(TileFwdArgs a) {
+__global__ __launch_bounds__(512, 4) void tile_fwd_kernel(TileFwdArgs a) {
   extern __shared__ f32x4 lds4[];
   constexpr int NCB = FP >= 16 ? FP / 16 : 1;
   constexpr int KS = FP / 4;
@@ -163,6 +170,9 @@ __global__ __launch_bounds__(512) void tile_fwd_kernel(TileFwdArgs a) {
   f32x4* wl = lds4;                                              // [NQ][NCB][64]
   float* bufA = reinterpret_cast<float*>(lds4 + NQ * NCB * 64);  // [cap][FP]  H0', later P
   float* bufB = bufA + a.cap * FP;                               // [cap][FP]  H2'
+  float* bufC = bufB + a.cap * FP;                               // (backward only: P tile)
+  int32_t* rp = reinterpret_cast<int32_t*>(bufC + a.cap * FP + 8 * (FP + 2));  // [cap + 1]
+  int32_t* cl = rp + a.cap + 16;                                 // [ecap]
 
   const int lane = threadIdx.x & 63, wave = wave_id();
   const int nwaves = blockDim.x >> 6;
@@ -199,13 +209,14 @@ __global__ __launch_bounds__(512) void tile_fwd_kernel(TileFwdArgs a) {
     const int ts = a.tile_ptr[tile], nt = a.tile_ptr[tile + 1] - ts;
     if (nt <= 0) continue;  // uniform
 
-    // ---- phase 1: H0' -> bufA
+    // ---- phase 1: H0' -> bufA (the tile's CSR slice lands in LDS meanwhile)
+    stage_tile_csr(a.rowptr, a.col, ts, nt, rp, cl);
     tile_rowsA<FP, NQ>(a.x, wl, bufA, a.dis, nullptr, 1.f, ts, nt, a.d, nwaves, wave, lane);
     __syncthreads();
 
     // ---- phase 2: H2' -> bufB (+ saved_h, saved_h1)
     for (int lr = grp; lr < nt; lr += ngrp) {
-      f32x4 v = tile_row_sum<FP, NORM>(bufA, a.rowptr, a.col, a.dis, ts, lr, sub);
+      f32x4 v = tile_row_sum<FP, NORM>(bufA, rp, cl, a.dis, ts, lr, sub);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int c = 4 * sub + k;
@@ -223,7 +234,7 @@ __global__ __launch_bounds__(512) void tile_fwd_kernel(TileFwdArgs a) {
 
     // ---- phase 3: P -> bufA (+ saved_p)
     for (int lr = grp; lr < nt; lr += ngrp) {
-      const f32x4 v = tile_row_sum<FP, NORM>(bufB, a.rowptr, a.col, a.dis, ts, lr, sub);
+      const f32x4 v = tile_row_sum<FP, NORM>(bufB, rp, cl, a.dis, ts, lr, sub);
       *reinterpret_cast<f32x4*>(bufA + lr * FP + 4 * sub) = v;
       stg4(a.saved_p + static_cast<size_t>(ts + lr) * FP + 4 * sub, v);
     }
@@ -291,7 +302,10 @@ __global__ __launch_bounds__(512) void tile_bwd_kernel(TileBwdArgs a) {
   f32x4* wl = lds4;                                              // [NQ][NCB][64]  W_up^T frags
   float* bufA = reinterpret_cast<float*>(lds4 + NQ * NCB * 64);  // [cap][FP]  dP', later T
   float* bufB = bufA + a.cap * FP;                               // [cap][FP]  dH1'
-  float* red = bufB + a.cap * FP;                                // [nwaves][FP + 2] scratch
+  float* bufC = bufB + a.cap * FP;                               // [cap][FP]  P tile
+  float* red = bufC + a.cap * FP;                                // [nwaves][FP + 2] scratch
+  int32_t* rp = reinterpret_cast<int32_t*>(red + 8 * (FP + 2));  // [cap + 1]
+  int32_t* cl = rp + a.cap + 16;                                 // [ecap]
 
   const int lane = threadIdx.x & 63, wave = wave_id();
   const int nwaves = blockDim.x >> 6;
@@ -332,13 +346,17 @@ __global__ __launch_bounds__(512) void tile_bwd_kernel(TileBwdArgs a) {
     if (nt <= 0) continue;  // uniform
 
     // ---- phase 1: dP' = dis . s (G Wu) -> bufA ; ds1 += sum (G Wu) . P
+    // (the tile's CSR slice and its P rows land in LDS meanwhile)
+    stage_tile_csr(a.rowptr, a.col, ts, nt, rp, cl);
+    for (int i = threadIdx.x; i < nt * LPR; i += blockDim.x)
+      *reinterpret_cast<f32x4*>(bufC + 4 * i) = ldg4(a.saved_p + static_cast<size_t>(ts) * FP + 4 * i);
     ds1 += tile_rowsA<FP, NQ>(a.g, wl, bufA, a.dis, a.want_ds ? a.saved_p : nullptr, sval, ts, nt,
                               a.d, nwaves, wave, lane);
     __syncthreads();
 
     // ---- phase 2: dH1' = dis . (S^T dP . act') -> bufB ; bias gradient
     for (int lr = grp; lr < nt; lr += ngrp) {
-      f32x4 v = tile_row_sum<FP, NORM>(bufA, a.rowptr, a.col, a.dis, ts, lr, sub);
+      f32x4 v = tile_row_sum<FP, NORM>(bufA, rp, cl, a.dis, ts, lr, sub);
       const size_t off = static_cast<size_t>(ts + lr) * FP + 4 * sub;
       if (a.act == GCONV_ACT_RELU) {
         const f32x4 h2 = ldg4(a.saved_h + off);
@@ -357,7 +375,7 @@ __global__ __launch_bounds__(512) void tile_bwd_kernel(TileBwdArgs a) {
 
     // ---- phase 3: T = S^T dH1 -> bufA
     for (int lr = grp; lr < nt; lr += ngrp) {
-      const f32x4 v = tile_row_sum<FP, NORM>(bufB, a.rowptr, a.col, a.dis, ts, lr, sub);
+      const f32x4 v = tile_row_sum<FP, NORM>(bufB, rp, cl, a.dis, ts, lr, sub);
       *reinterpret_cast<f32x4*>(bufA + lr * FP + 4 * sub) = v;
     }
     __syncthreads();
@@ -387,7 +405,7 @@ __global__ __launch_bounds__(512) void tile_bwd_kernel(TileBwdArgs a) {
           for (int cb = 0; cb < NCB; ++cb) {
             const int rc = 16 * cb + jj, rcc = min(rc, FP - 1);
             const float vt = bufA[lrc * FP + rcc];
-            const float vp = a.saved_p[static_cast<size_t>(ts + lrc) * FP + rcc];
+            const float vp = bufC[lrc * FP + rcc];
             const bool ok = lr < nt && rc < FP;
             at[m][cb] = ok ? vt : 0.f;
             ap[m][cb] = ok ? vp : 0.f;
@@ -516,18 +534,20 @@ static int tile_threads(int d) {
   return 64 * w;
 }
 
-size_t tile_lds_bytes(int d, int fp, int tile_nodes_max) {
+size_t tile_lds_bytes(int d, int fp, int tile_nodes_max, int tile_edges_max) {
   const int nq = tile_nq(d), ncb = fp >= 16 ? fp / 16 : 1;
   const int cap = ceil_div(tile_nodes_max > 0 ? tile_nodes_max : 1, 16) * 16;
-  return static_cast<size_t>(nq) * ncb * 64 * sizeof(f32x4) +
-         static_cast<size_t>(2) * cap * fp * sizeof(float) + 8 * (fp + 2) * sizeof(float) + 64;
+  return static_cast<size_t>(nq) * ncb * 64 * sizeof(f32x4) +              // weight fragments
+         static_cast<size_t>(3) * cap * fp * sizeof(float) +                // rank-width tiles
+         8 * (fp + 2) * sizeof(float) +                                     // reduction scratch
+         (static_cast<size_t>(cap) + 16 + (tile_edges_max > 0 ? tile_edges_max : 1)) * 4 + 64;
 }
 
 bool tile_path_ok(const gconv_graph_t* g, int d, int fp) {
   if (g->n_tiles <= 0 || tile_nq(d) == 0 || fp > 32 || ceil_div(d, 64) > 8) return false;
   static const bool off = getenv("GCONV_NO_TILE_PATH") != nullptr;  // debugging / A-B knob
   if (off) return false;
-  return tile_lds_bytes(d, fp, g->tile_nodes_max) <= 64 * 1024;
+  return tile_lds_bytes(d, fp, g->tile_nodes_max, g->tile_edges_max) <= 64 * 1024;
 }
 
 template <int FP, int NQ>
@@ -571,23 +591,23 @@ int tile_grid(int n_tiles) {  // persistent: <= 2 workgroups per CU
 }
 
 gconv_status_t launch_tile_fwd(TileFwdArgs a, int n_tiles, int tile_nodes_max,
-                               hipStream_t stream) {
+                               int tile_edges_max, hipStream_t stream) {
   const int nq = tile_nq(a.d);
   a.n_tiles = n_tiles;
   n_tiles = tile_grid(n_tiles);
   a.cap = ceil_div(tile_nodes_max > 0 ? tile_nodes_max : 1, 16) * 16;
-  const size_t lds = tile_lds_bytes(a.d, a.fp, tile_nodes_max);
+  const size_t lds = tile_lds_bytes(a.d, a.fp, tile_nodes_max, tile_edges_max);
   const int threads = tile_threads(a.d);
   GCONV_TILE_DISPATCH(launch_tile_fwd_t, (a, n_tiles, threads, lds, stream))
 }
 
 gconv_status_t launch_tile_bwd(TileBwdArgs a, int n_tiles, int tile_nodes_max,
-                               hipStream_t stream) {
+                               int tile_edges_max, hipStream_t stream) {
   const int nq = tile_nq(a.d);
   a.n_tiles = n_tiles;
   n_tiles = tile_grid(n_tiles);
   a.cap = ceil_div(tile_nodes_max > 0 ? tile_nodes_max : 1, 16) * 16;
-  const size_t lds = tile_lds_bytes(a.d, a.fp, tile_nodes_max);
+  const size_t lds = tile_lds_bytes(a.d, a.fp, tile_nodes_max, tile_edges_max);
   const int threads = tile_threads(a.d);
   GCONV_TILE_DISPATCH(launch_tile_bwd_t, (a, n_tiles, threads, lds, stream))
 }

@@ -610,11 +610,27 @@ gconv_status_t launch_bwd_main(const BwdMainArgs& a, hipStream_t stream) {
 // B5: fixed-order reduction of the per-workgroup partials
 // ===========================================================================
 // element space: [0, r d) dW_down | [r d, 2 r d) dW_up | [2 r d, 2 r d + d) colsum(G)
-//                | [2 r d + d, 2 r d + d + r) db_down
-// block = 32 consecutive elements x 8 interleaved partial streams.
+//                | [2 r d + d, 2 r d + d + r) db_down | (+ 1: d(scalar) when complete)
+// block = kFinE consecutive elements x kFinS interleaved partial streams; every stream keeps
+// 4 loads in flight; streams are added in a fixed tree.
+constexpr int kFinE = 16, kFinS = 16;
+
+__device__ __forceinline__ float strided_sum(const float* __restrict__ q, size_t stride, int first,
+                                             int count) {
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int p = first;
+  for (; p + 3 * kFinS < count; p += 4 * kFinS) {
+    s0 += q[p * stride]; s1 += q[(p + kFinS) * stride];
+    s2 += q[(p + 2 * kFinS) * stride]; s3 += q[(p + 3 * kFinS) * stride];
+  }
+  for (; p < count; p += kFinS) s0 += q[p * stride];
+  return (s0 + s1) + (s2 + s3);
+}
+
 __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
-  __shared__ float red[8][32];
-  const int e = blockIdx.x * 32 + (threadIdx.x & 31), ps = threadIdx.x >> 5;
+  __shared__ float red[kFinS][kFinE];
+  const int le = threadIdx.x % kFinE, ps = threadIdx.x / kFinE;
+  const int e = blockIdx.x * kFinE + le;
   const int rd = a.r * a.d, total = 2 * rd + a.d + a.r + (a.ds_complete ? 1 : 0);
   float sum = 0.f;
   if (e < total) {
@@ -622,46 +638,41 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
       const float* part = e < rd ? a.part_wd : a.part_wu;
       const int idx = e < rd ? e : e - rd;
       const int c = idx / a.d, j = idx % a.d;
-      const size_t stride = static_cast<size_t>(a.fp) * a.d;
-      const float* q = part + static_cast<size_t>(c) * a.d + j;
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // 4 loads in flight, fixed order
-      int p = ps;
-      for (; p + 24 < a.nparts; p += 32) {
-        s0 += q[p * stride]; s1 += q[(p + 8) * stride];
-        s2 += q[(p + 16) * stride]; s3 += q[(p + 24) * stride];
-      }
-      for (; p < a.nparts; p += 8) s0 += q[p * stride];
-      sum = (s0 + s1) + (s2 + s3);
+      sum = strided_sum(part + static_cast<size_t>(c) * a.d + j, static_cast<size_t>(a.fp) * a.d, ps,
+                        a.nparts);
     } else if (e < 2 * rd + a.d) {
-      const int j = e - 2 * rd;
-      for (int p = ps; p < a.nparts; p += 8) sum += a.part_cs[static_cast<size_t>(p) * a.d + j];
+      sum = strided_sum(a.part_cs + (e - 2 * rd), a.d, ps, a.nparts);
     } else if (e < 2 * rd + a.d + a.r) {
-      const int c = e - 2 * rd - a.d;
-      for (int p = ps; p < a.n_bd; p += 8) sum += a.part_bd[static_cast<size_t>(p) * a.fp + c];
+      sum = strided_sum(a.part_bd + (e - 2 * rd - a.d), a.fp, ps, a.n_bd);
     } else {
-      for (int p = ps; p < a.n_ds1; p += 8) sum += a.part_ds1[p];
+      sum = strided_sum(a.part_ds1, 1, ps, a.n_ds1);
     }
   }
-  red[ps][threadIdx.x & 31] = sum;
+  red[ps][le] = sum;
   __syncthreads();
   if (ps == 0 && e < total) {
-    const int x = threadIdx.x;
-    const float v = ((red[0][x] + red[1][x]) + (red[2][x] + red[3][x])) +
-                    ((red[4][x] + red[5][x]) + (red[6][x] + red[7][x]));
+    float v[kFinS];
+#pragma unroll
+    for (int k = 0; k < kFinS; ++k) v[k] = red[k][le];
+#pragma unroll
+    for (int w = 1; w < kFinS; w <<= 1)
+#pragma unroll
+      for (int k = 0; k < kFinS; k += 2 * w) v[k] += v[k + w];
+    const float r0 = v[0];
     const float sval = a.scalar ? a.scalar[0] : 1.f;
     if (e < rd) {
-      a.g_wd[e] = v;
+      a.g_wd[e] = r0;
     } else if (e < 2 * rd) {
       const int idx = e - rd, c = idx / a.d, j = idx % a.d;
-      a.g_wu[static_cast<size_t>(j) * a.r + c] = sval * v;
+      a.g_wu[static_cast<size_t>(j) * a.r + c] = sval * r0;
     } else if (e < 2 * rd + a.d) {
       const int j = e - 2 * rd;
-      a.cs_tmp[j] = v;
-      if (a.g_bu) a.g_bu[j] = sval * v;
+      a.cs_tmp[j] = r0;
+      if (a.g_bu) a.g_bu[j] = sval * r0;
     } else if (e < 2 * rd + a.d + a.r) {
-      if (a.g_bd) a.g_bd[e - 2 * rd - a.d] = v;
+      if (a.g_bd) a.g_bd[e - 2 * rd - a.d] = r0;
     } else {
-      if (a.g_s) a.g_s[0] = v;
+      if (a.g_s) a.g_s[0] = r0;
     }
   }
 }
@@ -715,7 +726,7 @@ gconv_status_t launch_reduce_rows(const float* in, int rows, int width, float* o
 
 gconv_status_t launch_finalize(const FinalizeArgs& a, hipStream_t stream) {
   const int total = 2 * a.r * a.d + a.d + a.r + (a.ds_complete ? 1 : 0);
-  finalize_kernel<<<ceil_div(total, 32), 256, 0, stream>>>(a);
+  finalize_kernel<<<ceil_div(total, kFinE), 256, 0, stream>>>(a);
   GCONV_LAUNCH_CHECK();
   if (a.g_s && !a.ds_complete) {
     finalize_scalar_kernel<<<1, 256, 0, stream>>>(a);

@@ -22,7 +22,7 @@ namespace gconv {
 
 enum {
   INFO_NNZ = 0, INFO_NLONG = 1, INFO_NSEG = 2, INFO_MAXDEG = 3, INFO_BAD = 4,
-  INFO_ASYM = 5, INFO_NOTILE = 6, INFO_TILEMAX = 7, INFO_WORDS = 8
+  INFO_ASYM = 5, INFO_NOTILE = 6, INFO_TILEMAX = 7, INFO_TILEEDGES = 8, INFO_WORDS = 9
 };
 
 template <typename K>
@@ -155,12 +155,23 @@ __global__ void tile_start_kernel(const int32_t* __restrict__ span_ps, int32_t n
   tile_ptr[t] = q;
 }
 
-__global__ void tile_max_kernel(const int32_t* __restrict__ tile_ptr, int ntiles,
+__global__ void tile_max_kernel(const int32_t* __restrict__ tile_ptr,
+                                const int32_t* __restrict__ rowptr, int ntiles,
                                 int32_t* __restrict__ info) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  int sz = (t < ntiles) ? tile_ptr[t + 1] - tile_ptr[t] : 0;
-  for (int off = 32; off > 0; off >>= 1) sz = max(sz, __shfl_xor(sz, off));
-  if ((threadIdx.x & 63) == 0 && sz > 0) atomicMax(&info[INFO_TILEMAX], sz);
+  int sz = 0, ed = 0;
+  if (t < ntiles) {
+    sz = tile_ptr[t + 1] - tile_ptr[t];
+    ed = rowptr[tile_ptr[t + 1]] - rowptr[tile_ptr[t]];
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    sz = max(sz, __shfl_xor(sz, off));
+    ed = max(ed, __shfl_xor(ed, off));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (sz > 0) atomicMax(&info[INFO_TILEMAX], sz);
+    if (ed > 0) atomicMax(&info[INFO_TILEEDGES], ed);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -315,7 +326,7 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
     GCONV_HIP(hipcub::DeviceScan::InclusiveSum(arena + L.cub, cub_bytes, span, span_ps, n + 2, stream));
     tile_start_kernel<<<(L.ntiles + 1 + T - 1) / T, T, 0, stream>>>(span_ps, n, L.ntiles, tile_ptr, info);
     GCONV_LAUNCH_CHECK();
-    tile_max_kernel<<<(L.ntiles + T - 1) / T, T, 0, stream>>>(tile_ptr, L.ntiles, info);
+    tile_max_kernel<<<(L.ntiles + T - 1) / T, T, 0, stream>>>(tile_ptr, of.rowptr, L.ntiles, info);
     GCONV_LAUNCH_CHECK();
   }
   int32_t h[64];
@@ -349,6 +360,7 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
   g->tile_ptr = tile_ptr;
   g->n_tiles = (h[INFO_NOTILE] || n == 0) ? 0 : L.ntiles;
   g->tile_nodes_max = h[INFO_TILEMAX];
+  g->tile_edges_max = h[INFO_TILEEDGES];
   g->normalize = normalize ? 1 : 0;
   g->bad_index = 0;
   return GCONV_OK;

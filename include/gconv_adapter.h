@@ -107,6 +107,7 @@ typedef struct gconv_graph {
   const int32_t* tile_ptr;       /* [n_tiles + 1] node offsets of the component tiles   */
   int32_t        n_tiles;        /* 0: not tileable (an edge-free boundary was not found) */
   int32_t        tile_nodes_max; /* nodes in the largest tile                           */
+  int32_t        tile_edges_max; /* stored edges (of fwd, == bwd count) in the largest tile */
   int32_t        symmetric;      /* edge multiset equals its transpose                  */
   int32_t        normalize;
   int32_t        max_degree;     /* of `fwd`                                            */
