@@ -182,6 +182,14 @@ def measure_arxiv(device, iters: int = 50) -> dict:
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "frac_of_measured_copy_peak": round(achieved / HBM_MEASURED_GBS, 4),
             "algorithmic_bytes": b, "avg_launch_us": round(ms * 1e3, 2), "traffic": None}
+    pmc = os.path.join(ROOT, "profiles", "r01_spmm_arxiv_pmc.json")
+    if os.path.exists(pmc):   # PMC passes cannot run inside the timed bench: committed rocprofv3 result
+        with open(pmc) as fh:
+            dv = json.load(fh)["derived"]
+        roof["traffic"] = round(dv["traffic_bytes_per_launch"])
+        roof["traffic_source"] = ("profiles/r01_spmm_arxiv_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE per launch "
+                                  "(separate rocprofv3 --pmc passes, gfx950 x2 fetch correction); L2 hit rate "
+                                  f"{dv['l2_hit_rate']:.2f}")
 
     mod = build_adapters(dict(d=d, r=r, adapters=1), True, device)[0]
     x = batch.x.to(device).requires_grad_(True)

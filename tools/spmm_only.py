@@ -1,0 +1,18 @@
+"""Runs only the S-arxiv normalized SpMM (rank 32, production flags) a few times — target of the
+rocprofv3 --pmc passes that give the roofline `traffic` figure."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import gconv_adapter_amd as ga
+dev = torch.device("cuda:0")
+batch, cfg = ga.synth.make_workload("arxiv")
+n, r = batch.num_nodes, cfg["r"]
+plan = ga.get_plan(batch.edge_index.to(dev), n, True)
+h = torch.randn(n, r, device=dev); y = torch.empty_like(h)
+lib = ga._lib.load()
+ws = torch.empty(max(int(lib.gconv_spmm_workspace_bytes(plan.fwd.ref(), r)), 16), dtype=torch.uint8, device=dev)
+fl = ga._lib.SPMM_IN_PRESCALED | ga._lib.SPMM_OUT_PRESCALE
+for _ in range(20):
+    ga.spmm(plan, h, flags=fl, out=y, workspace=ws)
+torch.cuda.synchronize()
+print("nnz", plan.fwd.nnz, "n_long", plan.fwd.n_long, "n_seg", plan.fwd.n_seg)
