@@ -96,17 +96,14 @@ class BatchStream:
 def adapter_step(mods, stream: BatchStream, normalize: bool, bucket=None):
     """fwd + bwd of the adapter chain on the next batch (+ gradient all-reduce)."""
     batch, x, ei, gout = stream.next(normalize)
-    if bucket is not None:
-        bucket.zero_()
-    else:
-        for p in mods.parameters():
-            p.grad = None
+    for p in mods.parameters():
+        p.grad = None
     h = x
     for m in mods:
         h = m(h, ei)
     h.backward(gout)
     if bucket is not None:
-        bucket.all_reduce()
+        bucket.all_reduce_grads()   # one cat + ONE flat all-reduce + one multi-tensor copy
     if stream.fresh:
         ga.PLAN_CACHE.discard(ei, x.shape[-2], normalize)   # a training batch is seen once
     return batch.num_graphs
@@ -308,12 +305,19 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU product path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; on a box with fewer GPUs than ranks (functional rehearsal of the
+    # N > 1 path only) ranks wrap around and RCCL is replaced by gloo
+    ngpu = torch.cuda.device_count()
+    dev_index = local_rank % max(ngpu, 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=device)
+        backend = os.environ.get("GCONV_BENCH_BACKEND", "nccl" if world <= ngpu else "gloo")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     normalize = bool(args.normalize)
     ga._lib.load()
 

@@ -147,6 +147,8 @@ class GConvAdapter(nn.Module):
         if x.dim() not in (2, 3) or x.size(-1) != self.hidden_size:
             raise RuntimeError(f"x must be [N, {self.hidden_size}] or [B, N, {self.hidden_size}], "
                                f"got {tuple(x.shape)}")
+        if edge_index.device != x.device:
+            raise RuntimeError(f"x is on {x.device} but edge_index is on {edge_index.device}")
         # the scalar is fused into the kernel epilogue unless a normalization layer sits
         # between the residual add and the scalar (reference order :94-106)
         fuse_scalar = self.normalization is None

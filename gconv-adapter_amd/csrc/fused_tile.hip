@@ -24,6 +24,10 @@
 
 #include "fused_tile.h"
 
+#ifndef GCONV_BWD_WAVES
+#define GCONV_BWD_WAVES 2
+#endif
+
 namespace gconv {
 
 namespace {
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(512, 4) void tile_fwd_kernel(TileFwdArgs a) {
 // partial row per workgroup reaches HBM and B5 is a single launch.
 // ===========================================================================
 template <int FP, int NQ, bool NORM, bool NEED_DX>
-__global__ __launch_bounds__(512) void tile_bwd_kernel(TileBwdArgs a) {
+__global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdArgs a) {
   extern __shared__ f32x4 lds4[];
   constexpr int NCB = FP >= 16 ? FP / 16 : 1;
   constexpr int KS = FP / 4;

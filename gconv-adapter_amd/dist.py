@@ -68,8 +68,15 @@ class FlatGradBucket:
             self.offsets.append(total)
             total += p.numel()
         self.flat = torch.zeros(total, dtype=dt, device=dev)
-        for p, off in zip(self.params, self.offsets):
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+        self.views = [self.flat[off:off + p.numel()].view_as(p)
+                      for p, off in zip(self.params, self.offsets)]
+        self.bind()
+
+    def bind(self) -> None:
+        """Makes every ``p.grad`` a view into the flat buffer (autograd then accumulates in
+        place: one small add kernel per parameter and backward)."""
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
     @property
     def nbytes(self) -> int:
@@ -91,6 +98,21 @@ class FlatGradBucket:
         if average and not async_op:
             self.flat.div_(dist.get_world_size())
         return work
+
+    def all_reduce_grads(self, average: bool = False) -> None:
+        """Launch-lean variant for steps that start from ``p.grad = None``: autograd hands
+        back fresh gradient tensors (no accumulate kernels); they are packed with ONE ``cat``
+        into the flat buffer, reduced with ONE collective, and copied back with ONE
+        multi-tensor copy. Three launches per step instead of one add per parameter."""
+        grads = [p.grad for p in self.params]
+        if any(g is None for g in grads):
+            raise RuntimeError("all_reduce_grads: every bucketed parameter needs a gradient")
+        torch.cat([g.reshape(-1) for g in grads], out=self.flat)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            if average:
+                self.flat.div_(dist.get_world_size())
+            torch._foreach_copy_(grads, self.views)
 
 
 def global_count(local_count: torch.Tensor) -> torch.Tensor:

@@ -54,8 +54,18 @@ def _worker(rank, world, port, out_path):
     loss.backward()
     assert [p.grad.data_ptr() for p in bucket.params] == views, "autograd must accumulate in place"
     bucket.all_reduce()
+    flat_views = bucket.flat.clone()
+    # launch-lean variant: fresh grads -> cat -> one all-reduce -> multi-tensor copy back
+    for p in bucket.params:
+        p.grad = None
+    loss = ((model(shard.x) - target) ** 2).sum() / count
+    loss.backward()
+    bucket.all_reduce_grads()
+    packed = torch.cat([p.grad.flatten() for p in bucket.params])
+    assert torch.allclose(packed, flat_views, rtol=1e-6, atol=1e-7)
+    assert torch.equal(packed, bucket.flat)
     if rank == 0:
-        torch.save({"flat": bucket.flat.clone(), "count": count}, out_path)
+        torch.save({"flat": flat_views, "count": count}, out_path)
     dist.barrier()
     dist.destroy_process_group()
 

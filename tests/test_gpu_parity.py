@@ -301,6 +301,17 @@ def test_adapter_edge_cases(dev):
             _check_workload(dev, batch, 8, 2, flags)
 
 
+def test_adapter_zero_nodes_and_device_mismatch(dev):
+    mod = ga.GConvAdapter(8, 2, learnable_scalar=True).to(dev)
+    x = torch.zeros(0, 8, device=dev, requires_grad=True)
+    out = mod(x, torch.zeros(2, 0, dtype=torch.long, device=dev))
+    assert out.shape == (0, 8)
+    out.sum().backward()
+    assert all(torch.count_nonzero(p.grad) == 0 for p in mod.parameters())
+    with pytest.raises(RuntimeError, match="edge_index is on"):
+        mod(torch.randn(2, 8, device=dev), torch.tensor([[0, 1], [1, 0]]))
+
+
 def test_adapter_near_identity_at_reference_init(dev):
     # reference init (gconv_adapter.py:65,73-78): W ~ N(0, 1e-5), b = 0, s = 1 -> out ~= x
     batch, cfg = ga.synth.make_workload("esol")
