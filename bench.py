@@ -188,6 +188,21 @@ def measure_arxiv(device, iters: int = 50) -> dict:
                                   "(separate rocprofv3 --pmc passes, gfx950 x2 fetch correction); L2 hit rate "
                                   f"{dv['l2_hit_rate']:.2f}")
 
+    # control: the SAME kernel on a graph of the same average degree whose neighbours are
+    # local (banded, 1 M nodes): how close it gets to HBM when gathers hit L2
+    bb = ga.synth.banded_like(1_000_000, 8, 2048)
+    bplan = ga.GraphPlan(bb.edge_index.to(device), bb.num_nodes, True)
+    bh = torch.randn(bb.num_nodes, r, device=device)
+    by = torch.empty_like(bh)
+    bws = torch.empty(max(int(lib.gconv_spmm_workspace_bytes(bplan.fwd.ref(), r)), 16),
+                      dtype=torch.uint8, device=device)
+    bms = event_time_ms(lambda: ga.spmm(bplan, bh, flags=flags, out=by, workspace=bws), 20)
+    bbytes = spmm_algorithmic_bytes(bb.num_nodes, bplan.fwd.nnz, r)
+    banded = {"spmm_banded_1M_us": round(bms * 1e3, 1),
+              "spmm_banded_1M_GBs": round(bbytes / (bms * 1e-3) / 1e9, 1),
+              "spmm_banded_1M_frac_of_hbm_peak": round(bbytes / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    del bplan, bh, by, bws
+
     mod = build_adapters(dict(d=d, r=r, adapters=1), True, device)[0]
     x = batch.x.to(device).requires_grad_(True)
     gout = torch.randn(n, d, device=device)
@@ -204,6 +219,7 @@ def measure_arxiv(device, iters: int = 50) -> dict:
              "arxiv_adapter_fwd_GBs": round(fb / (fwd_ms * 1e-3) / 1e9, 1),
              "arxiv_adapter_bwd_GBs": round(bb / (bwd_ms * 1e-3) / 1e9, 1),
              "arxiv_adapter_steps_per_s": round(1e3 / (fwd_ms + bwd_ms), 1)}
+    extra.update(banded)
     return {"roofline": roof, "extra": extra}
 
 
