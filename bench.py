@@ -93,10 +93,10 @@ class BatchStream:
         return batch, x, ei, gout
 
 
-def adapter_step(mods, stream: BatchStream, normalize: bool, bucket=None):
+def adapter_step(mods, params, stream: BatchStream, normalize: bool, bucket=None):
     """fwd + bwd of the adapter chain on the next batch (+ gradient all-reduce)."""
     batch, x, ei, gout = stream.next(normalize)
-    for p in mods.parameters():
+    for p in params:          # optimizer.zero_grad(set_to_none=True)
         p.grad = None
     h = x
     for m in mods:
@@ -285,11 +285,13 @@ def run_workload(name: str, normalize: bool, steps: int, warmup: int, rank: int,
     stream = BatchStream(name, rank, device, k=4, fresh=fresh)
     cfg = stream.cfg
     mods = build_adapters(cfg, normalize, device)
-    bucket = ga.dist.FlatGradBucket(list(mods.parameters())) if world > 1 else None
+    params = list(mods.parameters())
+    bucket = ga.dist.FlatGradBucket(params) if world > 1 else None
+    mods = list(mods)
     graphs = [0]
 
     def step():
-        graphs[0] += adapter_step(mods, stream, normalize, bucket)
+        graphs[0] += adapter_step(mods, params, stream, normalize, bucket)
 
     dt = timed_steps(step, steps, warmup, world, device)
     ga.PLAN_CACHE.clear()
