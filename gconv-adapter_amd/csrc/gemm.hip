@@ -168,8 +168,8 @@ size_t rowsA_lds_bytes(int d, int fp) {
 
 int rowsA_grid(int n) {
   const int nblk = ceil_div(n, 16);
-  int g = ceil_div(nblk, 4);  // persistent: <= 3 workgroups per CU walk the node blocks
-  return g < 1 ? 1 : (g > 3 * kNumCU ? 3 * kNumCU : g);
+  int g = ceil_div(nblk, 4);  // persistent: <= 2 workgroups per CU walk the node blocks
+  return g < 1 ? 1 : (g > 2 * kNumCU ? 2 * kNumCU : g);   // measured best at S-arxiv: 2 (27 us) vs 3-6 (28-29 us)
 }
 
 template <int NCB>
@@ -340,9 +340,9 @@ gconv_status_t launch_up_fwd(const UpArgs& a, hipStream_t stream) {
   if (nchunks > 16) return GCONV_E_UNSUPPORTED;
   const int nslots = chunk_slots(nchunks, 4);
   const int nblk = ceil_div(a.n, 16);
-  // persistent: ~4 workgroups per CU, each wave slot walks node blocks with a 1-deep prefetch
+  // persistent: 2 workgroups per CU, each wave slot walks node blocks with a 1-deep prefetch
   int grid = ceil_div(nblk, nslots);
-  if (grid > 4 * kNumCU) grid = 4 * kNumCU;
+  if (grid > 2 * kNumCU) grid = 2 * kNumCU;   // measured: 2 per CU 37 us, 4 per CU 41 us, 6 per CU 45 us
   const int threads = 64 * nchunks * nslots;
   switch (a.fp) {
     case 4:  return launch_up_fwd_fp<4>(a, grid, threads, nchunks, nslots, stream);
@@ -372,9 +372,9 @@ BwdMainGeom bwd_main_geom(int n, int d) {
   g.nchunks = ceil_div(d, 64);
   g.nslots = chunk_slots(g.nchunks, 8);
   const int nblk = ceil_div(n, 16);
-  // >= 4 node blocks per wave slot amortise the partial write-out; <= 2 workgroups per CU
+  // >= 4 node blocks per wave slot amortise the partial write-out; <= 1 workgroup per CU
   int grid = ceil_div(nblk, 4 * g.nslots);
-  if (grid > 2 * kNumCU) grid = 2 * kNumCU;
+  if (grid > kNumCU) grid = kNumCU;   // one 8-wave workgroup per CU (measured best)
   if (grid < 1) grid = 1;
   g.grid = grid;
   g.nparts = grid;
