@@ -11,7 +11,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgconv_adapter.so")
+# GCONV_ADAPTER_LIB: development override to load another build of the same C ABI (kernel variants)
+LIB_PATH = os.environ.get("GCONV_ADAPTER_LIB") or os.path.join(_HERE, "lib", "libgconv_adapter.so")
 
 ACT_CODES = {"none": 0, "relu": 1, "silu": 2}
 SPMM_IN_PRESCALED = 1

@@ -146,6 +146,9 @@ extern "C" size_t gconv_adapter_fwd_workspace_bytes(const gconv_graph_t* graph, 
   (void)hidden;
   const int fp = padded_rank(rank);
   if (!graph || fp == 0) return 0;
+#ifdef GCONV_TILE_STAMPS
+  if (tile_path_ok(graph, hidden, fp)) return 1 << 20;
+#endif
   if (tile_path_ok(graph, hidden, fp)) return 256;
   return carve_fwd(nullptr, &graph->fwd, fp).bytes;
 }
@@ -154,6 +157,9 @@ extern "C" size_t gconv_adapter_bwd_workspace_bytes(const gconv_graph_t* graph, 
                                                     int32_t rank) {
   const int fp = padded_rank(rank);
   if (!graph || fp == 0 || hidden <= 0) return 0;
+#ifdef GCONV_TILE_STAMPS
+  if (tile_path_ok(graph, hidden, fp)) return carve_bwd_tile(nullptr, graph->n_tiles, hidden, fp).bytes + (1 << 20);
+#endif
   if (tile_path_ok(graph, hidden, fp)) return carve_bwd_tile(nullptr, graph->n_tiles, hidden, fp).bytes;
   return carve_bwd(nullptr, &graph->bwd, hidden, fp).bytes;
 }
@@ -183,6 +189,9 @@ extern "C" gconv_status_t gconv_adapter_fwd_f32(const gconv_graph_t* gr,
     t.x = x; t.out = out; t.saved_h = saved_h; t.saved_h1 = saved_h1; t.saved_p = saved_p;
     t.w_down = p->w_down; t.b_down = p->b_down; t.w_up = p->w_up; t.b_up = p->b_up;
     t.scalar = p->scalar; t.d = d; t.r = r; t.fp = fp; t.act = p->act; t.skip = p->skip;
+#ifdef GCONV_TILE_STAMPS
+    t.stamps = static_cast<long long*>(workspace);   // diagnostic build: workspace = stamp buffer
+#endif
     return launch_tile_fwd(t, gr->n_tiles, gr->tile_nodes_max, gr->tile_edges_max, stream);
   }
   const FwdWs ws = carve_fwd(workspace, graph, fp);
@@ -246,6 +255,9 @@ extern "C" gconv_status_t gconv_adapter_bwd_f32(const gconv_graph_t* gr,
     t.part_bd = tw.part_bd; t.part_ds = tw.part_ds;
     t.d = d; t.r = r; t.fp = fp; t.act = p->act; t.skip = p->skip;
     t.want_ds = grad_scalar != nullptr;
+#ifdef GCONV_TILE_STAMPS
+    t.stamps = reinterpret_cast<long long*>(static_cast<char*>(workspace) + tw.bytes);
+#endif
     st = launch_tile_bwd(t, gr->n_tiles, gr->tile_nodes_max, gr->tile_edges_max, stream);
     if (st != GCONV_OK) return st;
     FinalizeArgs f{};   // ONE launch: every partial (d(scalar) included) is complete per workgroup

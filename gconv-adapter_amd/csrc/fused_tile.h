@@ -11,6 +11,7 @@ struct TileFwdArgs {
   const float* w_down; const float* b_down; const float* w_up; const float* b_up;
   const float* scalar;
   int d, r, fp, act, skip, cap, n_tiles;
+  long long* stamps;   // diagnostic build only (-DGCONV_TILE_STAMPS, tools/tilestamps.py)
 };
 
 struct TileBwdArgs {
@@ -23,6 +24,7 @@ struct TileBwdArgs {
   float* part_wd; float* part_wu; float* part_cs; float* part_bd;
   float* part_ds;   // complete scalar-gradient partial: (G Wu).P + [skip] G.X + b_up.colsum(G)
   int d, r, fp, act, skip, cap, want_ds, n_tiles;
+  long long* stamps;   // diagnostic build only
 };
 
 // true if the graph is tiled and one tile's rank-width state fits the LDS budget

@@ -21,11 +21,22 @@
 // its autograd backward for the batches the inductive script feeds it
 // (scripts/finetune_inductive_learning.py:43-67).
 #include <cstdlib>
+#include <type_traits>
 
 #include "fused_tile.h"
 
 #ifndef GCONV_BWD_WAVES
 #define GCONV_BWD_WAVES 2
+#endif
+
+// Diagnostic build (-DGCONV_TILE_STAMPS): per-workgroup phase time stamps (100 MHz wall clock)
+// into a side buffer that nothing else reads; never compiled into the product library.
+#ifdef GCONV_TILE_STAMPS
+#define TILE_STAMP(k) do { if (threadIdx.x == 0) a.stamps[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#define TILE_STAMP_NT(v) do { if (threadIdx.x == 0) a.stamps[blockIdx.x * 8 + 7] = (v); } while (0)
+#else
+#define TILE_STAMP(k)
+#define TILE_STAMP_NT(v)
 #endif
 
 namespace gconv {
@@ -75,42 +86,93 @@ __device__ __forceinline__ void stage_weights(f32x4* wl, const float* __restrict
 
 // Phase 1 of both directions: dst[local row][c] = row_scale * sval * (M_t Wt), tile rows
 // [ts, ts + nt). Returns this lane's partial of sum(acc * Pmat) (backward scalar gradient).
-template <int FP, int NQ>
+//
+// A wave owns the 16-row blocks wave, wave + nwaves, ...; the NQ 16-byte k-steps of a block
+// sit in a register ring: all of them are requested before the first MFMA, and while block b
+// is multiplied each freed ring slot is refilled with block b + nwaves (the refill variant of
+// the block body is a separate straight-line copy, selected by a wave-uniform branch, so the
+// compiler can count vmcnt exactly and never waits for more than it needs). `mid` runs once,
+// right after the first block's requests are in flight: the caller's small dependent loads
+// (CSR slice, dis) ride under the X / G tile latency instead of in front of it.
+template <int FP, int NQ, bool HAS_DIS, bool WANT_P, class Mid>
 __device__ __forceinline__ float tile_rowsA(const float* __restrict__ M, const f32x4* wl,
                                             float* dst, const float* __restrict__ dis,
                                             const float* __restrict__ Pmat, float sval, int ts,
-                                            int nt, int d, int nwaves, int wave, int lane) {
+                                            int nt, int d, int nwaves, int wave, int lane,
+                                            Mid&& mid) {
   constexpr int NCB = FP >= 16 ? FP / 16 : 1;
   const int node = lane & 15, kq = lane >> 4;
   const int nb = ceil_div(nt, 16);
   float ds_acc = 0.f;
-  int koff[NQ];
-  bool kok[NQ];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    koff[q] = min(16 * q + 4 * kq, d - 4);
-    kok[q] = 16 * q + 4 * kq < d;
+  int b = wave;
+  if (b >= nb) {  // wave-uniform: no block for this wave in this tile
+    mid();
+    return 0.f;
   }
-  for (int b = wave; b < nb; b += nwaves) {
-    const int lrow = min(16 * b + node, nt - 1);
-    const float* __restrict__ xb = M + static_cast<size_t>(ts + lrow) * d;
-    f32x4 x[NQ];
+  // ring of R k-steps (4 VGPRs each): the whole row up to d = 304 (d = 192 for rank 17..32,
+  // whose accumulators are twice as large), half a row beyond. Slot q % R serves k-steps
+  // q and q + R of a block, then k-step q % R of the wave's next block.
+  constexpr int R = (NQ > 19 || (FP >= 32 && NQ > 12)) ? (NQ + 1) / 2 : NQ;
+  f32x4 x[R];
+  // The NQ clamped column offsets are loop invariant; left alone the compiler hoists all of
+  // them (and their masks) into registers for the whole kernel (+40 VGPRs at d = 300, which
+  // costs a resident workgroup per CU). Laundering kq makes it recompute them: two VALU ops
+  // per 16-byte load.
+  auto launder = [](int v) { asm volatile("" : "+v"(v)); return v; };
+  auto row_ptr = [&](int blk) {
+    return M + static_cast<size_t>(ts + min(16 * blk + node, nt - 1)) * d;
+  };
+  {
+    const float* __restrict__ xb = row_ptr(b);
+    const int kqv = launder(kq);
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) x[q] = ldg4(xb + koff[q]);
+    for (int q = 0; q < R; ++q) x[q] = ldg4(xb + min(16 * q + 4 * kqv, d - 4));
+  }
+  mid();
+  const float* pmat = WANT_P ? (Pmat ? Pmat : M) : nullptr;  // never dereferenced out of range
+  auto block = [&](auto refill_tag, int blk) {
+    constexpr bool REFILL = decltype(refill_tag)::value;
+    // epilogue operands first (vmcnt retires in order: they sit between this block's tiles,
+    // requested one block ago, and the refills requested below)
+    float dv[4], pv[NCB][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int lrc = min(16 * blk + 4 * kq + m, nt - 1);
+      dv[m] = HAS_DIS ? dis[ts + lrc] : 1.f;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+        pv[cb][m] = WANT_P ? pmat[static_cast<size_t>(ts + lrc) * FP + min(16 * cb + node, FP - 1)] : 0.f;
+    }
+    const float* __restrict__ xc = row_ptr(blk);
+    const float* __restrict__ xn = REFILL ? row_ptr(blk + nwaves) : nullptr;
+    const int kqv = launder(kq);
     f32x4 acc[NCB][2];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) acc[cb][0] = acc[cb][1] = zero4f();
+    // W fragments: LDS reads one k-step ahead of their MFMAs; the scheduling fences keep the
+    // compiler from hoisting all NQ reads (4 VGPRs each) to the top of the block
+    f32x4 w[NCB], wn[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) w[cb] = wn[cb] = wl[cb * 64 + lane];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const f32x4 xv = kok[q] ? x[q] : zero4f();
+      const f32x4 xv = (16 * q + 4 * kqv < d) ? x[q % R] : zero4f();
+      if (q + 1 < NQ) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) wn[cb] = wl[((q + 1) * NCB + cb) * 64 + lane];
+      }
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
-        const f32x4 w = wl[(q * NCB + cb) * 64 + lane];
-        acc[cb][0] = mfma16(xv[0], w[0], acc[cb][0]);
-        acc[cb][1] = mfma16(xv[1], w[1], acc[cb][1]);
-        acc[cb][0] = mfma16(xv[2], w[2], acc[cb][0]);
-        acc[cb][1] = mfma16(xv[3], w[3], acc[cb][1]);
+        acc[cb][0] = mfma16(xv[0], w[cb][0], acc[cb][0]);
+        acc[cb][1] = mfma16(xv[1], w[cb][1], acc[cb][1]);
+        acc[cb][0] = mfma16(xv[2], w[cb][2], acc[cb][0]);
+        acc[cb][1] = mfma16(xv[3], w[cb][3], acc[cb][1]);
       }
+      if (q + R < NQ) x[q % R] = ldg4(xc + min(16 * (q + R) + 4 * kqv, d - 4));
+      else if constexpr (REFILL) x[q % R] = ldg4(xn + min(16 * (q % R) + 4 * kqv, d - 4));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) w[cb] = wn[cb];
     }
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
@@ -118,47 +180,81 @@ __device__ __forceinline__ float tile_rowsA(const float* __restrict__ M, const f
       const int c = 16 * cb + node;
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        const int lr = 16 * b + 4 * kq + m;
+        const int lr = 16 * blk + 4 * kq + m;
         if (lr < nt && c < FP) {
           float v = res[m];
-          if (Pmat) ds_acc += v * Pmat[static_cast<size_t>(ts + lr) * FP + c];
-          v *= sval;
-          if (dis) v *= dis[ts + lr];
+          if (WANT_P && Pmat) ds_acc += v * pv[cb][m];
+          v *= sval * dv[m];
           dst[lr * FP + c] = v;
         }
       }
     }
+  };
+  while (b + nwaves < nb) {
+    block(std::true_type{}, b);
+    b += nwaves;
   }
+  block(std::false_type{}, b);
   return ds_acc;
 }
 
 // Phases 2 / 3: one lane group (FP/4 lanes) per tile row, neighbour rows gathered from LDS.
 //   sum = sum over stored edges of src[col - ts]; v = NORM ? dis * (sum + src[row]) : sum
-// `rp` / `cl`: the tile's CSR slice staged in LDS (local row offsets, local column ids)
+// `rp` / `cl` / `dl`: the tile's CSR slice (local row offsets, local column ids) and its
+// dis values, staged in LDS during phase 1
 template <int FP, bool NORM>
 __device__ __forceinline__ f32x4 tile_row_sum(const float* src, const int32_t* rp,
-                                              const int32_t* cl, const float* __restrict__ dis,
-                                              int ts, int lrow, int sub) {
+                                              const int32_t* cl, const float* dl, int lrow,
+                                              int sub) {
   const int e0 = rp[lrow], e1 = rp[lrow + 1];
   f32x4 acc = zero4f();
   for (int e = e0; e < e1; ++e)
     acc += *reinterpret_cast<const f32x4*>(src + cl[e] * FP + 4 * sub);
   if (NORM) {
     acc += *reinterpret_cast<const f32x4*>(src + lrow * FP + 4 * sub);
-    acc *= dis[ts + lrow];
+    acc *= dl[lrow];
   }
   return acc;
 }
 
-// Stages the CSR slice of tile rows [ts, ts + nt) into LDS (issued at tile start, so its
-// latency hides under phase 1's X loads; the barrier after phase 1 publishes it).
-__device__ __forceinline__ void stage_tile_csr(const int32_t* __restrict__ rowptr,
-                                               const int32_t* __restrict__ col, int ts, int nt,
-                                               int32_t* rp, int32_t* cl) {
-  const int e0 = rowptr[ts], ne = rowptr[ts + nt] - e0;
-  for (int i = threadIdx.x; i <= nt; i += blockDim.x) rp[i] = rowptr[ts + i] - e0;
-  for (int e = threadIdx.x; e < ne; e += blockDim.x) cl[e] = col[e0 + e] - ts;
-}
+// Split-phase staging of a tile's CSR slice and dis values into LDS: `request` (before the
+// phase-1 tile loads) asks for the row offsets and dis, `advance` (the phase-1 `mid` hook:
+// the big tile loads are in flight by then) asks for the column ids, which need the slice
+// start, and parks what has arrived; `finish` parks the column ids. The barrier that ends
+// phase 1 publishes everything. First blockDim elements in registers, the rest (tiles with
+// more rows / edges than threads) by plain loops.
+template <bool NORM>
+struct TileCsrStage {
+  const int32_t* __restrict__ rowptr;
+  const int32_t* __restrict__ col;
+  const float* __restrict__ dis;
+  int32_t *rp, *cl;
+  float* dl;
+  int ts, nt, e0, e1, rpv, clv;
+  float dv;
+  __device__ __forceinline__ void request() {
+    const int tid = threadIdx.x;
+    e0 = rowptr[ts];
+    e1 = rowptr[ts + nt];
+    rpv = rowptr[ts + min(tid, nt)];
+    dv = NORM ? dis[ts + min(tid, nt - 1)] : 1.f;
+  }
+  __device__ __forceinline__ void advance() {
+    const int tid = threadIdx.x;
+    clv = col[e0 + min(tid, max(e1 - e0 - 1, 0))];
+    if (tid <= nt) rp[tid] = rpv - e0;
+    if (NORM && tid < nt) dl[tid] = dv;
+    for (int i = tid + blockDim.x; i <= nt; i += blockDim.x) {
+      rp[i] = rowptr[ts + i] - e0;
+      if (NORM && i < nt) dl[i] = dis[ts + i];
+    }
+  }
+  __device__ __forceinline__ void finish() {
+    const int tid = threadIdx.x, ne = e1 - e0;
+    if (tid < ne) cl[tid] = clv - ts;
+    for (int e = tid + blockDim.x; e < ne; e += blockDim.x) cl[e] = col[e0 + e] - ts;
+  }
+};
 
 }  // namespace
 
@@ -166,7 +262,7 @@ __device__ __forceinline__ void stage_tile_csr(const int32_t* __restrict__ rowpt
 // forward — persistent workgroups walk the tiles (weights staged / loaded once)
 // ===========================================================================
 template <int FP, int NQ, bool NORM>
-__global__ __launch_bounds__(512, 4) void tile_fwd_kernel(TileFwdArgs a) {
+__global__ __launch_bounds__(FP >= 32 ? 512 : 640) void tile_fwd_kernel(TileFwdArgs a) {
   extern __shared__ f32x4 lds4[];
   constexpr int NCB = FP >= 16 ? FP / 16 : 1;
   constexpr int KS = FP / 4;
@@ -176,7 +272,8 @@ __global__ __launch_bounds__(512, 4) void tile_fwd_kernel(TileFwdArgs a) {
   float* bufB = bufA + a.cap * FP;                               // [cap][FP]  H2'
   float* bufC = bufB + a.cap * FP;                               // (backward only: P tile)
   int32_t* rp = reinterpret_cast<int32_t*>(bufC + a.cap * FP + 8 * (FP + 2));  // [cap + 1]
-  int32_t* cl = rp + a.cap + 16;                                 // [ecap]
+  float* dl = reinterpret_cast<float*>(rp + a.cap + 16);         // [cap]  dis of the tile
+  int32_t* cl = reinterpret_cast<int32_t*>(dl + a.cap);          // [ecap]
 
   const int lane = threadIdx.x & 63, wave = wave_id();
   const int nwaves = blockDim.x >> 6;
@@ -209,18 +306,41 @@ __global__ __launch_bounds__(512, 4) void tile_fwd_kernel(TileFwdArgs a) {
   if (a.b_up) { const f32x4 bv = ldg4(a.b_up + colc); bu = colvalid ? bv : zero4f(); }
   __syncthreads();
 
+  TILE_STAMP(0);
   for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const int ts = a.tile_ptr[tile], nt = a.tile_ptr[tile + 1] - ts;
     if (nt <= 0) continue;  // uniform
+    TILE_STAMP_NT(nt);
+    TILE_STAMP(1);
 
-    // ---- phase 1: H0' -> bufA (the tile's CSR slice lands in LDS meanwhile)
-    stage_tile_csr(a.rowptr, a.col, ts, nt, rp, cl);
-    tile_rowsA<FP, NQ>(a.x, wl, bufA, a.dis, nullptr, 1.f, ts, nt, a.d, nwaves, wave, lane);
+    // ---- phase 1: H0' -> bufA (the tile's CSR slice and dis land in LDS meanwhile)
+    TileCsrStage<NORM> csr{a.rowptr, a.col, a.dis, rp, cl, dl, ts, nt};
+    csr.request();
+    tile_rowsA<FP, NQ, NORM, false>(a.x, wl, bufA, a.dis, nullptr, 1.f, ts, nt, a.d, nwaves, wave, lane,
+                                    [&]() { csr.advance(); });
+    csr.finish();
     __syncthreads();
+    TILE_STAMP(2);
+
+    // phase 4's first two X tiles are requested now: their latency passes under phases 2 / 3.
+    // Unconditional, clamped requests (a conditional prefetch makes the compiler drain vmcnt);
+    // a clamped repeat re-reads the wave's last block, i.e. lines it has just touched.
+    const int nb4 = ceil_div(nt, 16);
+    auto load_x = [&](int blk, f32x4 (&xq)[4]) {
+      const int bc = min(blk, nb4 - 1);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int lr = min(16 * bc + 4 * t + m, nt - 1);
+        xq[m] = ldg4(a.x + static_cast<size_t>(ts + lr) * a.d + colc);
+      }
+    };
+    f32x4 xa[4], xb[4];
+    load_x(slot, xa);
+    load_x(slot + nslots, xb);
 
     // ---- phase 2: H2' -> bufB (+ saved_h, saved_h1)
     for (int lr = grp; lr < nt; lr += ngrp) {
-      f32x4 v = tile_row_sum<FP, NORM>(bufA, rp, cl, a.dis, ts, lr, sub);
+      f32x4 v = tile_row_sum<FP, NORM>(bufA, rp, cl, dl, lr, sub);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int c = 4 * sub + k;
@@ -230,41 +350,27 @@ __global__ __launch_bounds__(512, 4) void tile_fwd_kernel(TileFwdArgs a) {
       if (a.act == GCONV_ACT_SILU) stg4(a.saved_h1 + off, v);
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = act_fwd(a.act, v[k]);
-      if (NORM) v *= a.dis[ts + lr];
+      if (NORM) v *= dl[lr];
       *reinterpret_cast<f32x4*>(bufB + lr * FP + 4 * sub) = v;
       stg4(a.saved_h + off, v);
     }
     __syncthreads();
 
+    TILE_STAMP(3);
     // ---- phase 3: P -> bufA (+ saved_p)
     for (int lr = grp; lr < nt; lr += ngrp) {
-      const f32x4 v = tile_row_sum<FP, NORM>(bufB, rp, cl, a.dis, ts, lr, sub);
+      const f32x4 v = tile_row_sum<FP, NORM>(bufB, rp, cl, dl, lr, sub);
       *reinterpret_cast<f32x4*>(bufA + lr * FP + 4 * sub) = v;
       stg4(a.saved_p + static_cast<size_t>(ts + lr) * FP + 4 * sub, v);
     }
     __syncthreads();
 
-    // ---- phase 4: out = s (P Wu^T + bu + X); the X tile of the wave's next node block is
-    // in flight while the current one computes (unconditional, clamped prefetch)
+    TILE_STAMP(4);
+    // ---- phase 4: out = s (P Wu^T + bu + X); two X tiles per wave in flight
     if (active) {
-      const int nb = ceil_div(nt, 16);
-      auto load_x = [&](int b, f32x4 (&xq)[4]) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const int lr = min(16 * b + 4 * t + m, nt - 1);
-          xq[m] = ldg4(a.x + static_cast<size_t>(ts + lr) * a.d + colc);
-        }
-      };
-      f32x4 xv[4], xn[4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) xv[m] = xn[m] = zero4f();
-      int b = slot;
-      if (b < nb && a.skip) load_x(b, xv);
-      while (b < nb) {
-        const int nxt = b + nslots;
+      auto step = [&](int b, f32x4 (&xv)[4], int refill) {
         float pa[KS];
         lds_rank_frag<FP>(bufA, min(16 * b + jj, nt - 1), t, 16 * b + jj < nt, pa);
-        if (a.skip) load_x(min(nxt, nb - 1), xn);
         f32x4 acc[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = zero4f();
@@ -279,16 +385,19 @@ __global__ __launch_bounds__(512, 4) void tile_fwd_kernel(TileFwdArgs a) {
           if (colvalid && lr < nt) {
             f32x4 o;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) o[c] = sval * (acc[c][m] + bu[c] + xv[m][c]);
+            for (int c = 0; c < 4; ++c) o[c] = sval * (acc[c][m] + bu[c] + (a.skip ? xv[m][c] : 0.f));
             stg4(a.out + static_cast<size_t>(ts + lr) * a.d + colbase, o);
           }
         }
-#pragma unroll
-        for (int m = 0; m < 4; ++m) xv[m] = xn[m];
-        b = nxt;
+        load_x(refill, xv);
+      };
+      for (int b = slot; b < nb4; b += 2 * nslots) {
+        step(b, xa, b + 2 * nslots);
+        if (b + nslots < nb4) step(b + nslots, xb, b + 3 * nslots);
       }
     }
     __syncthreads();  // bufA / bufB are reused by the next tile
+    TILE_STAMP(5);
   }
 }
 
@@ -309,7 +418,8 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
   float* bufC = bufB + a.cap * FP;                               // [cap][FP]  P tile
   float* red = bufC + a.cap * FP;                                // [nwaves][FP + 2] scratch
   int32_t* rp = reinterpret_cast<int32_t*>(red + 8 * (FP + 2));  // [cap + 1]
-  int32_t* cl = rp + a.cap + 16;                                 // [ecap]
+  float* dl = reinterpret_cast<float*>(rp + a.cap + 16);         // [cap]  dis of the tile
+  int32_t* cl = reinterpret_cast<int32_t*>(dl + a.cap);          // [ecap]
 
   const int lane = threadIdx.x & 63, wave = wave_id();
   const int nwaves = blockDim.x >> 6;
@@ -345,22 +455,51 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
   float ds1 = 0.f, dsx = 0.f;
   __syncthreads();
 
+  TILE_STAMP(0);
   for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const int ts = a.tile_ptr[tile], nt = a.tile_ptr[tile + 1] - ts;
     if (nt <= 0) continue;  // uniform
+    TILE_STAMP_NT(nt);
+    TILE_STAMP(1);
 
     // ---- phase 1: dP' = dis . s (G Wu) -> bufA ; ds1 += sum (G Wu) . P
     // (the tile's CSR slice and its P rows land in LDS meanwhile)
-    stage_tile_csr(a.rowptr, a.col, ts, nt, rp, cl);
-    for (int i = threadIdx.x; i < nt * LPR; i += blockDim.x)
+    TileCsrStage<NORM> csr{a.rowptr, a.col, a.dis, rp, cl, dl, ts, nt};
+    csr.request();
+    const int np4 = nt * LPR;  // the P tile: np4 float4, the first blockDim of them via registers
+    const f32x4 pfirst =
+        ldg4(a.saved_p + static_cast<size_t>(ts) * FP + 4 * min(static_cast<int>(threadIdx.x), np4 - 1));
+    ds1 += tile_rowsA<FP, NQ, NORM, true>(a.g, wl, bufA, a.dis, a.want_ds ? a.saved_p : nullptr, sval, ts,
+                                          nt, a.d, nwaves, wave, lane, [&]() { csr.advance(); });
+    csr.finish();
+    if (static_cast<int>(threadIdx.x) < np4) *reinterpret_cast<f32x4*>(bufC + 4 * threadIdx.x) = pfirst;
+    for (int i = threadIdx.x + blockDim.x; i < np4; i += blockDim.x)
       *reinterpret_cast<f32x4*>(bufC + 4 * i) = ldg4(a.saved_p + static_cast<size_t>(ts) * FP + 4 * i);
-    ds1 += tile_rowsA<FP, NQ>(a.g, wl, bufA, a.dis, a.want_ds ? a.saved_p : nullptr, sval, ts, nt,
-                              a.d, nwaves, wave, lane);
     __syncthreads();
+
+    TILE_STAMP(2);
+    // phase 4's first two (G, X) tile pairs are requested now: their latency passes under
+    // phases 2 / 3. Unconditional, clamped requests (a conditional prefetch makes the compiler
+    // drain vmcnt): a clamped repeat re-reads the wave's last block, and the waves that own no
+    // column chunk keep re-reading one row (L1 hits).
+    const int nb4 = ceil_div(nt, 16);
+    auto load_gx = [&](int blk, f32x4 (&gq)[4], f32x4 (&xq)[4]) {
+      const int bc = min(blk, nb4 - 1);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int lrc = owner ? min(16 * bc + 4 * t + m, nt - 1) : 0;
+        gq[m] = ldg4(a.g + static_cast<size_t>(ts + lrc) * a.d + colc);
+        xq[m] = ldg4(a.x + static_cast<size_t>(ts + lrc) * a.d + colc);
+      }
+    };
+    constexpr bool DEEP = FP < 32;  // rank 17..32: no registers left for the second pair
+    f32x4 ga[4], xa[4], gb[DEEP ? 4 : 1], xb[DEEP ? 4 : 1];
+    load_gx(0, ga, xa);
+    if constexpr (DEEP) load_gx(1, gb, xb);
 
     // ---- phase 2: dH1' = dis . (S^T dP . act') -> bufB ; bias gradient
     for (int lr = grp; lr < nt; lr += ngrp) {
-      f32x4 v = tile_row_sum<FP, NORM>(bufA, rp, cl, a.dis, ts, lr, sub);
+      f32x4 v = tile_row_sum<FP, NORM>(bufA, rp, cl, dl, lr, sub);
       const size_t off = static_cast<size_t>(ts + lr) * FP + 4 * sub;
       if (a.act == GCONV_ACT_RELU) {
         const f32x4 h2 = ldg4(a.saved_h + off);
@@ -372,35 +511,24 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
         for (int k = 0; k < 4; ++k) v[k] *= silu_grad(h1[k]);
       }
       bgrad += v;
-      if (NORM) v *= a.dis[ts + lr];
+      if (NORM) v *= dl[lr];
       *reinterpret_cast<f32x4*>(bufB + lr * FP + 4 * sub) = v;
     }
     __syncthreads();
 
+    TILE_STAMP(3);
     // ---- phase 3: T = S^T dH1 -> bufA
     for (int lr = grp; lr < nt; lr += ngrp) {
-      const f32x4 v = tile_row_sum<FP, NORM>(bufB, rp, cl, a.dis, ts, lr, sub);
+      const f32x4 v = tile_row_sum<FP, NORM>(bufB, rp, cl, dl, lr, sub);
       *reinterpret_cast<f32x4*>(bufA + lr * FP + 4 * sub) = v;
     }
     __syncthreads();
 
+    TILE_STAMP(4);
     // ---- phase 4 (owner waves): dX = T Wd + s G ; dWd^T += T^T X ; dWu^T += P^T G ;
-    //      colsum(G) ; sum G.X — next block's G / X tiles prefetched
+    //      colsum(G) ; sum G.X — two (G, X) tile pairs per wave in flight
     if (owner) {
-      const int nb = ceil_div(nt, 16);
-      auto load_gx = [&](int b, f32x4 (&gq)[4], f32x4 (&xq)[4]) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const int lrc = min(16 * b + 4 * t + m, nt - 1);
-          gq[m] = ldg4(a.g + static_cast<size_t>(ts + lrc) * a.d + colc);
-          xq[m] = ldg4(a.x + static_cast<size_t>(ts + lrc) * a.d + colc);
-        }
-      };
-      f32x4 gr[4], xr[4], gn[4], xn[4];
-      load_gx(0, gr, xr);
-      for (int b = 0; b < nb; ++b) {
-        // rank-width operands of this block first (vmcnt retires in order), then the
-        // unconditional prefetch of the next block's tiles
+      auto step = [&](int b, f32x4 (&gv)[4], f32x4 (&xv)[4], int refill) {
         float at[4][NCB], ap[4][NCB];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -415,14 +543,11 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
             ap[m][cb] = ok ? vp : 0.f;
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        load_gx(min(b + 1, nb - 1), gn, xn);
-        f32x4 gv[4], xv[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < 4; ++m) {   // mask in place: no second copy of the tiles
           const bool ok = colvalid && 16 * b + 4 * t + m < nt;
-          gv[m] = ok ? gr[m] : zero4f();
-          xv[m] = ok ? xr[m] : zero4f();
+          gv[m] = ok ? gv[m] : zero4f();
+          xv[m] = ok ? xv[m] : zero4f();
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -459,11 +584,19 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
             }
           }
         }
-#pragma unroll
-        for (int m = 0; m < 4; ++m) { gr[m] = gn[m]; xr[m] = xn[m]; }
+        load_gx(refill, gv, xv);
+      };
+      if constexpr (DEEP) {
+        for (int b = 0; b < nb4; b += 2) {
+          step(b, ga, xa, b + 2);
+          if (b + 1 < nb4) step(b + 1, gb, xb, b + 3);
+        }
+      } else {
+        for (int b = 0; b < nb4; ++b) step(b, ga, xa, b + 1);
       }
     }
     __syncthreads();  // bufA / bufB are reused by the next tile
+    TILE_STAMP(5);
   }
 
   // ---- one partial row per workgroup
@@ -518,6 +651,7 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
     for (int w = 0; w < nwaves; ++w) v += red[w * (FP + 2) + FP];
     a.part_ds[pid] = v;
   }
+  TILE_STAMP(6);
 }
 
 // ===========================================================================
@@ -531,10 +665,22 @@ static int tile_nq(int d) {
   return 0;
 }
 
-static int tile_threads(int d) {
-  int w = ceil_div(d, 64);   // one wave per 64-column chunk in backward phase 4
+// Workgroup shapes. One workgroup per CU, walking its tiles; a tile's time is a chain of
+// memory latencies, so a workgroup carries as many waves as its registers allow:
+//   forward   nchunks * nslots waves (a wave owns a 64-column chunk and every nslots-th node
+//             block in phase 4), up to 12 (8 for rank 17..32, whose kernel needs more VGPRs)
+//   backward  8 waves (the dW accumulators pin a chunk to one wave: nchunks owner waves)
+static int tile_threads_fwd(int d, int fp) {
+  const int nchunks = ceil_div(d, 64), cap = fp >= 32 ? 8 : 10;
+  int nslots = cap / nchunks;
+  if (nslots < 1) nslots = 1;
+  int w = nchunks * nslots;
   if (w < 4) w = 4;
-  if (w > 8) w = 8;
+  return 64 * w;
+}
+static int tile_threads_bwd(int d) {
+  int w = ceil_div(d, 64);
+  if (w < 8) w = 8;
   return 64 * w;
 }
 
@@ -544,11 +690,14 @@ size_t tile_lds_bytes(int d, int fp, int tile_nodes_max, int tile_edges_max) {
   return static_cast<size_t>(nq) * ncb * 64 * sizeof(f32x4) +              // weight fragments
          static_cast<size_t>(3) * cap * fp * sizeof(float) +                // rank-width tiles
          8 * (fp + 2) * sizeof(float) +                                     // reduction scratch
-         (static_cast<size_t>(cap) + 16 + (tile_edges_max > 0 ? tile_edges_max : 1)) * 4 + 64;
+         (static_cast<size_t>(2) * cap + 16 + (tile_edges_max > 0 ? tile_edges_max : 1)) * 4 + 64;  // rp, dl, cl
 }
 
 bool tile_path_ok(const gconv_graph_t* g, int d, int fp) {
   if (g->n_tiles <= 0 || tile_nq(d) == 0 || fp > 32 || ceil_div(d, 64) > 8) return false;
+  // wide rows at high rank do not fit the register budget of the fused kernels (they would
+  // spill); the four-launch path is the better one there anyway
+  if ((fp >= 32 && tile_nq(d) > 19) || (fp >= 16 && tile_nq(d) > 24)) return false;
   static const bool off = getenv("GCONV_NO_TILE_PATH") != nullptr;  // debugging / A-B knob
   if (off) return false;
   return tile_lds_bytes(d, fp, g->tile_nodes_max, g->tile_edges_max) <= 64 * 1024;
@@ -590,8 +739,8 @@ static gconv_status_t launch_tile_bwd_t(const TileBwdArgs& a, int grid, int thre
   case FP_ * 100 + 16: return FN<FP_, 16> ARGS; case FP_ * 100 + 19: return FN<FP_, 19> ARGS;  \
   case FP_ * 100 + 24: return FN<FP_, 24> ARGS; case FP_ * 100 + 32: return FN<FP_, 32> ARGS;
 
-int tile_grid(int n_tiles) {  // persistent: <= 2 workgroups per CU
-  return n_tiles < 2 * kNumCU ? (n_tiles > 0 ? n_tiles : 1) : 2 * kNumCU;
+int tile_grid(int n_tiles) {  // persistent: one workgroup per CU
+  return n_tiles < kNumCU ? (n_tiles > 0 ? n_tiles : 1) : kNumCU;
 }
 
 gconv_status_t launch_tile_fwd(TileFwdArgs a, int n_tiles, int tile_nodes_max,
@@ -601,7 +750,7 @@ gconv_status_t launch_tile_fwd(TileFwdArgs a, int n_tiles, int tile_nodes_max,
   n_tiles = tile_grid(n_tiles);
   a.cap = ceil_div(tile_nodes_max > 0 ? tile_nodes_max : 1, 16) * 16;
   const size_t lds = tile_lds_bytes(a.d, a.fp, tile_nodes_max, tile_edges_max);
-  const int threads = tile_threads(a.d);
+  const int threads = tile_threads_fwd(a.d, a.fp);
   GCONV_TILE_DISPATCH(launch_tile_fwd_t, (a, n_tiles, threads, lds, stream))
 }
 
@@ -612,7 +761,7 @@ gconv_status_t launch_tile_bwd(TileBwdArgs a, int n_tiles, int tile_nodes_max,
   n_tiles = tile_grid(n_tiles);
   a.cap = ceil_div(tile_nodes_max > 0 ? tile_nodes_max : 1, 16) * 16;
   const size_t lds = tile_lds_bytes(a.d, a.fp, tile_nodes_max, tile_edges_max);
-  const int threads = tile_threads(a.d);
+  const int threads = tile_threads_bwd(a.d);
   GCONV_TILE_DISPATCH(launch_tile_bwd_t, (a, n_tiles, threads, lds, stream))
 }
 

@@ -1,0 +1,51 @@
+"""Per-phase timing of the fused tile kernels (diagnostic build with -DGCONV_TILE_STAMPS).
+    python tools/tilestamps.py [hiv|esol]
+Builds lib/libgconv_adapter_stamps.so on first use (hipcc), runs one adapter forward+backward through the
+ctypes binding and prints, for the largest and some median tiles, the time spent in each phase."""
+import ctypes as C, glob, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["GCONV_PY_BINDING"] = "1"
+import numpy as np, torch
+import gconv_adapter_amd as ga
+from gconv_adapter_amd import _lib
+alt = _lib.LIB_PATH.replace("libgconv_adapter.so", "libgconv_adapter_stamps.so")
+if not os.path.exists(alt):
+    srcs = sorted(glob.glob(os.path.join(ROOT, "gconv-adapter_amd", "csrc", "*.hip")))
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                    "-DGCONV_TILE_STAMPS", "-Wno-unused-value", "-Wno-pass-failed", "-o", alt] + srcs, check=True)
+_lib.LIB_PATH = alt
+dev = torch.device("cuda:0")
+batch, cfg = ga.synth.make_workload(sys.argv[1] if len(sys.argv) > 1 else "hiv")
+d, r = cfg["d"], cfg["r"]
+x = batch.x.to(dev); ei = batch.edge_index.to(dev); g = torch.randn_like(x)
+m = ga.GConvAdapter(d, r, learnable_scalar=True).to(dev)
+plan = ga.get_plan(ei, x.shape[0], True)
+lib = _lib.load()
+fp, wsf, wsb = plan.sizes(lib, d, r)
+out = torch.empty_like(x); saved = torch.empty(2, x.shape[0], fp, device=dev)
+wsF = torch.zeros(wsf, dtype=torch.uint8, device=dev); wsB = torch.zeros(wsb, dtype=torch.uint8, device=dev)
+P = _lib.AdapterParams(m.conv_down.lin.weight.data_ptr(), m.conv_down.bias.data_ptr(), m.conv_up.lin.weight.data_ptr(),
+                       m.conv_up.bias.data_ptr(), m.scalar.data_ptr(), d, r, 1, 1)
+gx = torch.empty_like(x); gp = [torch.empty_like(p) for p in (m.conv_down.lin.weight, m.conv_down.bias, m.conv_up.lin.weight, m.conv_up.bias, m.scalar)]
+st = torch.cuda.current_stream().cuda_stream
+for _ in range(4):
+    lib.gconv_adapter_fwd_f32(plan.ref(), C.byref(P), x.data_ptr(), out.data_ptr(), saved[0].data_ptr(), None, saved[1].data_ptr(), wsF.data_ptr(), wsf, st)
+    lib.gconv_adapter_bwd_f32(plan.ref(), C.byref(P), x.data_ptr(), g.data_ptr(), saved[0].data_ptr(), None, saved[1].data_ptr(), gx.data_ptr(),
+                              gp[0].data_ptr(), gp[1].data_ptr(), gp[2].data_ptr(), gp[3].data_ptr(), gp[4].data_ptr(), wsB.data_ptr(), wsb, st)
+torch.cuda.synchronize()
+grid = min(plan.n_tiles, 256)
+def show(tag, ws, off):
+    st = ws[off:off + grid * 64].view(torch.int64).cpu().numpy().reshape(-1, 8)
+    t0 = st[:, 0].min(); nt = st[:, 7]
+    last = 6 if tag == "bwd" else 5
+    print(f"{tag}: tiles {plan.n_tiles} grid {grid} max nodes {nt.max()} span {(st[:, last].max() - t0) / 100.0:.1f} us; starts: "
+          f"{np.percentile((st[:,0]-t0)/100.0,[0,50,90,100]).round(1)}")
+    print("     nt | start | setup  ph1   ph2   ph3   ph4  " + ("tail" if tag == "bwd" else ""))
+    order = np.argsort(-nt)
+    for i in list(order[:4]) + list(order[len(order) // 2: len(order) // 2 + 3]):
+        dur = (st[i, 1:last + 1] - st[i, 0:last]) / 100.0
+        print("  %5d | %5.1f | " % (nt[i], (st[i, 0] - t0) / 100.0) + " ".join("%5.1f" % v for v in dur))
+show("fwd", wsF, 0)
+tw = wsb - (1 << 20)
+show("bwd", wsB, tw)
