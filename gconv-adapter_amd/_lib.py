@@ -46,6 +46,7 @@ class GraphStruct(C.Structure):
         ("bwd", CsrStruct),
         ("dis", C.c_void_p),
         ("tile_ptr", C.c_void_p),
+        ("tile_order", C.c_void_p),
         ("n_tiles", C.c_int32),
         ("tile_nodes_max", C.c_int32),
         ("tile_edges_max", C.c_int32),
@@ -115,7 +116,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.gconv_abi_version() != 1:
+    if lib.gconv_abi_version() != 2:
         raise RuntimeError("gconv_adapter_amd: ABI version mismatch, rebuild the library")
     _lib = lib
     return lib

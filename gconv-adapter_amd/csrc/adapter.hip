@@ -185,7 +185,7 @@ extern "C" gconv_status_t gconv_adapter_fwd_f32(const gconv_graph_t* gr,
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (tile_path_ok(gr, d, fp)) {  // block-diagonal batch: one fused launch
     TileFwdArgs t{};
-    t.tile_ptr = gr->tile_ptr; t.rowptr = graph->rowptr; t.col = graph->col; t.dis = dis;
+    t.tile_ptr = gr->tile_ptr; t.tile_order = gr->tile_order; t.rowptr = graph->rowptr; t.col = graph->col; t.dis = dis;
     t.x = x; t.out = out; t.saved_h = saved_h; t.saved_h1 = saved_h1; t.saved_p = saved_p;
     t.w_down = p->w_down; t.b_down = p->b_down; t.w_up = p->w_up; t.b_up = p->b_up;
     t.scalar = p->scalar; t.d = d; t.r = r; t.fp = fp; t.act = p->act; t.skip = p->skip;
@@ -247,7 +247,7 @@ extern "C" gconv_status_t gconv_adapter_bwd_f32(const gconv_graph_t* gr,
     const TileBwdWs tw = carve_bwd_tile(workspace, gr->n_tiles, d, fp);
     if (workspace_bytes < tw.bytes) return GCONV_E_WORKSPACE;
     TileBwdArgs t{};
-    t.tile_ptr = gr->tile_ptr; t.rowptr = graph_t->rowptr; t.col = graph_t->col; t.dis = dis;
+    t.tile_ptr = gr->tile_ptr; t.tile_order = gr->tile_order; t.rowptr = graph_t->rowptr; t.col = graph_t->col; t.dis = dis;
     t.x = x; t.g = grad_out; t.saved_h = saved_h; t.saved_h1 = saved_h1; t.saved_p = saved_p;
     t.w_down = p->w_down; t.w_up = p->w_up; t.b_up = p->b_up; t.scalar = p->scalar;
     t.dx = grad_x;

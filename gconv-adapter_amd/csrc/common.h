@@ -52,6 +52,28 @@ __device__ __forceinline__ float silu_grad(float h) {
   return sig * (1.f + h * (1.f - sig));
 }
 
+// Buffer-resource access (raw buffers, 32-bit byte offsets, hardware range check): a load
+// whose offset is >= the descriptor's byte count returns 0 and such a store is dropped. The
+// tile kernels build one descriptor per tile and let the range check handle ragged node
+// blocks and column tails — no clamped addresses, no operand masks, no branches around
+// stores, so every lane issues the same number of memory operations and the compiler can
+// count vmcnt exactly. Descriptors must be built from wave-uniform values only.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr int kBufOob = 0x40000000;  // added to an offset to push it out of any tile's range
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, static_cast<int>(bytes), 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_ld4(rsrc_t r, int byte_off) {
+  const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+  return __builtin_bit_cast(f32x4, v);
+}
+__device__ __forceinline__ void buf_st4(rsrc_t r, int byte_off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), r, byte_off, 0, 0);
+}
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 // Wave index inside the workgroup as a provably wave-uniform (SGPR) value. Without the
 // readfirstlane hipcc treats `threadIdx.x >> 6` as divergent, turns every branch that
 // depends on it into an exec-masked one and fences each load under it with vmcnt(0).

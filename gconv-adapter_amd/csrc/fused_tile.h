@@ -6,7 +6,7 @@
 namespace gconv {
 
 struct TileFwdArgs {
-  const int32_t* tile_ptr; const int32_t* rowptr; const int32_t* col; const float* dis;
+  const int32_t* tile_ptr; const int32_t* tile_order; const int32_t* rowptr; const int32_t* col; const float* dis;
   const float* x; float* out; float* saved_h; float* saved_h1; float* saved_p;
   const float* w_down; const float* b_down; const float* w_up; const float* b_up;
   const float* scalar;
@@ -15,7 +15,7 @@ struct TileFwdArgs {
 };
 
 struct TileBwdArgs {
-  const int32_t* tile_ptr; const int32_t* rowptr; const int32_t* col; const float* dis;  // S^T
+  const int32_t* tile_ptr; const int32_t* tile_order; const int32_t* rowptr; const int32_t* col; const float* dis;  // S^T
   const float* x; const float* g; const float* saved_h; const float* saved_h1;
   const float* saved_p;
   const float* w_down; const float* w_up; const float* b_up; const float* scalar;

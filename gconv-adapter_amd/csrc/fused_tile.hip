@@ -86,20 +86,23 @@ __device__ __forceinline__ void stage_weights(f32x4* wl, const float* __restrict
 
 // Phase 1 of both directions: dst[local row][c] = row_scale * sval * (M_t Wt), tile rows
 // [ts, ts + nt). Returns this lane's partial of sum(acc * Pmat) (backward scalar gradient).
+// `rm` is the buffer descriptor of the tile's rows of M (nt * d floats): node blocks that run
+// past the tile and k-steps past the row end read zeros through its range check.
 //
-// A wave owns the 16-row blocks wave, wave + nwaves, ...; the NQ 16-byte k-steps of a block
-// sit in a register ring: all of them are requested before the first MFMA, and while block b
-// is multiplied each freed ring slot is refilled with block b + nwaves (the refill variant of
+// A wave owns the 16-row blocks wave, wave + nwaves, ...; the k-steps of a block sit in a
+// register ring: all of them are requested before the first MFMA, and while block b is
+// multiplied each freed ring slot is refilled with block b + nwaves (the refill variant of
 // the block body is a separate straight-line copy, selected by a wave-uniform branch, so the
 // compiler can count vmcnt exactly and never waits for more than it needs). `mid` runs once,
 // right after the first block's requests are in flight: the caller's small dependent loads
 // (CSR slice, dis) ride under the X / G tile latency instead of in front of it.
 template <int FP, int NQ, bool HAS_DIS, bool WANT_P, class Mid>
-__device__ __forceinline__ float tile_rowsA(const float* __restrict__ M, const f32x4* wl,
-                                            float* dst, const float* __restrict__ dis,
+__device__ __forceinline__ float tile_rowsA(rsrc_t rm, const float* __restrict__ anyrow,
+                                            const f32x4* wl, float* dst,
+                                            const float* __restrict__ dis,
                                             const float* __restrict__ Pmat, float sval, int ts,
-                                            int nt, int d, int nwaves, int wave, int lane,
-                                            Mid&& mid) {
+                                            int nt, int d, int rowb, int nwaves, int wave,
+                                            int lane, Mid&& mid) {
   constexpr int NCB = FP >= 16 ? FP / 16 : 1;
   const int node = lane & 15, kq = lane >> 4;
   const int nb = ceil_div(nt, 16);
@@ -114,22 +117,20 @@ __device__ __forceinline__ float tile_rowsA(const float* __restrict__ M, const f
   // q and q + R of a block, then k-step q % R of the wave's next block.
   constexpr int R = (NQ > 19 || (FP >= 32 && NQ > 12)) ? (NQ + 1) / 2 : NQ;
   f32x4 x[R];
-  // The NQ clamped column offsets are loop invariant; left alone the compiler hoists all of
-  // them (and their masks) into registers for the whole kernel (+40 VGPRs at d = 300, which
-  // costs a resident workgroup per CU). Laundering kq makes it recompute them: two VALU ops
-  // per 16-byte load.
+  // The per-k-step offsets are loop invariant; left alone the compiler hoists all NQ of them
+  // into registers for the whole kernel (+40 VGPRs at d = 300). Laundering kq makes it
+  // recompute them: two VALU ops per 16-byte load.
   auto launder = [](int v) { asm volatile("" : "+v"(v)); return v; };
-  auto row_ptr = [&](int blk) {
-    return M + static_cast<size_t>(ts + min(16 * blk + node, nt - 1)) * d;
+  auto koff = [&](int rowoff, int q, int kqv) {  // a k-step past the row end reads zeros
+    return 16 * q + 4 * kqv < d ? rowoff + 64 * q + 16 * kqv : kBufOob;
   };
   {
-    const float* __restrict__ xb = row_ptr(b);
-    const int kqv = launder(kq);
+    const int ro = (16 * b + node) * rowb, kqv = launder(kq);
 #pragma unroll
-    for (int q = 0; q < R; ++q) x[q] = ldg4(xb + min(16 * q + 4 * kqv, d - 4));
+    for (int q = 0; q < R; ++q) x[q] = buf_ld4(rm, koff(ro, q, kqv));
   }
   mid();
-  const float* pmat = WANT_P ? (Pmat ? Pmat : M) : nullptr;  // never dereferenced out of range
+  const float* pmat = WANT_P ? (Pmat ? Pmat : anyrow) : nullptr;  // never read out of range
   auto block = [&](auto refill_tag, int blk) {
     constexpr bool REFILL = decltype(refill_tag)::value;
     // epilogue operands first (vmcnt retires in order: they sit between this block's tiles,
@@ -143,8 +144,7 @@ __device__ __forceinline__ float tile_rowsA(const float* __restrict__ M, const f
       for (int cb = 0; cb < NCB; ++cb)
         pv[cb][m] = WANT_P ? pmat[static_cast<size_t>(ts + lrc) * FP + min(16 * cb + node, FP - 1)] : 0.f;
     }
-    const float* __restrict__ xc = row_ptr(blk);
-    const float* __restrict__ xn = REFILL ? row_ptr(blk + nwaves) : nullptr;
+    const int rc = (16 * blk + node) * rowb, rn = (16 * (blk + nwaves) + node) * rowb;
     const int kqv = launder(kq);
     f32x4 acc[NCB][2];
 #pragma unroll
@@ -156,7 +156,10 @@ __device__ __forceinline__ float tile_rowsA(const float* __restrict__ M, const f
     for (int cb = 0; cb < NCB; ++cb) w[cb] = wn[cb] = wl[cb * 64 + lane];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const f32x4 xv = (16 * q + 4 * kqv < d) ? x[q % R] : zero4f();
+      // operand copy behind an opaque asm: without it the compiler gives the refill below a
+      // second set of ring registers (and copies the whole ring at the loop head)
+      f32x4 xv = x[q % R];
+      asm volatile("" : "+v"(xv));
       if (q + 1 < NQ) {
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) wn[cb] = wl[((q + 1) * NCB + cb) * 64 + lane];
@@ -168,8 +171,8 @@ __device__ __forceinline__ float tile_rowsA(const float* __restrict__ M, const f
         acc[cb][0] = mfma16(xv[2], w[cb][2], acc[cb][0]);
         acc[cb][1] = mfma16(xv[3], w[cb][3], acc[cb][1]);
       }
-      if (q + R < NQ) x[q % R] = ldg4(xc + min(16 * (q + R) + 4 * kqv, d - 4));
-      else if constexpr (REFILL) x[q % R] = ldg4(xn + min(16 * (q % R) + 4 * kqv, d - 4));
+      if (q + R < NQ) x[q % R] = buf_ld4(rm, koff(rc, q + R, kqv));
+      else if constexpr (REFILL) x[q % R] = buf_ld4(rm, koff(rn, q % R, kqv));
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) w[cb] = wn[cb];
@@ -222,7 +225,7 @@ __device__ __forceinline__ f32x4 tile_row_sum(const float* src, const int32_t* r
 // the big tile loads are in flight by then) asks for the column ids, which need the slice
 // start, and parks what has arrived; `finish` parks the column ids. The barrier that ends
 // phase 1 publishes everything. First blockDim elements in registers, the rest (tiles with
-// more rows / edges than threads) by plain loops.
+// more rows / edges than threads) by plain loops in `finish`.
 template <bool NORM>
 struct TileCsrStage {
   const int32_t* __restrict__ rowptr;
@@ -244,15 +247,15 @@ struct TileCsrStage {
     clv = col[e0 + min(tid, max(e1 - e0 - 1, 0))];
     if (tid <= nt) rp[tid] = rpv - e0;
     if (NORM && tid < nt) dl[tid] = dv;
-    for (int i = tid + blockDim.x; i <= nt; i += blockDim.x) {
-      rp[i] = rowptr[ts + i] - e0;
-      if (NORM && i < nt) dl[i] = dis[ts + i];
-    }
   }
   __device__ __forceinline__ void finish() {
     const int tid = threadIdx.x, ne = e1 - e0;
     if (tid < ne) cl[tid] = clv - ts;
     for (int e = tid + blockDim.x; e < ne; e += blockDim.x) cl[e] = col[e0 + e] - ts;
+    for (int i = tid + blockDim.x; i <= nt; i += blockDim.x) {
+      rp[i] = rowptr[ts + i] - e0;
+      if (NORM && i < nt) dl[i] = dis[ts + i];
+    }
   }
 };
 
@@ -307,32 +310,45 @@ __global__ __launch_bounds__(FP >= 32 ? 512 : 640) void tile_fwd_kernel(TileFwdA
   __syncthreads();
 
   TILE_STAMP(0);
-  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-    const int ts = a.tile_ptr[tile], nt = a.tile_ptr[tile + 1] - ts;
+  // tiles are dealt from the size-sorted list boustrophedon: pass 0 gives workgroup w the
+  // w-th largest tile, pass 1 the (2 G - 1 - w)-th, ... — the big tiles end up alone
+  for (int pass = 0;; ++pass) {
+    const int G = gridDim.x;
+    const int idx = (pass & 1) ? (pass + 1) * G - 1 - static_cast<int>(blockIdx.x) : pass * G + static_cast<int>(blockIdx.x);
+    if (idx >= a.n_tiles) break;
+    const int tile = uniform(a.tile_order[idx]);
+    const int ts = uniform(a.tile_ptr[tile]), nt = uniform(a.tile_ptr[tile + 1]) - ts;
     if (nt <= 0) continue;  // uniform
     TILE_STAMP_NT(nt);
     TILE_STAMP(1);
+    // Row pitch in bytes, re-derived per tile behind an opaque asm: the byte offsets built on
+    // it are tile invariant, and hoisted out of this loop they would be kept (and spilled)
+    // for the whole kernel instead of being recomputed with one or two VALU ops.
+    int rowb = 4 * a.d;
+    asm volatile("" : "+s"(rowb));
+    // phase-4 byte offset of this lane inside a tile: row 4t of a node block, its 4 columns;
+    // a lane past the last column is pushed out of the tile's range (loads 0, stores nothing)
+    const int voff4 = 4 * t * rowb + (colvalid ? 4 * colbase : kBufOob);
+    // the tile's rows of X and of out as range-checked buffers
+    const rsrc_t rx = make_rsrc(a.x + static_cast<size_t>(ts) * a.d, static_cast<uint32_t>(nt) * rowb);
+    const rsrc_t ro = make_rsrc(a.out + static_cast<size_t>(ts) * a.d, static_cast<uint32_t>(nt) * rowb);
 
     // ---- phase 1: H0' -> bufA (the tile's CSR slice and dis land in LDS meanwhile)
     TileCsrStage<NORM> csr{a.rowptr, a.col, a.dis, rp, cl, dl, ts, nt};
     csr.request();
-    tile_rowsA<FP, NQ, NORM, false>(a.x, wl, bufA, a.dis, nullptr, 1.f, ts, nt, a.d, nwaves, wave, lane,
-                                    [&]() { csr.advance(); });
+    tile_rowsA<FP, NQ, NORM, false>(rx, a.x, wl, bufA, a.dis, nullptr, 1.f, ts, nt, a.d, rowb, nwaves, wave,
+                                    lane, [&]() { csr.advance(); });
     csr.finish();
     __syncthreads();
     TILE_STAMP(2);
 
     // phase 4's first two X tiles are requested now: their latency passes under phases 2 / 3.
-    // Unconditional, clamped requests (a conditional prefetch makes the compiler drain vmcnt);
-    // a clamped repeat re-reads the wave's last block, i.e. lines it has just touched.
+    // Unconditional requests (a conditional prefetch makes the compiler drain vmcnt): a node
+    // block past the tile lies outside the buffer and costs no traffic.
     const int nb4 = ceil_div(nt, 16);
     auto load_x = [&](int blk, f32x4 (&xq)[4]) {
-      const int bc = min(blk, nb4 - 1);
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int lr = min(16 * bc + 4 * t + m, nt - 1);
-        xq[m] = ldg4(a.x + static_cast<size_t>(ts + lr) * a.d + colc);
-      }
+      for (int m = 0; m < 4; ++m) xq[m] = buf_ld4(rx, voff4 + (16 * blk + m) * rowb);
     };
     f32x4 xa[4], xb[4];
     load_x(slot, xa);
@@ -366,8 +382,11 @@ __global__ __launch_bounds__(FP >= 32 ? 512 : 640) void tile_fwd_kernel(TileFwdA
     __syncthreads();
 
     TILE_STAMP(4);
-    // ---- phase 4: out = s (P Wu^T + bu + X); two X tiles per wave in flight
-    if (active) {
+    // ---- phase 4: out = s (P Wu^T + bu + X); two X tiles per wave in flight. Everything
+    // requested so far has landed (the phases in between waited on younger loads): saying so
+    // gives the loop below one known state on entry and around its back edge.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    if (active && slot < nb4) {
       auto step = [&](int b, f32x4 (&xv)[4], int refill) {
         float pa[KS];
         lds_rank_frag<FP>(bufA, min(16 * b + jj, nt - 1), t, 16 * b + jj < nt, pa);
@@ -381,19 +400,20 @@ __global__ __launch_bounds__(FP >= 32 ? 512 : 640) void tile_fwd_kernel(TileFwdA
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-          const int lr = 16 * b + 4 * t + m;
-          if (colvalid && lr < nt) {
-            f32x4 o;
+          f32x4 o;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) o[c] = sval * (acc[c][m] + bu[c] + (a.skip ? xv[m][c] : 0.f));
-            stg4(a.out + static_cast<size_t>(ts + lr) * a.d + colbase, o);
-          }
+          for (int c = 0; c < 4; ++c) o[c] = sval * (acc[c][m] + bu[c] + (a.skip ? xv[m][c] : 0.f));
+          buf_st4(ro, voff4 + (16 * b + m) * rowb, o);  // rows / columns past the tile: dropped
         }
         load_x(refill, xv);
       };
-      for (int b = slot; b < nb4; b += 2 * nslots) {
+      for (int b = slot;;) {
         step(b, xa, b + 2 * nslots);
-        if (b + nslots < nb4) step(b + nslots, xb, b + 3 * nslots);
+        b += nslots;
+        if (b >= nb4) break;
+        step(b, xb, b + 2 * nslots);
+        b += nslots;
+        if (b >= nb4) break;
       }
     }
     __syncthreads();  // bufA / bufB are reused by the next tile
@@ -456,11 +476,31 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
   __syncthreads();
 
   TILE_STAMP(0);
-  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-    const int ts = a.tile_ptr[tile], nt = a.tile_ptr[tile + 1] - ts;
+  // tiles are dealt from the size-sorted list boustrophedon: pass 0 gives workgroup w the
+  // w-th largest tile, pass 1 the (2 G - 1 - w)-th, ... — the big tiles end up alone
+  for (int pass = 0;; ++pass) {
+    const int G = gridDim.x;
+    const int idx = (pass & 1) ? (pass + 1) * G - 1 - static_cast<int>(blockIdx.x) : pass * G + static_cast<int>(blockIdx.x);
+    if (idx >= a.n_tiles) break;
+    const int tile = uniform(a.tile_order[idx]);
+    const int ts = uniform(a.tile_ptr[tile]), nt = uniform(a.tile_ptr[tile + 1]) - ts;
     if (nt <= 0) continue;  // uniform
     TILE_STAMP_NT(nt);
     TILE_STAMP(1);
+    // Row pitch in bytes, re-derived per tile behind an opaque asm: the byte offsets built on
+    // it are tile invariant, and hoisted out of this loop they would be kept (and spilled)
+    // for the whole kernel instead of being recomputed with one or two VALU ops.
+    int rowb = 4 * a.d;
+    asm volatile("" : "+s"(rowb));
+    // phase-4 byte offset of this lane inside a tile: row 4t of a node block, its 4 columns;
+    // a lane past the last column, and every lane of a wave that owns no chunk, is pushed out
+    // of the tile's range (loads 0 without traffic, stores nothing)
+    const int voff4 = 4 * t * rowb + (colvalid ? 4 * colbase : kBufOob);
+    // the tile's rows of G, X and dX as range-checked buffers
+    const uint32_t tbytes = static_cast<uint32_t>(nt) * rowb;
+    const rsrc_t rg = make_rsrc(a.g + static_cast<size_t>(ts) * a.d, tbytes);
+    const rsrc_t rx = make_rsrc(a.x + static_cast<size_t>(ts) * a.d, tbytes);
+    const rsrc_t rdx = make_rsrc(NEED_DX ? a.dx + static_cast<size_t>(ts) * a.d : nullptr, NEED_DX ? tbytes : 0);
 
     // ---- phase 1: dP' = dis . s (G Wu) -> bufA ; ds1 += sum (G Wu) . P
     // (the tile's CSR slice and its P rows land in LDS meanwhile)
@@ -469,8 +509,8 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
     const int np4 = nt * LPR;  // the P tile: np4 float4, the first blockDim of them via registers
     const f32x4 pfirst =
         ldg4(a.saved_p + static_cast<size_t>(ts) * FP + 4 * min(static_cast<int>(threadIdx.x), np4 - 1));
-    ds1 += tile_rowsA<FP, NQ, NORM, true>(a.g, wl, bufA, a.dis, a.want_ds ? a.saved_p : nullptr, sval, ts,
-                                          nt, a.d, nwaves, wave, lane, [&]() { csr.advance(); });
+    ds1 += tile_rowsA<FP, NQ, NORM, true>(rg, a.g, wl, bufA, a.dis, a.want_ds ? a.saved_p : nullptr, sval, ts,
+                                          nt, a.d, rowb, nwaves, wave, lane, [&]() { csr.advance(); });
     csr.finish();
     if (static_cast<int>(threadIdx.x) < np4) *reinterpret_cast<f32x4*>(bufC + 4 * threadIdx.x) = pfirst;
     for (int i = threadIdx.x + blockDim.x; i < np4; i += blockDim.x)
@@ -479,17 +519,15 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
 
     TILE_STAMP(2);
     // phase 4's first two (G, X) tile pairs are requested now: their latency passes under
-    // phases 2 / 3. Unconditional, clamped requests (a conditional prefetch makes the compiler
-    // drain vmcnt): a clamped repeat re-reads the wave's last block, and the waves that own no
-    // column chunk keep re-reading one row (L1 hits).
+    // phases 2 / 3. Unconditional requests (a conditional prefetch makes the compiler drain
+    // vmcnt): a node block past the tile lies outside the buffers and costs no traffic.
     const int nb4 = ceil_div(nt, 16);
     auto load_gx = [&](int blk, f32x4 (&gq)[4], f32x4 (&xq)[4]) {
-      const int bc = min(blk, nb4 - 1);
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        const int lrc = owner ? min(16 * bc + 4 * t + m, nt - 1) : 0;
-        gq[m] = ldg4(a.g + static_cast<size_t>(ts + lrc) * a.d + colc);
-        xq[m] = ldg4(a.x + static_cast<size_t>(ts + lrc) * a.d + colc);
+        const int off = voff4 + (16 * blk + m) * rowb;
+        gq[m] = buf_ld4(rg, off);
+        xq[m] = buf_ld4(rx, off);
       }
     };
     constexpr bool DEEP = FP < 32;  // rank 17..32: no registers left for the second pair
@@ -527,6 +565,9 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
     TILE_STAMP(4);
     // ---- phase 4 (owner waves): dX = T Wd + s G ; dWd^T += T^T X ; dWu^T += P^T G ;
     //      colsum(G) ; sum G.X — two (G, X) tile pairs per wave in flight
+    // (everything requested so far has landed — the phases in between waited on younger
+    // loads; saying so gives the loop one known state on entry and around its back edge)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     if (owner) {
       auto step = [&](int b, f32x4 (&gv)[4], f32x4 (&xv)[4], int refill) {
         float at[4][NCB], ap[4][NCB];
@@ -542,12 +583,6 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
             at[m][cb] = ok ? vt : 0.f;
             ap[m][cb] = ok ? vp : 0.f;
           }
-        }
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {   // mask in place: no second copy of the tiles
-          const bool ok = colvalid && 16 * b + 4 * t + m < nt;
-          gv[m] = ok ? gv[m] : zero4f();
-          xv[m] = ok ? xv[m] : zero4f();
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -575,21 +610,20 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
           }
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
-            const int lr = 16 * b + 4 * t + m;
-            if (colvalid && lr < nt) {
-              f32x4 o;
+            f32x4 o;
 #pragma unroll
-              for (int c = 0; c < 4; ++c) o[c] = acc[c][m] + (a.skip ? sval * gv[m][c] : 0.f);
-              stg4(a.dx + static_cast<size_t>(ts + lr) * a.d + colbase, o);
-            }
+            for (int c = 0; c < 4; ++c) o[c] = acc[c][m] + (a.skip ? sval * gv[m][c] : 0.f);
+            buf_st4(rdx, voff4 + (16 * b + m) * rowb, o);  // rows / columns past the tile: dropped
           }
         }
         load_gx(refill, gv, xv);
       };
       if constexpr (DEEP) {
-        for (int b = 0; b < nb4; b += 2) {
+        for (int b = 0;;) {
           step(b, ga, xa, b + 2);
-          if (b + 1 < nb4) step(b + 1, gb, xb, b + 3);
+          if (++b >= nb4) break;
+          step(b, gb, xb, b + 2);
+          if (++b >= nb4) break;
         }
       } else {
         for (int b = 0; b < nb4; ++b) step(b, ga, xa, b + 1);
@@ -694,7 +728,8 @@ size_t tile_lds_bytes(int d, int fp, int tile_nodes_max, int tile_edges_max) {
 }
 
 bool tile_path_ok(const gconv_graph_t* g, int d, int fp) {
-  if (g->n_tiles <= 0 || tile_nq(d) == 0 || fp > 32 || ceil_div(d, 64) > 8) return false;
+  if (g->n_tiles <= 0 || !g->tile_ptr || !g->tile_order) return false;
+  if (tile_nq(d) == 0 || fp > 32 || ceil_div(d, 64) > 8) return false;
   // wide rows at high rank do not fit the register budget of the fused kernels (they would
   // spill); the four-launch path is the better one there anyway
   if ((fp >= 32 && tile_nq(d) > 19) || (fp >= 16 && tile_nq(d) > 24)) return false;

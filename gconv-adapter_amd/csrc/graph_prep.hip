@@ -20,6 +20,9 @@
 
 namespace gconv {
 
+// a tile holds at most GCONV_TILE_NODES + GCONV_TILE_BACK = 512 nodes: 10-bit size keys
+constexpr int kTileSizeMax = 1023, kTileSizeBits = 10;
+
 enum {
   INFO_NNZ = 0, INFO_NLONG = 1, INFO_NSEG = 2, INFO_MAXDEG = 3, INFO_BAD = 4,
   INFO_ASYM = 5, INFO_NOTILE = 6, INFO_TILEMAX = 7, INFO_TILEEDGES = 8, INFO_WORDS = 9
@@ -155,14 +158,19 @@ __global__ void tile_start_kernel(const int32_t* __restrict__ span_ps, int32_t n
   tile_ptr[t] = q;
 }
 
+// Largest tile (nodes, stored edges) for the LDS budget of the fused kernels, and the keys of
+// the size sort behind gconv_graph_t::tile_order (ascending key = descending node count).
 __global__ void tile_max_kernel(const int32_t* __restrict__ tile_ptr,
                                 const int32_t* __restrict__ rowptr, int ntiles,
-                                int32_t* __restrict__ info) {
+                                int32_t* __restrict__ info, uint32_t* __restrict__ size_key,
+                                int32_t* __restrict__ tile_id) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   int sz = 0, ed = 0;
   if (t < ntiles) {
     sz = tile_ptr[t + 1] - tile_ptr[t];
     ed = rowptr[tile_ptr[t + 1]] - rowptr[tile_ptr[t]];
+    size_key[t] = static_cast<uint32_t>(kTileSizeMax - min(sz, kTileSizeMax));
+    tile_id[t] = t;
   }
   for (int off = 32; off > 0; off >>= 1) {
     sz = max(sz, __shfl_xor(sz, off));
@@ -182,7 +190,8 @@ struct CsrSlots {
 };
 struct BuildLayout {
   CsrSlots f, b;
-  size_t dis, tile_ptr, span, span_ps, keys_a, keys_b, info, cub, total, cub_bytes;
+  size_t dis, tile_ptr, tile_order, tile_key, tile_key_out, tile_id, span, span_ps, keys_a, keys_b, info, cub,
+      total, cub_bytes;
   int ntiles;
 };
 
@@ -198,8 +207,14 @@ static size_t cub_bytes_for(int64_t E, int32_t n) {
                                     static_cast<uint32_t*>(nullptr), cnt, 0, 32, nullptr);
   hipcub::DeviceScan::InclusiveSum(nullptr, sc, static_cast<const int32_t*>(nullptr),
                                    static_cast<int32_t*>(nullptr), n + 2, nullptr);
+  size_t st = 0;
+  hipcub::DeviceRadixSort::SortPairs(nullptr, st, static_cast<const uint32_t*>(nullptr),
+                                     static_cast<uint32_t*>(nullptr), static_cast<const int32_t*>(nullptr),
+                                     static_cast<int32_t*>(nullptr), ceil_div(n > 0 ? n : 1, GCONV_TILE_NODES),
+                                     0, kTileSizeBits, nullptr);
   size_t m = s64 > s32 ? s64 : s32;
-  return m > sc ? m : sc;
+  m = m > sc ? m : sc;
+  return m > st ? m : st;
 }
 
 static BuildLayout build_layout(int64_t E, int32_t n) {
@@ -219,6 +234,10 @@ static BuildLayout build_layout(int64_t E, int32_t n) {
   L.ntiles = ceil_div(n > 0 ? n : 1, GCONV_TILE_NODES);
   L.dis = take((static_cast<size_t>(n) + 1) * 4);
   L.tile_ptr = take((static_cast<size_t>(L.ntiles) + 1) * 4);
+  L.tile_order = take(static_cast<size_t>(L.ntiles) * 4);
+  L.tile_key = take(static_cast<size_t>(L.ntiles) * 4);
+  L.tile_key_out = take(static_cast<size_t>(L.ntiles) * 4);
+  L.tile_id = take(static_cast<size_t>(L.ntiles) * 4);
   L.span = take((static_cast<size_t>(n) + 2) * 4);
   L.span_ps = take((static_cast<size_t>(n) + 2) * 4);
   L.keys_a = take(e1 * 8);
@@ -326,7 +345,9 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
     GCONV_HIP(hipcub::DeviceScan::InclusiveSum(arena + L.cub, cub_bytes, span, span_ps, n + 2, stream));
     tile_start_kernel<<<(L.ntiles + 1 + T - 1) / T, T, 0, stream>>>(span_ps, n, L.ntiles, tile_ptr, info);
     GCONV_LAUNCH_CHECK();
-    tile_max_kernel<<<(L.ntiles + T - 1) / T, T, 0, stream>>>(tile_ptr, of.rowptr, L.ntiles, info);
+    tile_max_kernel<<<(L.ntiles + T - 1) / T, T, 0, stream>>>(
+        tile_ptr, of.rowptr, L.ntiles, info, reinterpret_cast<uint32_t*>(arena + L.tile_key),
+        reinterpret_cast<int32_t*>(arena + L.tile_id));
     GCONV_LAUNCH_CHECK();
   }
   int32_t h[64];
@@ -358,7 +379,15 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
   }
   g->dis = dis;
   g->tile_ptr = tile_ptr;
+  g->tile_order = reinterpret_cast<int32_t*>(arena + L.tile_order);
   g->n_tiles = (h[INFO_NOTILE] || n == 0) ? 0 : L.ntiles;
+  if (g->n_tiles > 0) {  // largest tile first; stable, so the order is a function of the graph alone
+    size_t cub_bytes = L.cub_bytes;
+    GCONV_HIP(hipcub::DeviceRadixSort::SortPairs(
+        arena + L.cub, cub_bytes, reinterpret_cast<const uint32_t*>(arena + L.tile_key),
+        reinterpret_cast<uint32_t*>(arena + L.tile_key_out), reinterpret_cast<const int32_t*>(arena + L.tile_id),
+        reinterpret_cast<int32_t*>(arena + L.tile_order), L.ntiles, 0, kTileSizeBits, stream));
+  }
   g->tile_nodes_max = h[INFO_TILEMAX];
   g->tile_edges_max = h[INFO_TILEEDGES];
   g->normalize = normalize ? 1 : 0;

@@ -118,6 +118,10 @@ class GraphPlan:
         return self.arena_view(self.struct.tile_ptr, self.n_tiles + 1, torch.int32)
 
     @property
+    def tile_order(self) -> torch.Tensor:
+        return self.arena_view(self.struct.tile_order, self.n_tiles, torch.int32)
+
+    @property
     def dis_ptr(self) -> Optional[int]:
         return self.struct.dis if self.normalize else None
 

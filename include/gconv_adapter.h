@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GCONV_ABI_VERSION 1
+#define GCONV_ABI_VERSION 2
 
 typedef int32_t gconv_status_t;
 typedef void*   gconv_stream_t; /* hipStream_t */
@@ -105,6 +105,10 @@ typedef struct gconv_graph {
   gconv_csr_t    bwd;            /* rows = sources: S^T (a copy of `fwd` if symmetric)  */
   const float*   dis;            /* [num_nodes] (in-degree + 1)^-1/2; NULL if !normalize */
   const int32_t* tile_ptr;       /* [n_tiles + 1] node offsets of the component tiles   */
+  const int32_t* tile_order;     /* [n_tiles] tile ids, largest tile first (stable): the
+                                  * persistent workgroups deal themselves tiles from this
+                                  * list boustrophedon, big ones first, so that no
+                                  * workgroup ends up with two big tiles               */
   int32_t        n_tiles;        /* 0: not tileable (an edge-free boundary was not found) */
   int32_t        tile_nodes_max; /* nodes in the largest tile                           */
   int32_t        tile_edges_max; /* stored edges (of fwd, == bwd count) in the largest tile */

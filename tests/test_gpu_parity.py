@@ -92,6 +92,10 @@ def test_graph_build_component_tiles(dev):
     for t, q in enumerate(tp[:-1]):
         assert q in gptr and q <= t * ga._lib.TILE_NODES
         assert gptr[gptr <= t * ga._lib.TILE_NODES].max() == q
+    # tile_order: every tile once, largest first, ties in tile order (stable sort)
+    order = plan.tile_order.cpu().numpy()
+    want = np.argsort(-np.diff(tp), kind="stable")
+    assert (order == want).all()
     # no edge crosses a tile boundary
     ei = batch.edge_index.numpy()
     tile_of = np.searchsorted(tp, np.arange(n), side="right") - 1
