@@ -451,9 +451,22 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
 
   stage_weights<NCB, NQ>(wl, a.w_up, a.d, a.r, false);
 
-  // phase-4 ownership: wave J owns column chunk J (nchunks <= nwaves)
-  const bool owner = wave < nchunks;
-  const int colbase = 64 * (owner ? wave : 0) + 4 * jj;
+  // phase-4 ownership: wave J < nchunks is the primary owner of 64-column chunk J (its dW
+  // accumulators live in that wave's registers for the whole kernel). Up to kExtra of the
+  // remaining waves co-own chunks, last chunk first, each with accumulators of its own: the
+  // co-owners of a chunk split its node blocks (slot, nslots) and are summed into the primary
+  // owner once, at the end. At d = 300 that is waves 0..3 -> chunks 0..3 and waves 4..7 ->
+  // chunk 4: 1.25 chunks of MFMA work on each of the CU's four SIMDs instead of 2 on one.
+  constexpr int kExtra = FP >= 32 ? 1 : 3;
+  const int extras = min(kExtra, nwaves - nchunks);
+  const bool primary = wave < nchunks;
+  const bool owner = wave < nchunks + extras;
+  const int ex = wave - nchunks;                                    // co-owner index
+  const int J = primary ? wave : (owner ? nchunks - 1 - ex % nchunks : 0);
+  const int jr = nchunks - 1 - J;
+  const int slot = primary ? 0 : 1 + ex / nchunks;
+  const int nslots = 1 + (extras > jr ? (extras - 1 - jr) / nchunks + 1 : 0);
+  const int colbase = 64 * J + 4 * jj;
   const bool colvalid = owner && colbase < a.d;
   const int colc = min(colbase, a.d - 4);
   float wd[NEED_DX ? KS : 1][4];
@@ -532,8 +545,8 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
     };
     constexpr bool DEEP = FP < 32;  // rank 17..32: no registers left for the second pair
     f32x4 ga[4], xa[4], gb[DEEP ? 4 : 1], xb[DEEP ? 4 : 1];
-    load_gx(0, ga, xa);
-    if constexpr (DEEP) load_gx(1, gb, xb);
+    load_gx(slot, ga, xa);
+    if constexpr (DEEP) load_gx(slot + nslots, gb, xb);
 
     // ---- phase 2: dH1' = dis . (S^T dP . act') -> bufB ; bias gradient
     for (int lr = grp; lr < nt; lr += ngrp) {
@@ -568,7 +581,7 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
     // (everything requested so far has landed — the phases in between waited on younger
     // loads; saying so gives the loop one known state on entry and around its back edge)
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    if (owner) {
+    if (owner && slot < nb4) {
       auto step = [&](int b, f32x4 (&gv)[4], f32x4 (&xv)[4], int refill) {
         float at[4][NCB], ap[4][NCB];
 #pragma unroll
@@ -619,21 +632,62 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
         load_gx(refill, gv, xv);
       };
       if constexpr (DEEP) {
-        for (int b = 0;;) {
-          step(b, ga, xa, b + 2);
-          if (++b >= nb4) break;
-          step(b, gb, xb, b + 2);
-          if (++b >= nb4) break;
+        for (int b = slot;;) {
+          step(b, ga, xa, b + 2 * nslots);
+          b += nslots;
+          if (b >= nb4) break;
+          step(b, gb, xb, b + 2 * nslots);
+          b += nslots;
+          if (b >= nb4) break;
         }
       } else {
-        for (int b = 0; b < nb4; ++b) step(b, ga, xa, b + 1);
+        for (int b = slot; b < nb4; b += nslots) step(b, ga, xa, b + nslots);
       }
     }
     __syncthreads();  // bufA / bufB are reused by the next tile
     TILE_STAMP(5);
   }
 
-  // ---- one partial row per workgroup
+  // ---- co-owners hand their accumulators to the chunk's primary owner through LDS (the
+  // tile buffers are dead: the loop ends on a barrier); summed in slot order
+  {
+    constexpr int kSlab = (2 * NCB * 16 + 4) * 64;  // floats per co-owner wave
+    float* slabs = reinterpret_cast<float*>(lds4);
+    if (owner && !primary) {
+      float* sl = slabs + ex * kSlab + lane;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            sl[((cb * 4 + c) * 4 + m) * 64] = awd[cb][c][m];
+            sl[(NCB * 16 + (cb * 4 + c) * 4 + m) * 64] = awu[cb][c][m];
+          }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) sl[(2 * NCB * 16 + c) * 64] = cs[c];
+    }
+    __syncthreads();
+    if (primary) {
+      for (int s = 1; s < nslots; ++s) {
+        const float* sl = slabs + ((s - 1) * nchunks + jr) * kSlab + lane;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              awd[cb][c][m] += sl[((cb * 4 + c) * 4 + m) * 64];
+              awu[cb][c][m] += sl[(NCB * 16 + (cb * 4 + c) * 4 + m) * 64];
+            }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cs[c] += sl[(2 * NCB * 16 + c) * 64];
+      }
+    }
+    __syncthreads();  // the slabs may overlap the reduction scratch used below
+  }
+
+  // ---- one partial row per workgroup (primary owners)
   // colsum(G): add the four lane quarters (fixed order); quarter 0 stores
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -642,11 +696,11 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
   }
   // b_up . colsum(G) of this wave's chunk joins the scalar-gradient partial
   float bdot = 0.f;
-  if (colvalid && t == 0 && a.b_up) {
+  if (primary && colvalid && t == 0 && a.b_up) {
     const f32x4 bv = ldg4(a.b_up + colbase);
     bdot = bv[0] * cs[0] + bv[1] * cs[1] + bv[2] * cs[2] + bv[3] * cs[3];
   }
-  if (colvalid) {
+  if (primary && colvalid) {
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
 #pragma unroll
@@ -721,10 +775,14 @@ static int tile_threads_bwd(int d) {
 size_t tile_lds_bytes(int d, int fp, int tile_nodes_max, int tile_edges_max) {
   const int nq = tile_nq(d), ncb = fp >= 16 ? fp / 16 : 1;
   const int cap = ceil_div(tile_nodes_max > 0 ? tile_nodes_max : 1, 16) * 16;
-  return static_cast<size_t>(nq) * ncb * 64 * sizeof(f32x4) +              // weight fragments
-         static_cast<size_t>(3) * cap * fp * sizeof(float) +                // rank-width tiles
-         8 * (fp + 2) * sizeof(float) +                                     // reduction scratch
-         (static_cast<size_t>(2) * cap + 16 + (tile_edges_max > 0 ? tile_edges_max : 1)) * 4 + 64;  // rp, dl, cl
+  const size_t tiles =
+      static_cast<size_t>(nq) * ncb * 64 * sizeof(f32x4) +              // weight fragments
+      static_cast<size_t>(3) * cap * fp * sizeof(float) +                // rank-width tiles
+      8 * (fp + 2) * sizeof(float) +                                     // reduction scratch
+      (static_cast<size_t>(2) * cap + 16 + (tile_edges_max > 0 ? tile_edges_max : 1)) * 4 + 64;  // rp, dl, cl
+  // the backward's co-owner slabs reuse the same space after the last tile
+  const size_t slabs = static_cast<size_t>(fp >= 32 ? 1 : 3) * (2 * ncb * 16 + 4) * 64 * sizeof(float);
+  return tiles > slabs ? tiles : slabs;
 }
 
 bool tile_path_ok(const gconv_graph_t* g, int d, int fp) {
