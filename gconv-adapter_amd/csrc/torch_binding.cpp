@@ -1,4 +1,5 @@
-// Autograd binding of the adapter in C++ (host code only, no device code, no HIP headers).
+// Autograd binding of the adapter in C++ and the native graph-plan prefetch worker (host code
+// only, no device code; the HIP runtime API is used for one event per prefetched plan).
 //
 // The product boundary stays the plain C ABI of include/gconv_adapter.h; this file is the
 // thinnest possible bridge from torch's autograd engine to gconv_adapter_fwd_f32 /
@@ -10,10 +11,17 @@
 // Replaces on the reference side: the torch autograd graph that PyG's GCNConv builds for
 // `conv_up(act_fn(conv_down(x, ei)), ei)` (/root/reference/src/finetune/gconv_adapter.py:92).
 #include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
 #include <torch/extension.h>
 
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
+#include <unordered_map>
 
 #include "../../include/gconv_adapter.h"
 
@@ -27,12 +35,17 @@ using bwd_fn_t = gconv_status_t (*)(const gconv_graph_t*, const gconv_adapter_pa
                                     const float*, float*, float*, float*, float*, float*, float*,
                                     void*, size_t, gconv_stream_t);
 using str_fn_t = const char* (*)(gconv_status_t);
+using bytes_fn_t = size_t (*)(int64_t, int32_t);
+using build_fn_t = gconv_status_t (*)(const int64_t*, int64_t, int32_t, int32_t, void*, size_t,
+                                      gconv_graph_t*, gconv_stream_t);
 
 struct Lib {
   void* handle = nullptr;
   fwd_fn_t fwd = nullptr;
   bwd_fn_t bwd = nullptr;
   str_fn_t str = nullptr;
+  bytes_fn_t build_bytes = nullptr;
+  build_fn_t build = nullptr;
 };
 Lib g_lib;
 
@@ -43,7 +56,10 @@ void load_library(const std::string& path) {
   g_lib.fwd = reinterpret_cast<fwd_fn_t>(dlsym(h, "gconv_adapter_fwd_f32"));
   g_lib.bwd = reinterpret_cast<bwd_fn_t>(dlsym(h, "gconv_adapter_bwd_f32"));
   g_lib.str = reinterpret_cast<str_fn_t>(dlsym(h, "gconv_status_string"));
-  TORCH_CHECK(g_lib.fwd && g_lib.bwd && g_lib.str, "gconv_adapter_amd: C ABI symbols missing in ", path);
+  g_lib.build_bytes = reinterpret_cast<bytes_fn_t>(dlsym(h, "gconv_graph_build_bytes"));
+  g_lib.build = reinterpret_cast<build_fn_t>(dlsym(h, "gconv_graph_build"));
+  TORCH_CHECK(g_lib.fwd && g_lib.bwd && g_lib.str && g_lib.build_bytes && g_lib.build,
+              "gconv_adapter_amd: C ABI symbols missing in ", path);
   g_lib.handle = h;
 }
 
@@ -143,10 +159,140 @@ at::Tensor adapter_apply(at::Tensor x, at::Tensor w_down, c10::optional<at::Tens
                           ws_bwd, act, skip, stream);
 }
 
+// ---------------------------------------------------------------------------------------
+// Graph-plan prefetch worker: builds the plan of a FUTURE batch (gconv_graph_build on a side
+// stream) from a native thread, so the build — a dozen small launches and one stream
+// synchronisation — neither holds the interpreter lock nor sits in front of the next step.
+// Plays the role of the DataLoader workers that collate the next batch in the reference
+// (/root/reference/scripts/finetune_inductive_learning.py:246-258).
+//
+// Memory: the arena is allocated by the submitting thread on ITS current stream; the side
+// stream first waits for an event recorded there at submit time (edge_index is complete and
+// every earlier use of the recycled block has drained), and gconv_graph_build returns only
+// after the side stream has finished, so the consumer needs no further synchronisation.
+// ---------------------------------------------------------------------------------------
+struct PlanJob {
+  at::Tensor edge_index, arena;
+  int64_t num_edges = 0;
+  int32_t num_nodes = 0, normalize = 0, device = 0;
+  hipEvent_t ready = nullptr;
+  void* side_stream = nullptr;
+  gconv_graph_t graph{};
+  gconv_status_t status = 0;
+  bool done = false;
+};
+
+class PlanWorker {
+ public:
+  ~PlanWorker() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    if (thread_.joinable()) thread_.join();
+  }
+
+  int64_t submit(at::Tensor edge_index, int64_t num_nodes, bool normalize, int64_t main_stream,
+                 int64_t side_stream) {
+    TORCH_CHECK(g_lib.handle, "gconv_adapter_amd: library not loaded");
+    TORCH_CHECK(edge_index.is_cuda() && edge_index.scalar_type() == at::kLong && edge_index.dim() == 2 &&
+                    edge_index.size(0) == 2 && edge_index.is_contiguous(),
+                "gconv_adapter_amd: edge_index must be a contiguous int64 [2, E] HIP tensor");
+    auto job = std::make_shared<PlanJob>();
+    job->edge_index = edge_index;
+    job->num_edges = edge_index.size(1);
+    job->num_nodes = static_cast<int32_t>(num_nodes);
+    job->normalize = normalize ? 1 : 0;
+    job->device = edge_index.get_device();
+    job->side_stream = reinterpret_cast<void*>(side_stream);
+    const size_t bytes = g_lib.build_bytes(job->num_edges, job->num_nodes);
+    job->arena = at::empty({static_cast<int64_t>(bytes)}, edge_index.options().dtype(at::kByte));
+    TORCH_CHECK(hipEventCreateWithFlags(&job->ready, hipEventDisableTiming) == hipSuccess &&
+                    hipEventRecord(job->ready, reinterpret_cast<hipStream_t>(main_stream)) == hipSuccess,
+                "gconv_adapter_amd: cannot record the prefetch event");
+    std::lock_guard<std::mutex> lk(mu_);
+    const int64_t id = next_id_++;
+    jobs_[id] = job;
+    queue_.push_back(job);
+    if (!thread_.joinable()) thread_ = std::thread([this] { run(); });
+    cv_.notify_all();
+    return id;
+  }
+
+  // (arena, gconv_graph_t bytes, status); blocks until the build has finished
+  std::tuple<at::Tensor, py::bytes, int64_t> take(int64_t id) {
+    std::shared_ptr<PlanJob> job;
+    {
+      py::gil_scoped_release nogil;
+      std::unique_lock<std::mutex> lk(mu_);
+      auto it = jobs_.find(id);
+      TORCH_CHECK(it != jobs_.end(), "gconv_adapter_amd: unknown prefetch job ", id);
+      job = it->second;
+      done_cv_.wait(lk, [&] { return job->done; });
+      jobs_.erase(it);
+    }
+    (void)hipEventDestroy(job->ready);
+    return {job->arena, py::bytes(reinterpret_cast<const char*>(&job->graph), sizeof(gconv_graph_t)),
+            static_cast<int64_t>(job->status)};
+  }
+
+ private:
+  void run() {
+    int cur = -1;
+    for (;;) {
+      std::shared_ptr<PlanJob> job;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+        if (stop_) return;
+        job = queue_.front();
+        queue_.pop_front();
+      }
+      if (job->device != cur) {
+        (void)hipSetDevice(job->device);
+        cur = job->device;
+      }
+      hipStream_t side = static_cast<hipStream_t>(job->side_stream);
+      gconv_status_t st = static_cast<gconv_status_t>(hipStreamWaitEvent(side, job->ready, 0));
+      if (st == 0)
+        st = g_lib.build(job->edge_index.data_ptr<int64_t>(), job->num_edges, job->num_nodes, job->normalize,
+                         job->arena.data_ptr(), static_cast<size_t>(job->arena.numel()), &job->graph, side);
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        job->status = st;
+        job->done = true;
+      }
+      done_cv_.notify_all();
+    }
+  }
+
+  std::mutex mu_;
+  std::condition_variable cv_, done_cv_;
+  std::deque<std::shared_ptr<PlanJob>> queue_;
+  std::unordered_map<int64_t, std::shared_ptr<PlanJob>> jobs_;
+  std::thread thread_;
+  int64_t next_id_ = 1;
+  bool stop_ = false;
+};
+
+PlanWorker& worker() {
+  static PlanWorker* w = new PlanWorker();  // leaked on purpose: no thread join at interpreter exit
+  return *w;
+}
+
+int64_t plan_submit(at::Tensor edge_index, int64_t num_nodes, bool normalize, int64_t main_stream,
+                    int64_t side_stream) {
+  return worker().submit(std::move(edge_index), num_nodes, normalize, main_stream, side_stream);
+}
+std::tuple<at::Tensor, py::bytes, int64_t> plan_take(int64_t id) { return worker().take(id); }
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
-  m.doc() = "C++ autograd bridge to the gconv_adapter C ABI";
+  m.doc() = "C++ autograd bridge to the gconv_adapter C ABI + native graph-plan prefetch worker";
   m.def("load_library", &load_library);
   m.def("adapter_apply", &adapter_apply);
+  m.def("plan_submit", &plan_submit);
+  m.def("plan_take", &plan_take);
 }

@@ -21,6 +21,15 @@ import torch
 from . import _lib
 
 
+def _check_edge_index(edge_index: torch.Tensor) -> None:
+    if edge_index.dim() != 2 or edge_index.size(0) != 2:
+        raise RuntimeError("edge_index must have shape [2, num_edges]")
+    if edge_index.dtype != torch.int64:
+        raise RuntimeError("edge_index must be int64 (PyG convention)")
+    if not edge_index.is_cuda:
+        raise RuntimeError("gconv_adapter_amd has no CPU path: edge_index must live on a HIP device")
+
+
 class CsrView:
     """Read-only view of one CSR direction inside a plan's arena (tensors are
     materialised lazily: the kernels only need the ``gconv_csr_t``)."""
@@ -56,25 +65,24 @@ class GraphPlan:
     """Everything the kernels need to apply S and S^T for one ``edge_index``:
     ONE ``gconv_graph_build`` call, ONE device allocation (the arena)."""
 
-    def __init__(self, edge_index: torch.Tensor, num_nodes: int, normalize: bool):
-        if edge_index.dim() != 2 or edge_index.size(0) != 2:
-            raise RuntimeError("edge_index must have shape [2, num_edges]")
-        if edge_index.dtype != torch.int64:
-            raise RuntimeError("edge_index must be int64 (PyG convention)")
-        if not edge_index.is_cuda:
-            raise RuntimeError("gconv_adapter_amd has no CPU path: edge_index must live on a HIP device")
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, normalize: bool, _built=None):
+        _check_edge_index(edge_index)
         lib = _lib.load()
         ei = edge_index if edge_index.is_contiguous() else edge_index.contiguous()
         self.num_nodes, self.normalize = int(num_nodes), bool(normalize)
         self.num_edges = int(ei.shape[1])
         self.device = ei.device
         self.struct = _lib.GraphStruct()
-        with torch.cuda.device(ei.device):
-            nbytes = int(lib.gconv_graph_build_bytes(self.num_edges, self.num_nodes))
-            self.arena = torch.empty(nbytes, dtype=torch.uint8, device=ei.device)
-            st = lib.gconv_graph_build(ei.data_ptr(), self.num_edges, self.num_nodes,
-                                       int(self.normalize), self.arena.data_ptr(), nbytes,
-                                       C.byref(self.struct), torch.cuda.current_stream().cuda_stream)
+        if _built is not None:   # (arena, gconv_graph_t bytes, status) from the native prefetch worker
+            self.arena, raw, st = _built
+            C.memmove(C.addressof(self.struct), raw, C.sizeof(self.struct))
+        else:
+            with torch.cuda.device(ei.device):
+                nbytes = int(lib.gconv_graph_build_bytes(self.num_edges, self.num_nodes))
+                self.arena = torch.empty(nbytes, dtype=torch.uint8, device=ei.device)
+                st = lib.gconv_graph_build(ei.data_ptr(), self.num_edges, self.num_nodes,
+                                           int(self.normalize), self.arena.data_ptr(), nbytes,
+                                           C.byref(self.struct), torch.cuda.current_stream().cuda_stream)
         _lib.check(st, "graph_build")
         self.symmetric = bool(self.struct.symmetric)
         self.fwd = CsrView(self, self.struct.fwd)
@@ -133,10 +141,12 @@ class PlanCache:
     recycled for a different edge list while the key is alive; an in-place edit
     bumps ``_version`` and misses.
 
-    ``prefetch`` builds a plan for a FUTURE batch on a side stream from a worker thread
-    (ctypes releases the GIL inside the C ABI), the way the reference's DataLoader workers
-    collate the next batch while the current step runs: the graph build then overlaps the
-    adapters of the current step instead of preceding those of the next one."""
+    ``prefetch`` builds a plan for a FUTURE batch on a side stream from a worker thread, the
+    way the reference's DataLoader workers collate the next batch while the current step
+    runs: the graph build then overlaps the adapters of the current step instead of preceding
+    those of the next one. With the C++ extension the worker is a native thread
+    (``csrc/torch_binding.cpp``, no interpreter lock involved); without it, a Python thread
+    (ctypes releases the GIL inside the C ABI)."""
 
     def __init__(self, capacity: int = 8):
         self.capacity = capacity
@@ -168,7 +178,11 @@ class PlanCache:
             self.hits += 1
             return hit[1]
         fut = self._pending.pop(key, None)
-        if fut is not None:                       # built (or being built) by the prefetcher
+        if isinstance(fut, tuple):                # (job id, edge_index) of the native worker
+            from . import _torch_ext
+            plan = GraphPlan(fut[1], num_nodes, normalize, _built=_torch_ext.get().plan_take(fut[0]))
+            self.hits += 1
+        elif fut is not None:                     # built (or being built) by the Python prefetcher
             plan = fut.result()
             # the arena was allocated on the side stream but is consumed on this one
             plan.arena.record_stream(torch.cuda.current_stream(plan.device))
@@ -184,15 +198,23 @@ class PlanCache:
         key = self._key(edge_index, num_nodes, normalize)
         if key in self._entries or key in self._pending:
             return
-        if not edge_index.is_cuda:
-            raise RuntimeError("gconv_adapter_amd has no CPU path: edge_index must live on a HIP device")
+        _check_edge_index(edge_index)
         dev = edge_index.device
+        from . import _torch_ext
+        ext = _torch_ext.get()
         with self._lock:
-            if self._pool is None:
+            if self._pool is None and ext is None:
                 self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="gconv-plan")
             side = self._side_streams.get(dev)
             if side is None:
                 side = self._side_streams[dev] = torch.cuda.Stream(device=dev)
+        if ext is not None:
+            ei = edge_index if edge_index.is_contiguous() else edge_index.contiguous()
+            with torch.cuda.device(dev):
+                job = ext.plan_submit(ei, int(num_nodes), bool(normalize),
+                                      torch._C._cuda_getCurrentRawStream(dev.index), side.cuda_stream)
+            self._pending[key] = (job, ei)
+            return
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(dev))   # edge_index is complete after this point
 
@@ -209,7 +231,11 @@ class PlanCache:
 
     def clear(self) -> None:
         for fut in list(self._pending.values()):
-            fut.result()
+            if isinstance(fut, tuple):
+                from . import _torch_ext
+                _torch_ext.get().plan_take(fut[0])
+            else:
+                fut.result()
         self._pending.clear()
         self._entries.clear()
 

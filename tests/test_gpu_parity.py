@@ -105,6 +105,32 @@ def test_graph_build_component_tiles(dev):
     assert ga.GraphPlan(big.edge_index.to(dev), 3000, True).n_tiles == 0
 
 
+def test_prefetched_plan_equals_direct_build(dev):
+    """The plan built ahead of time by the prefetch worker (native thread with the C++
+    extension, Python thread without) is the plan a direct build gives: bit-exact index
+    arrays, same counters; and the adapter consumes it."""
+    batch = ga.synth.molecule_batch("hiv", 64, seed=11)
+    n = batch.num_nodes
+    ei = batch.edge_index.to(dev)
+    direct = ga.GraphPlan(ei, n, True)
+    ga.PLAN_CACHE.clear()
+    ga.prefetch_plan(ei, n, True)
+    plan = ga.get_plan(ei, n, True)
+    assert ga.PLAN_CACHE.hits >= 1 and plan is not direct
+    for name in ("rowptr", "col"):
+        assert torch.equal(getattr(plan.fwd, name), getattr(direct.fwd, name))
+    assert torch.equal(plan.tile_ptr, direct.tile_ptr) and torch.equal(plan.tile_order, direct.tile_order)
+    assert torch.equal(plan.dis, direct.dis)
+    assert (plan.n_tiles, plan.tile_nodes_max, plan.symmetric) == (direct.n_tiles, direct.tile_nodes_max,
+                                                                  direct.symmetric)
+    # a bad edge list surfaces as RuntimeError when the plan is taken, as in a direct build
+    bad = torch.tensor([[0, 1, 70], [1, 0, 2]], device=dev)
+    ga.prefetch_plan(bad, 8, True)
+    with pytest.raises(RuntimeError):
+        ga.get_plan(bad, 8, True)
+    ga.PLAN_CACHE.clear()
+
+
 def test_graph_prep_rejects_bad_index(dev):
     ei = torch.tensor([[0, 1, 7], [1, 0, 2]])
     with pytest.raises(RuntimeError, match="outside"):

@@ -9,7 +9,7 @@ os.environ["GCONV_PY_BINDING"] = "1"
 import numpy as np, torch
 import gconv_adapter_amd as ga
 from gconv_adapter_amd import _lib
-alt = _lib.LIB_PATH.replace("libgconv_adapter.so", "libgconv_adapter_stamps.so")
+alt = os.environ.get("GCONV_STAMPS_LIB") or _lib.LIB_PATH.replace("libgconv_adapter.so", "libgconv_adapter_stamps.so")
 if not os.path.exists(alt):
     srcs = sorted(glob.glob(os.path.join(ROOT, "gconv-adapter_amd", "csrc", "*.hip")))
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
