@@ -289,6 +289,47 @@ def test_adapter_hiv_shard(dev, normalize):
     _check_workload(dev, batch, cfg["d"], cfg["r"], flags)
 
 
+@pytest.mark.parametrize("d,r,act,normalize", [
+    (8, 1, "relu", True), (16, 3, "silu", True), (64, 4, "relu", False), (100, 8, "none", True),
+    (128, 16, "relu", True), (200, 5, "silu", False), (256, 8, "relu", True), (300, 16, "silu", True),
+    (300, 32, "relu", True), (304, 2, "relu", False), (320, 8, "relu", True), (384, 16, "none", True),
+    (512, 4, "relu", True), (512, 8, "silu", False)])
+def test_adapter_tile_path_width_rank_sweep(dev, d, r, act, normalize):
+    """The fused tile kernels at every compiled row length / rank class (ring sizes, co-owner
+    slot maps and the range-checked column tails differ per (d, Fp)), vs the fp64 oracle."""
+    batch = ga.synth.molecule_batch("hiv", 40, hidden=d, seed=d + r)
+    flags = oracle.AdapterFlags(non_linearity=act, learnable_scalar=True, normalize=normalize)
+    _check_workload(dev, batch, d, r, flags, seed=r)
+
+
+def test_adapter_tile_path_large_components(dev):
+    """Components far larger than the workgroup (400-node rings with chords: more tile rows and
+    more tile edges than threads, several node blocks per wave in phases 1 and 4) next to
+    single-node and two-node graphs."""
+    gen = torch.Generator().manual_seed(5)
+    sizes = [400, 1, 2, 390, 17, 1, 350]
+    src, dst, off = [], [], 0
+    for n in sizes:
+        if n > 1:
+            a = torch.arange(n)
+            ring = torch.stack([a, (a + 1) % n]) if n > 2 else torch.tensor([[0], [1]])
+            chords = torch.randint(n, (2, n // 2), generator=gen)
+            chords = chords[:, chords[0] != chords[1]]
+            e = torch.cat([ring, chords], dim=1)
+            e = torch.cat([e, e.flip(0)], dim=1) + off
+            src.append(e[0]); dst.append(e[1])
+        off += n
+    ei = torch.stack([torch.cat(src), torch.cat(dst)])
+    x = torch.randn(off, 300, generator=gen)
+    ptr = torch.tensor([0] + list(np.cumsum(sizes)))
+    batch = ga.synth.GraphBatch(x=x, edge_index=ei, graph_ptr=ptr, num_graphs=len(sizes))
+    plan = ga.GraphPlan(ei.to(dev), off, True)
+    assert plan.n_tiles > 0 and plan.tile_nodes_max >= 400      # the fused tile path takes it
+    for normalize in (True, False):
+        flags = oracle.AdapterFlags(learnable_scalar=True, normalize=normalize)
+        _check_workload(dev, batch, 300, 8, flags)
+
+
 def test_adapter_cora_3d_input(dev):
     batch, cfg = ga.synth.make_workload("cora")
     assert batch.x.dim() == 3
