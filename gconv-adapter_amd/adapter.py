@@ -15,6 +15,7 @@ library through ``functional.GConvAdapterFunction``. There is no CPU path.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -23,6 +24,9 @@ import torch.nn as nn
 from . import _lib, _torch_ext
 from .functional import GConvAdapterFunction, _stream
 from .graph import get_plan
+
+#: default of ``GConvAdapter.direct_param_grads`` (env GCONV_AUTOGRAD_PARAM_GRADS=1 turns it off)
+DIRECT_PARAM_GRADS = not os.environ.get("GCONV_AUTOGRAD_PARAM_GRADS")
 
 
 class GCNConvParams(nn.Module):
@@ -104,6 +108,11 @@ class GConvAdapter(nn.Module):
         else:
             self.scalar = None
         self.skip_connection = skip_connection
+        #: backward stores the parameter gradients in ``p.grad`` itself instead of handing them
+        #: to five AccumulateGrad nodes (C++ binding only; ≈ 15 µs less host time per call).
+        #: Set False for ``torch.autograd.grad(..., parameters)`` or autograd hooks on the
+        #: parameters (DistributedDataParallel).
+        self.direct_param_grads = DIRECT_PARAM_GRADS
 
         # near-identity init (reference :73-78)
         nn.init.normal_(self.conv_down.lin.weight, mean=0.0, std=1e-5)
@@ -127,9 +136,45 @@ class GConvAdapter(nn.Module):
         if dev.index != torch.cuda.current_device():
             torch.cuda.set_device(dev)
         fp, ws_fwd, ws_bwd = plan.sizes(_lib.load(), self.hidden_size, self.bottleneck_size)
+        if self.direct_param_grads and torch.is_grad_enabled():
+            pack = self._param_pack(ext, p, fuse_scalar)
+            if pack is not None:
+                anchor = None
+                if not x2d.requires_grad:   # keeps the node alive when only the parameters train
+                    anchor = self.__dict__.get("_anchor")
+                    if anchor is None or anchor.device != dev:
+                        anchor = torch.zeros(1, device=dev, requires_grad=True)
+                        self.__dict__["_anchor"] = anchor
+                return ext.adapter_apply_direct(x2d, anchor, pack, plan.arena, plan.struct_addr, fp, ws_fwd,
+                                                ws_bwd, p[5], bool(self.skip_connection), _stream(dev.index))
         return ext.adapter_apply(x2d, p[0], p[1], p[2], p[3], p[4] if fuse_scalar else None,
                                  plan.arena, plan.struct_addr, fp, ws_fwd, ws_bwd, p[5],
                                  bool(self.skip_connection), _stream(dev.index))
+
+    def _param_pack(self, ext, p, fuse_scalar: bool):
+        """Handle of the C++ ParamPack for direct gradient deposit, or None when a parameter
+        carries a tensor hook (hooks only run under standard autograd accumulation)."""
+        key = (id(p[0]), id(p[1]), id(p[2]), id(p[3]), id(p[4]) if fuse_scalar else 0)
+        hit = self.__dict__.get("_pack")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        params = (p[0], p[1], p[2], p[3], p[4] if fuse_scalar else None)
+        if any(q is not None and (q._backward_hooks or getattr(q, "_post_accumulate_grad_hooks", None))
+               for q in params):
+            return None
+        if hit is not None:
+            ext.pack_release(hit[1])
+        pack = ext.pack_create(*params)
+        self.__dict__["_pack"] = (key, pack)
+        return pack
+
+    def __del__(self):
+        hit = self.__dict__.get("_pack")
+        if hit is not None:
+            try:
+                _torch_ext.get().pack_release(hit[1])
+            except Exception:   # interpreter shutdown
+                pass
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor,
                 edge_attr: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -150,6 +150,137 @@ struct AdapterFn : public torch::autograd::Function<AdapterFn> {
   }
 };
 
+// ---------------------------------------------------------------------------------------
+// Direct-deposit variant. The parameters are not autograd inputs of the node: backward writes
+// their gradients into `p.grad` itself (assign if undefined, add in place otherwise — what
+// AccumulateGrad does), so the engine runs ONE node per adapter instead of six and nothing but
+// x / the saved rank-width tensors is packed for backward. Same kernels, same numbers; what
+// changes is who stores the result. Not for callers that need `torch.autograd.grad(…, params)`
+// or autograd hooks on the parameters (DDP): GConvAdapter.direct_param_grads = False selects
+// AdapterFn above. A ParamPack holds the module's parameter tensors (the Parameter objects
+// are stable across .to() / load_state_dict / optimizer steps).
+// ---------------------------------------------------------------------------------------
+struct ParamPack {
+  at::Tensor w_down, b_down, w_up, b_up, scalar;
+};
+std::mutex g_pack_mu;
+std::unordered_map<int64_t, std::shared_ptr<ParamPack>> g_packs;
+int64_t g_next_pack = 1;
+
+int64_t pack_create(at::Tensor w_down, c10::optional<at::Tensor> b_down, at::Tensor w_up,
+                    c10::optional<at::Tensor> b_up, c10::optional<at::Tensor> scalar) {
+  auto pk = std::make_shared<ParamPack>();
+  pk->w_down = std::move(w_down);
+  pk->b_down = b_down.value_or(at::Tensor());
+  pk->w_up = std::move(w_up);
+  pk->b_up = b_up.value_or(at::Tensor());
+  pk->scalar = scalar.value_or(at::Tensor());
+  std::lock_guard<std::mutex> lk(g_pack_mu);
+  g_packs[g_next_pack] = pk;
+  return g_next_pack++;
+}
+void pack_release(int64_t id) {
+  std::lock_guard<std::mutex> lk(g_pack_mu);
+  g_packs.erase(id);
+}
+std::shared_ptr<ParamPack> pack_get(int64_t id) {
+  std::lock_guard<std::mutex> lk(g_pack_mu);
+  auto it = g_packs.find(id);
+  TORCH_CHECK(it != g_packs.end(), "gconv_adapter_amd: the adapter module of this graph node is gone");
+  return it->second;
+}
+
+void deposit_grad(const at::Tensor& p, at::Tensor g) {
+  if (!p.defined() || !g.defined() || !p.requires_grad()) return;
+  at::Tensor& cur = p.mutable_grad();
+  if (!cur.defined()) cur = std::move(g);
+  else cur.add_(g);
+}
+
+struct AdapterFnDirect : public torch::autograd::Function<AdapterFnDirect> {
+  static at::Tensor forward(torch::autograd::AutogradContext* ctx, at::Tensor x,
+                            c10::optional<at::Tensor> anchor, int64_t pack_id, at::Tensor arena,
+                            int64_t graph_addr, int64_t fp, int64_t ws_fwd, int64_t ws_bwd, int64_t act,
+                            bool skip, int64_t stream) {
+    (void)anchor;  // differentiable dummy: keeps the node alive when x needs no gradient
+    TORCH_CHECK(g_lib.handle, "gconv_adapter_amd: library not loaded");
+    TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat,
+                "gconv_adapter_amd computes in fp32 on a HIP device (no CPU path)");
+    const std::shared_ptr<ParamPack> pk = pack_get(pack_id);
+    if (!x.is_contiguous()) x = x.contiguous();
+    TORCH_CHECK(pk->w_down.is_contiguous() && pk->w_up.is_contiguous(),
+                "gconv_adapter_amd: adapter weights must be contiguous");
+    const int64_t n = x.size(0), d = x.size(1), r = pk->w_down.size(0);
+    gconv_graph_t g;
+    std::memcpy(&g, reinterpret_cast<const void*>(graph_addr), sizeof(g));
+    TORCH_CHECK(n == g.fwd.num_nodes, "x has ", n, " nodes but the graph plan was built for ",
+                g.fwd.num_nodes);
+    at::Tensor out = at::empty_like(x);
+    at::Tensor saved = at::empty({act == GCONV_ACT_SILU ? 3 : 2, n, fp}, x.options());
+    at::Tensor ws = at::empty({ws_fwd}, x.options().dtype(at::kByte));
+    float* sv = saved.data_ptr<float>();
+    gconv_adapter_params_t p{fptr(pk->w_down), fptr(pk->b_down), fptr(pk->w_up), fptr(pk->b_up),
+                             fptr(pk->scalar), static_cast<int32_t>(d), static_cast<int32_t>(r),
+                             static_cast<int32_t>(act), skip ? 1 : 0};
+    check(g_lib.fwd(&g, &p, x.data_ptr<float>(), out.data_ptr<float>(), sv,
+                    act == GCONV_ACT_SILU ? sv + 2 * n * fp : nullptr, sv + n * fp, ws.data_ptr(),
+                    static_cast<size_t>(ws_fwd), reinterpret_cast<void*>(stream)),
+          "adapter_fwd");
+    ctx->save_for_backward({x, saved, arena});
+    ctx->saved_data["g"] = std::string(reinterpret_cast<const char*>(&g), sizeof(g));
+    ctx->saved_data["i"] = std::vector<int64_t>{pack_id, fp, ws_bwd, act, skip ? 1 : 0, stream};
+    return out;
+  }
+
+  static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx,
+                                                 torch::autograd::variable_list grads) {
+    auto sv = ctx->get_saved_variables();
+    at::Tensor x = sv[0], saved = sv[1];
+    gconv_graph_t g;
+    const std::string& gs = ctx->saved_data["g"].toStringRef();
+    std::memcpy(&g, gs.data(), sizeof(g));
+    const std::vector<int64_t> iv = ctx->saved_data["i"].toIntVector();
+    const int64_t fp = iv[1], ws_bwd = iv[2], act = iv[3], stream = iv[5];
+    const bool skip = iv[4] != 0;
+    const std::shared_ptr<ParamPack> pk = pack_get(iv[0]);
+    at::Tensor go = grads[0];
+    TORCH_CHECK(go.defined() && go.is_cuda() && go.scalar_type() == at::kFloat,
+                "gconv_adapter_amd: grad_output must be an fp32 HIP tensor");
+    if (!go.is_contiguous()) go = go.contiguous();
+    const int64_t n = x.size(0), d = x.size(1), r = pk->w_down.size(0);
+    at::NoGradGuard no_grad;
+    at::Tensor gx = ctx->needs_input_grad(0) ? at::empty_like(x) : at::Tensor();
+    at::Tensor gwd = at::empty_like(pk->w_down), gwu = at::empty_like(pk->w_up);
+    at::Tensor gbd = pk->b_down.defined() ? at::empty_like(pk->b_down) : at::Tensor();
+    at::Tensor gbu = pk->b_up.defined() ? at::empty_like(pk->b_up) : at::Tensor();
+    at::Tensor gsc = pk->scalar.defined() ? at::empty_like(pk->scalar) : at::Tensor();
+    at::Tensor ws = at::empty({ws_bwd}, x.options().dtype(at::kByte));
+    const float* svp = saved.data_ptr<float>();
+    gconv_adapter_params_t p{fptr(pk->w_down), fptr(pk->b_down), fptr(pk->w_up), fptr(pk->b_up),
+                             fptr(pk->scalar), static_cast<int32_t>(d), static_cast<int32_t>(r),
+                             static_cast<int32_t>(act), skip ? 1 : 0};
+    check(g_lib.bwd(&g, &p, x.data_ptr<float>(), go.data_ptr<float>(), svp,
+                    act == GCONV_ACT_SILU ? svp + 2 * n * fp : nullptr, svp + n * fp,
+                    fptr_mut(gx), gwd.data_ptr<float>(), fptr_mut(gbd), gwu.data_ptr<float>(),
+                    fptr_mut(gbu), fptr_mut(gsc), ws.data_ptr(), static_cast<size_t>(ws_bwd),
+                    reinterpret_cast<void*>(stream)),
+          "adapter_bwd");
+    deposit_grad(pk->w_down, std::move(gwd));
+    deposit_grad(pk->b_down, std::move(gbd));
+    deposit_grad(pk->w_up, std::move(gwu));
+    deposit_grad(pk->b_up, std::move(gbu));
+    deposit_grad(pk->scalar, std::move(gsc));
+    at::Tensor none;
+    return {gx, none, none, none, none, none, none, none, none, none, none};
+  }
+};
+
+at::Tensor adapter_apply_direct(at::Tensor x, c10::optional<at::Tensor> anchor, int64_t pack_id,
+                                at::Tensor arena, int64_t graph_addr, int64_t fp, int64_t ws_fwd,
+                                int64_t ws_bwd, int64_t act, bool skip, int64_t stream) {
+  return AdapterFnDirect::apply(x, anchor, pack_id, arena, graph_addr, fp, ws_fwd, ws_bwd, act, skip, stream);
+}
+
 at::Tensor adapter_apply(at::Tensor x, at::Tensor w_down, c10::optional<at::Tensor> b_down,
                          at::Tensor w_up, c10::optional<at::Tensor> b_up,
                          c10::optional<at::Tensor> scalar, at::Tensor arena, int64_t graph_addr,
@@ -293,6 +424,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "C++ autograd bridge to the gconv_adapter C ABI + native graph-plan prefetch worker";
   m.def("load_library", &load_library);
   m.def("adapter_apply", &adapter_apply);
+  m.def("adapter_apply_direct", &adapter_apply_direct);
+  m.def("pack_create", &pack_create);
+  m.def("pack_release", &pack_release);
   m.def("plan_submit", &plan_submit);
   m.def("plan_take", &plan_take);
 }

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import threading
+import weakref
 from collections import OrderedDict
 from concurrent.futures import ThreadPoolExecutor
 from typing import Optional, Tuple
@@ -35,7 +36,10 @@ class CsrView:
     materialised lazily: the kernels only need the ``gconv_csr_t``)."""
 
     def __init__(self, plan: "GraphPlan", struct: _lib.CsrStruct):
-        self._plan, self.struct = plan, struct
+        # weak: plan -> view -> plan would be a reference cycle, and a discarded plan (with its
+        # arena) would then live until the cyclic GC runs instead of until its last use — a
+        # training loop that builds a plan per batch would keep allocating fresh arenas
+        self._plan, self.struct = weakref.proxy(plan), struct
         self.nnz, self.n_long, self.n_seg = struct.nnz, struct.n_long, struct.n_seg
 
     def ref(self):

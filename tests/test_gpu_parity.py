@@ -403,6 +403,50 @@ def test_adapter_rejects_cpu_and_wrong_dtype(dev):
         ga.GConvAdapter(10, 2).to(dev)(torch.randn(2, 10, device=dev), ei.to(dev))  # d % 4 != 0
 
 
+def test_direct_param_grad_deposit_equals_autograd_accumulation(dev):
+    """C++ binding, two ways of storing the parameter gradients — written into p.grad by the
+    node itself (default) or returned to AccumulateGrad nodes: bit-identical results; a second
+    backward accumulates; inputs without grad still train the parameters; a parameter with a
+    tensor hook takes the standard route."""
+    if ga._torch_ext.get() is None:
+        pytest.skip("pure-Python binding selected")
+    batch, cfg = ga.synth.make_workload("esol")
+    d, r = cfg["d"], cfg["r"]
+    x = batch.x.to(dev); ei = batch.edge_index.to(dev)
+    g = torch.randn(x.shape, generator=torch.Generator().manual_seed(4)).to(dev)
+    mods = [ga.GConvAdapter(d, r, learnable_scalar=True, non_linearity="silu").to(dev) for _ in range(2)]
+    with torch.no_grad():
+        for p0, p1 in zip(mods[0].parameters(), mods[1].parameters()):
+            p0.normal_(0, 0.1); p1.copy_(p0)
+    mods[1].direct_param_grads = False
+    res = []
+    for m in mods:
+        xg = x.clone().requires_grad_(True)
+        out = m(xg, ei)
+        out.backward(g, retain_graph=True)
+        first = [p.grad.clone() for p in m.parameters()]
+        out.backward(g)                       # accumulates into the existing .grad
+        res.append((out.detach(), xg.grad, first, [p.grad for p in m.parameters()]))
+    assert type(res[0][0].grad_fn) is type(None)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for a, b in zip(res[0][2], res[1][2]):
+        assert torch.equal(a, b)
+    for first, twice in zip(res[0][2], res[0][3]):
+        assert torch.equal(twice, first + first)
+    # x without grad: the anchor keeps the node alive
+    m = mods[0]
+    m.zero_grad(set_to_none=True)
+    m(x, ei).backward(g)
+    for p, want in zip(m.parameters(), res[0][2]):   # (another kernel variant: no dX)
+        assert p.grad is not None and torch.allclose(p.grad, want, rtol=1e-5, atol=1e-6)
+    # a tensor hook on a parameter -> standard autograd (the hook runs)
+    m2 = ga.GConvAdapter(d, r, learnable_scalar=True).to(dev)
+    seen = []
+    m2.conv_up.bias.register_hook(lambda gr: seen.append(gr.shape))
+    m2(x, ei).backward(g)
+    assert seen == [m2.conv_up.bias.shape] and m2.conv_down.lin.weight.grad is not None
+
+
 def test_plan_cache_shared_across_adapters(dev):
     batch, cfg = ga.synth.make_workload("esol")
     ga.PLAN_CACHE.clear()

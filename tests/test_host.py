@@ -193,3 +193,23 @@ def test_cpp_autograd_binding_loads_and_binds_the_same_c_abi():
     with pytest.raises(RuntimeError):
         ext.adapter_apply(torch.randn(2, 8), torch.randn(2, 8), None, torch.randn(8, 2), None, None,
                           torch.zeros(1, dtype=torch.uint8), 0, 4, 16, 16, 1, True, 0)
+
+
+def test_host_thread_pinning_helpers():
+    """dist.local_core_set: every local rank gets a non-empty set inside the process's CPU mask,
+    ranks on the same NUMA node get disjoint sets when there are enough cores."""
+    import os
+    from gconv_adapter_amd import dist as gd
+    assert gd._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    allowed = set(os.sched_getaffinity(0))
+    sets = [gd.local_core_set(r, 4, cores_per_rank=2) for r in range(4)]
+    for s in sets:
+        assert s and set(s) <= allowed
+    if len(allowed) >= 16:
+        flat = [c for s in sets for c in s]
+        assert len(flat) == len(set(flat))
+    os.environ["GCONV_NO_PIN"] = "1"
+    try:
+        assert gd.pin_to_local_cores() == []
+    finally:
+        del os.environ["GCONV_NO_PIN"]

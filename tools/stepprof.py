@@ -9,6 +9,8 @@ import gconv_adapter_amd as ga
 dev = torch.device("cuda:0")
 name = sys.argv[1] if len(sys.argv) > 1 else "esol"
 fresh = (sys.argv[2] != "cached") if len(sys.argv) > 2 else True
+if "heat" in sys.argv:   # what a preceding heavy phase (S-arxiv measurement) does to the step
+    bench.measure_arxiv(dev, banded_control=False)
 stream = bench.BatchStream(name, 0, dev, 4, fresh)
 cfg = stream.cfg
 mods = [ga.GConvAdapter(cfg["d"], cfg["r"], learnable_scalar=True).to(dev) for _ in range(cfg["adapters"])]
