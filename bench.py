@@ -131,12 +131,17 @@ def adapter_step(mods, params, stream: BatchStream, normalize: bool, bucket=None
     return batch.num_graphs
 
 
-def settle(fn, device, chunk: int = 100, max_seconds: float = 3.0) -> int:
+def settle(fn, device, world: int = 1, chunk: int = 100, max_seconds: float = 3.0) -> int:
     """Untimed pre-roll until the step rate is steady. A fresh process on the GPU box runs the
     same step 1.3–1.8x slower for its first 0.1–0.7 s (hundreds to ~2000 steps; host-side
     ramp-up of the box: the step is host-bound, back-to-back kernel time does not change) —
     longer than any sensible --warmup. Runs chunks of `chunk` steps until two consecutive
     chunks agree within 3 % (or `max_seconds`); returns the number of steps it ran."""
+    if world > 1:   # the step contains a collective: every rank must run the same number of steps
+        for _ in range(5 * chunk):
+            fn()
+        torch.cuda.synchronize(device)
+        return 5 * chunk
     ran, prev, t_end = 0, None, time.perf_counter() + max_seconds
     while time.perf_counter() < t_end:
         torch.cuda.synchronize(device)
@@ -349,7 +354,7 @@ def run_workload(name: str, normalize: bool, steps: int, warmup: int, rank: int,
     def step():
         graphs[0] += adapter_step(mods, params, stream, normalize, bucket)
 
-    settled = settle(step, device)
+    settled = settle(step, device, world)
     graphs[0] = 0
     dt = timed_steps(step, steps, warmup, world, device)
     ga.PLAN_CACHE.clear()
