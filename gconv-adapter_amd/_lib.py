@@ -57,6 +57,14 @@ class GraphStruct(C.Structure):
     ]
 
 
+class PendingFinalize(C.Structure):
+    """``gconv_pending_finalize_t`` (opaque)"""
+    _fields_ = [("opaque", C.c_uint64 * 24)]
+
+
+FINALIZE_BATCH = 8
+
+
 class AdapterParams(C.Structure):
     """``gconv_adapter_params_t``"""
     _fields_ = [
@@ -93,6 +101,10 @@ SIGNATURES = {
                                      _vp, _vp, _sz, _vp]),
     "gconv_adapter_bwd_f32": (_i32, [_graph_p, C.POINTER(AdapterParams), _vp, _vp, _vp, _vp,
                                      _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "gconv_adapter_bwd_partial_f32": (_i32, [_graph_p, C.POINTER(AdapterParams), _vp, _vp, _vp, _vp,
+                                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+                                             C.POINTER(PendingFinalize), _vp]),
+    "gconv_adapter_bwd_finalize_f32": (_i32, [C.POINTER(PendingFinalize), _i32, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -116,7 +128,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.gconv_abi_version() != 2:
+    if lib.gconv_abi_version() != 3:
         raise RuntimeError("gconv_adapter_amd: ABI version mismatch, rebuild the library")
     _lib = lib
     return lib

@@ -15,6 +15,8 @@
 //             parameter gradients                          B5  finalize
 // (dis . = row scaling by deg^-1/2; without normalisation dis == 1 and the
 // implicit self-loop term disappears.)
+#include <cstring>
+
 #include "fused_tile.h"
 #include "gemm.h"
 #include "spmm.h"
@@ -220,15 +222,18 @@ extern "C" gconv_status_t gconv_adapter_fwd_f32(const gconv_graph_t* gr,
   return launch_up_fwd(k3, stream);
 }
 
-extern "C" gconv_status_t gconv_adapter_bwd_f32(const gconv_graph_t* gr,
-                                                const gconv_adapter_params_t* p, const float* x,
-                                                const float* grad_out, const float* saved_h,
-                                                const float* saved_h1, const float* saved_p,
-                                                float* grad_x, float* grad_w_down,
-                                                float* grad_b_down, float* grad_w_up,
-                                                float* grad_b_up, float* grad_scalar,
-                                                void* workspace, size_t workspace_bytes,
-                                                gconv_stream_t stream_) {
+static_assert(sizeof(FinalizeArgs) <= sizeof(gconv_pending_finalize_t),
+              "gconv_pending_finalize_t must be able to hold a FinalizeArgs");
+
+// The whole backward; the last reduction is either launched (pending == nullptr) or described
+// in *pending for gconv_adapter_bwd_finalize_f32.
+static gconv_status_t adapter_bwd(const gconv_graph_t* gr, const gconv_adapter_params_t* p,
+                                  const float* x, const float* grad_out, const float* saved_h,
+                                  const float* saved_h1, const float* saved_p, float* grad_x,
+                                  float* grad_w_down, float* grad_b_down, float* grad_w_up,
+                                  float* grad_b_up, float* grad_scalar, void* workspace,
+                                  size_t workspace_bytes, FinalizeArgs* pending,
+                                  gconv_stream_t stream_) {
   if (!gr) return GCONV_E_INVALID_ARG;
   const gconv_csr_t* graph_t = &gr->bwd;
   const float* dis = gr->dis;
@@ -267,6 +272,7 @@ extern "C" gconv_status_t gconv_adapter_bwd_f32(const gconv_graph_t* gr,
     f.scalar = p->scalar; f.b_up = p->b_up; f.cs_tmp = tw.cs_tmp;
     f.g_wd = grad_w_down; f.g_bd = grad_b_down; f.g_wu = grad_w_up; f.g_bu = grad_b_up;
     f.g_s = grad_scalar; f.d = d; f.r = r; f.fp = fp; f.skip = p->skip;
+    if (pending) { *pending = f; return GCONV_OK; }
     return launch_finalize(f, stream);
   }
   const BwdWs ws = carve_bwd(workspace, graph_t, d, fp);
@@ -319,5 +325,51 @@ extern "C" gconv_status_t gconv_adapter_bwd_f32(const gconv_graph_t* gr,
   f.g_wd = grad_w_down; f.g_bd = grad_b_down; f.g_wu = grad_w_up; f.g_bu = grad_b_up;
   f.g_s = grad_scalar;
   f.d = d; f.r = r; f.fp = fp; f.skip = p->skip;
+  if (pending) { *pending = f; return GCONV_OK; }
   return launch_finalize(f, stream);
+}
+
+extern "C" gconv_status_t gconv_adapter_bwd_f32(const gconv_graph_t* gr,
+                                                const gconv_adapter_params_t* p, const float* x,
+                                                const float* grad_out, const float* saved_h,
+                                                const float* saved_h1, const float* saved_p,
+                                                float* grad_x, float* grad_w_down,
+                                                float* grad_b_down, float* grad_w_up,
+                                                float* grad_b_up, float* grad_scalar,
+                                                void* workspace, size_t workspace_bytes,
+                                                gconv_stream_t stream) {
+  return adapter_bwd(gr, p, x, grad_out, saved_h, saved_h1, saved_p, grad_x, grad_w_down, grad_b_down,
+                     grad_w_up, grad_b_up, grad_scalar, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" gconv_status_t gconv_adapter_bwd_partial_f32(
+    const gconv_graph_t* gr, const gconv_adapter_params_t* p, const float* x, const float* grad_out,
+    const float* saved_h, const float* saved_h1, const float* saved_p, float* grad_x,
+    float* grad_w_down, float* grad_b_down, float* grad_w_up, float* grad_b_up, float* grad_scalar,
+    void* workspace, size_t workspace_bytes, gconv_pending_finalize_t* pending,
+    gconv_stream_t stream) {
+  if (!pending) return GCONV_E_INVALID_ARG;
+  FinalizeArgs f{};
+  const gconv_status_t st =
+      adapter_bwd(gr, p, x, grad_out, saved_h, saved_h1, saved_p, grad_x, grad_w_down, grad_b_down,
+                  grad_w_up, grad_b_up, grad_scalar, workspace, workspace_bytes, &f, stream);
+  if (st != GCONV_OK) return st;
+  memset(pending, 0, sizeof(*pending));
+  memcpy(pending, &f, sizeof(f));
+  return GCONV_OK;
+}
+
+extern "C" gconv_status_t gconv_adapter_bwd_finalize_f32(const gconv_pending_finalize_t* pending,
+                                                         int32_t count, gconv_stream_t stream) {
+  if (count < 0 || (count > 0 && !pending)) return GCONV_E_INVALID_ARG;
+  if (count == 0) return GCONV_OK;
+  static_assert(sizeof(gconv_pending_finalize_t) % alignof(FinalizeArgs) == 0, "array stride");
+  FinalizeArgs f[GCONV_FINALIZE_BATCH];
+  for (int base = 0; base < count; base += GCONV_FINALIZE_BATCH) {
+    const int m = count - base < GCONV_FINALIZE_BATCH ? count - base : GCONV_FINALIZE_BATCH;
+    for (int j = 0; j < m; ++j) memcpy(&f[j], &pending[base + j], sizeof(FinalizeArgs));
+    const gconv_status_t st = launch_finalize_batched(f, m, static_cast<hipStream_t>(stream));
+    if (st != GCONV_OK) return st;
+  }
+  return GCONV_OK;
 }

@@ -75,6 +75,8 @@ struct FinalizeArgs {
   int ds_complete;   // part_ds1 already holds the whole d(scalar) partial (fused tile path)
 };
 gconv_status_t launch_finalize(const FinalizeArgs& a, hipStream_t stream);
+// up to GCONV_FINALIZE_BATCH reductions per launch (same arithmetic, same order per entry)
+gconv_status_t launch_finalize_batched(const FinalizeArgs* a, int count, hipStream_t stream);
 
 // [rows, width] -> [kReduceBlocks, width] column sums in a fixed order (width in 4..64)
 constexpr int kReduceBlocks = 32;

@@ -627,10 +627,9 @@ __device__ __forceinline__ float strided_sum(const float* __restrict__ q, size_t
   return (s0 + s1) + (s2 + s3);
 }
 
-__global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
-  __shared__ float red[kFinS][kFinE];
+__device__ __forceinline__ void finalize_body(const FinalizeArgs& a, int block, float (*red)[kFinE]) {
   const int le = threadIdx.x % kFinE, ps = threadIdx.x / kFinE;
-  const int e = blockIdx.x * kFinE + le;
+  const int e = block * kFinE + le;
   const int rd = a.r * a.d, total = 2 * rd + a.d + a.r + (a.ds_complete ? 1 : 0);
   float sum = 0.f;
   if (e < total) {
@@ -678,8 +677,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
 }
 
 // d(scalar) = sum_i (G_i W_up) . P_i  +  b_up . colsum(G)  +  [skip] sum(G . X)
-__global__ __launch_bounds__(256) void finalize_scalar_kernel(FinalizeArgs a) {
-  __shared__ float red[4];
+__device__ __forceinline__ void finalize_scalar_body(const FinalizeArgs& a, float* red) {
   float acc = 0.f;
   for (int i = threadIdx.x; i < a.n_ds1; i += 256) acc += a.part_ds1[i];
   if (a.skip)
@@ -690,6 +688,36 @@ __global__ __launch_bounds__(256) void finalize_scalar_kernel(FinalizeArgs a) {
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) a.g_s[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
+  __shared__ float red[kFinS][kFinE];
+  finalize_body(a, blockIdx.x, red);
+}
+
+__global__ __launch_bounds__(256) void finalize_scalar_kernel(FinalizeArgs a) {
+  __shared__ float red[4];
+  finalize_scalar_body(a, red);
+}
+
+// Several pending reductions in one launch: blocks [start[j], start[j + 1]) belong to entry j.
+struct FinalizeBatch {
+  FinalizeArgs a[GCONV_FINALIZE_BATCH];
+  int start[GCONV_FINALIZE_BATCH + 1];
+  int count;
+};
+
+__global__ __launch_bounds__(256) void finalize_batched_kernel(FinalizeBatch b) {
+  __shared__ float red[kFinS][kFinE];
+  int j = 0;
+  while (j + 1 < b.count && static_cast<int>(blockIdx.x) >= b.start[j + 1]) ++j;   // uniform
+  finalize_body(b.a[j], blockIdx.x - b.start[j], red);
+}
+
+__global__ __launch_bounds__(256) void finalize_scalar_batched_kernel(FinalizeBatch b) {
+  __shared__ float red[4];
+  const FinalizeArgs& a = b.a[blockIdx.x];
+  if (a.g_s && !a.ds_complete) finalize_scalar_body(a, red);   // uniform per block
 }
 
 // Stage 1 for tall partial arrays: [rows, width] -> [kReduceBlocks, width], fixed order.
@@ -721,6 +749,30 @@ gconv_status_t launch_reduce_rows(const float* in, int rows, int width, float* o
                                   hipStream_t stream) {
   reduce_rows_kernel<<<kReduceBlocks, 256, 0, stream>>>(in, rows, width, out);
   GCONV_LAUNCH_CHECK();
+  return GCONV_OK;
+}
+
+gconv_status_t launch_finalize_batched(const FinalizeArgs* a, int count, hipStream_t stream) {
+  for (int base = 0; base < count; base += GCONV_FINALIZE_BATCH) {
+    FinalizeBatch b;
+    b.count = count - base < GCONV_FINALIZE_BATCH ? count - base : GCONV_FINALIZE_BATCH;
+    bool need_scalar = false;
+    b.start[0] = 0;
+    for (int j = 0; j < b.count; ++j) {
+      b.a[j] = a[base + j];
+      const FinalizeArgs& f = b.a[j];
+      const int total = 2 * f.r * f.d + f.d + f.r + (f.ds_complete ? 1 : 0);
+      b.start[j + 1] = b.start[j] + ceil_div(total, kFinE);
+      need_scalar = need_scalar || (f.g_s && !f.ds_complete);
+    }
+    for (int j = b.count; j < GCONV_FINALIZE_BATCH; ++j) b.start[j + 1] = b.start[b.count];
+    finalize_batched_kernel<<<b.start[b.count], 256, 0, stream>>>(b);
+    GCONV_LAUNCH_CHECK();
+    if (need_scalar) {
+      finalize_scalar_batched_kernel<<<b.count, 256, 0, stream>>>(b);
+      GCONV_LAUNCH_CHECK();
+    }
+  }
   return GCONV_OK;
 }
 

@@ -12,6 +12,7 @@
 // `conv_up(act_fn(conv_down(x, ei)), ei)` (/root/reference/src/finetune/gconv_adapter.py:92).
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
+#include <torch/csrc/autograd/engine.h>
 #include <torch/extension.h>
 
 #include <condition_variable>
@@ -38,6 +39,11 @@ using str_fn_t = const char* (*)(gconv_status_t);
 using bytes_fn_t = size_t (*)(int64_t, int32_t);
 using build_fn_t = gconv_status_t (*)(const int64_t*, int64_t, int32_t, int32_t, void*, size_t,
                                       gconv_graph_t*, gconv_stream_t);
+using bwd_partial_fn_t = gconv_status_t (*)(const gconv_graph_t*, const gconv_adapter_params_t*,
+                                            const float*, const float*, const float*, const float*,
+                                            const float*, float*, float*, float*, float*, float*, float*,
+                                            void*, size_t, gconv_pending_finalize_t*, gconv_stream_t);
+using bwd_finalize_fn_t = gconv_status_t (*)(const gconv_pending_finalize_t*, int32_t, gconv_stream_t);
 
 struct Lib {
   void* handle = nullptr;
@@ -46,6 +52,8 @@ struct Lib {
   str_fn_t str = nullptr;
   bytes_fn_t build_bytes = nullptr;
   build_fn_t build = nullptr;
+  bwd_partial_fn_t bwd_partial = nullptr;
+  bwd_finalize_fn_t bwd_finalize = nullptr;
 };
 Lib g_lib;
 
@@ -58,7 +66,10 @@ void load_library(const std::string& path) {
   g_lib.str = reinterpret_cast<str_fn_t>(dlsym(h, "gconv_status_string"));
   g_lib.build_bytes = reinterpret_cast<bytes_fn_t>(dlsym(h, "gconv_graph_build_bytes"));
   g_lib.build = reinterpret_cast<build_fn_t>(dlsym(h, "gconv_graph_build"));
-  TORCH_CHECK(g_lib.fwd && g_lib.bwd && g_lib.str && g_lib.build_bytes && g_lib.build,
+  g_lib.bwd_partial = reinterpret_cast<bwd_partial_fn_t>(dlsym(h, "gconv_adapter_bwd_partial_f32"));
+  g_lib.bwd_finalize = reinterpret_cast<bwd_finalize_fn_t>(dlsym(h, "gconv_adapter_bwd_finalize_f32"));
+  TORCH_CHECK(g_lib.fwd && g_lib.bwd && g_lib.str && g_lib.build_bytes && g_lib.build && g_lib.bwd_partial &&
+                  g_lib.bwd_finalize,
               "gconv_adapter_amd: C ABI symbols missing in ", path);
   g_lib.handle = h;
 }
@@ -190,11 +201,46 @@ std::shared_ptr<ParamPack> pack_get(int64_t id) {
   return it->second;
 }
 
-void deposit_grad(const at::Tensor& p, at::Tensor g) {
-  if (!p.defined() || !g.defined() || !p.requires_grad()) return;
+// The last kernel of every adapter's backward (the fixed-order reduction of the per-workgroup
+// partials into dW / db / ds) is deferred to the end of the autograd pass and run for ALL
+// adapters of that pass in one launch (gconv_adapter_bwd_finalize_f32): nobody reads a
+// parameter gradient before backward() returns, and a model with five adapters otherwise pays
+// five small launches and five kernel boundaries on the critical path of its backward.
+struct PendingAdd {   // p.grad existed already: add the fresh gradient once it has been reduced
+  at::Tensor param, grad;
+};
+struct Deferred {
+  std::vector<gconv_pending_finalize_t> pending;
+  std::vector<at::Tensor> keep;      // workspaces and gradient buffers of the pending entries
+  std::vector<PendingAdd> adds;
+  int64_t stream = 0;
+  bool callback_queued = false;
+};
+std::mutex g_def_mu;
+Deferred g_def;
+
+void flush_deferred() {
+  Deferred d;
+  {
+    std::lock_guard<std::mutex> lk(g_def_mu);
+    std::swap(d, g_def);
+  }
+  if (d.pending.empty()) return;
+  check(g_lib.bwd_finalize(d.pending.data(), static_cast<int32_t>(d.pending.size()),
+                           reinterpret_cast<void*>(d.stream)),
+        "adapter_bwd_finalize");
+  at::NoGradGuard no_grad;
+  for (auto& a : d.adds) a.param.mutable_grad().add_(a.grad);
+}
+
+// assigns (p.grad undefined: the tensor is filled by the deferred reduction) or schedules the add
+void deposit_grad(const at::Tensor& p, at::Tensor g, Deferred& d) {
+  if (!g.defined()) return;
+  d.keep.push_back(g);
+  if (!p.defined() || !p.requires_grad()) return;
   at::Tensor& cur = p.mutable_grad();
   if (!cur.defined()) cur = std::move(g);
-  else cur.add_(g);
+  else d.adds.push_back({p, std::move(g)});
 }
 
 struct AdapterFnDirect : public torch::autograd::Function<AdapterFnDirect> {
@@ -259,17 +305,37 @@ struct AdapterFnDirect : public torch::autograd::Function<AdapterFnDirect> {
     gconv_adapter_params_t p{fptr(pk->w_down), fptr(pk->b_down), fptr(pk->w_up), fptr(pk->b_up),
                              fptr(pk->scalar), static_cast<int32_t>(d), static_cast<int32_t>(r),
                              static_cast<int32_t>(act), skip ? 1 : 0};
-    check(g_lib.bwd(&g, &p, x.data_ptr<float>(), go.data_ptr<float>(), svp,
-                    act == GCONV_ACT_SILU ? svp + 2 * n * fp : nullptr, svp + n * fp,
-                    fptr_mut(gx), gwd.data_ptr<float>(), fptr_mut(gbd), gwu.data_ptr<float>(),
-                    fptr_mut(gbu), fptr_mut(gsc), ws.data_ptr(), static_cast<size_t>(ws_bwd),
-                    reinterpret_cast<void*>(stream)),
+    gconv_pending_finalize_t pend;
+    check(g_lib.bwd_partial(&g, &p, x.data_ptr<float>(), go.data_ptr<float>(), svp,
+                            act == GCONV_ACT_SILU ? svp + 2 * n * fp : nullptr, svp + n * fp,
+                            fptr_mut(gx), gwd.data_ptr<float>(), fptr_mut(gbd), gwu.data_ptr<float>(),
+                            fptr_mut(gbu), fptr_mut(gsc), ws.data_ptr(), static_cast<size_t>(ws_bwd),
+                            &pend, reinterpret_cast<void*>(stream)),
           "adapter_bwd");
-    deposit_grad(pk->w_down, std::move(gwd));
-    deposit_grad(pk->b_down, std::move(gbd));
-    deposit_grad(pk->w_up, std::move(gwu));
-    deposit_grad(pk->b_up, std::move(gbu));
-    deposit_grad(pk->scalar, std::move(gsc));
+    bool queue = false;
+    {
+      std::lock_guard<std::mutex> lk(g_def_mu);
+      if (!g_def.pending.empty() && g_def.stream != stream) {   // another stream: do not mix
+        Deferred other;
+        std::swap(other, g_def);
+        g_def.callback_queued = other.callback_queued;
+        check(g_lib.bwd_finalize(other.pending.data(), static_cast<int32_t>(other.pending.size()),
+                                 reinterpret_cast<void*>(other.stream)),
+              "adapter_bwd_finalize");
+        for (auto& a : other.adds) a.param.mutable_grad().add_(a.grad);
+      }
+      g_def.stream = stream;
+      g_def.pending.push_back(pend);
+      g_def.keep.push_back(ws);
+      deposit_grad(pk->w_down, std::move(gwd), g_def);
+      deposit_grad(pk->b_down, std::move(gbd), g_def);
+      deposit_grad(pk->w_up, std::move(gwu), g_def);
+      deposit_grad(pk->b_up, std::move(gbu), g_def);
+      deposit_grad(pk->scalar, std::move(gsc), g_def);
+      queue = !g_def.callback_queued;
+      g_def.callback_queued = true;
+    }
+    if (queue) torch::autograd::Engine::get_default_engine().queue_callback([] { flush_deferred(); });
     at::Tensor none;
     return {gx, none, none, none, none, none, none, none, none, none, none};
   }

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GCONV_ABI_VERSION 2
+#define GCONV_ABI_VERSION 3
 
 typedef int32_t gconv_status_t;
 typedef void*   gconv_stream_t; /* hipStream_t */
@@ -220,6 +220,33 @@ gconv_status_t gconv_adapter_bwd_f32(const gconv_graph_t* graph,
                                      float* grad_w_up, float* grad_b_up, float* grad_scalar,
                                      void* workspace, size_t workspace_bytes,
                                      gconv_stream_t stream);
+
+/* The same backward in two steps, for callers that run several adapters' backward passes
+ * before anyone reads the parameter gradients (one `loss.backward()` over a model with 5-10
+ * adapters): `..._bwd_partial_f32` does everything except the last kernel — grad_x is complete
+ * when it returns, the parameter gradients exist as per-workgroup partials in `workspace` — and
+ * describes that last reduction in `*pending` (a host-side POD: pointers into `workspace` and to
+ * the grad_* buffers, which must all stay alive and untouched until the reduction has run).
+ * `gconv_adapter_bwd_finalize_f32` then runs any number of pending reductions,
+ * GCONV_FINALIZE_BATCH per launch, on `stream` (the stream of the partial calls).
+ * bwd == bwd_partial + bwd_finalize(…, 1), bit for bit.                                      */
+#define GCONV_FINALIZE_BATCH 8
+typedef struct gconv_pending_finalize {
+  uint64_t opaque[24];
+} gconv_pending_finalize_t;
+
+gconv_status_t gconv_adapter_bwd_partial_f32(const gconv_graph_t* graph,
+                                             const gconv_adapter_params_t* params, const float* x,
+                                             const float* grad_out, const float* saved_h,
+                                             const float* saved_h1, const float* saved_p,
+                                             float* grad_x, float* grad_w_down, float* grad_b_down,
+                                             float* grad_w_up, float* grad_b_up, float* grad_scalar,
+                                             void* workspace, size_t workspace_bytes,
+                                             gconv_pending_finalize_t* pending,
+                                             gconv_stream_t stream);
+
+gconv_status_t gconv_adapter_bwd_finalize_f32(const gconv_pending_finalize_t* pending,
+                                              int32_t count, gconv_stream_t stream);
 
 #ifdef __cplusplus
 }

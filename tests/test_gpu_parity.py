@@ -403,6 +403,57 @@ def test_adapter_rejects_cpu_and_wrong_dtype(dev):
         ga.GConvAdapter(10, 2).to(dev)(torch.randn(2, 10, device=dev), ei.to(dev))  # d % 4 != 0
 
 
+@pytest.mark.parametrize("workload", ["esol", "cora"])
+def test_split_backward_with_batched_finalize_is_bit_identical(dev, workload):
+    """C ABI: gconv_adapter_bwd_partial_f32 x 3 + ONE gconv_adapter_bwd_finalize_f32 == three
+    gconv_adapter_bwd_f32 calls, bit for bit (fused tile path: esol; general path: cora)."""
+    import ctypes as C
+    lib = ga._lib.load()
+    batch, cfg = ga.synth.make_workload(workload)
+    d, r = cfg["d"], cfg["r"]
+    x = batch.x.reshape(-1, d).to(dev); ei = batch.edge_index.to(dev)
+    n = x.shape[0]
+    plan = ga.get_plan(ei, n, True)
+    fp, wsf, wsb = plan.sizes(lib, d, r)
+    st = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator().manual_seed(3)
+    results = {"whole": [], "split": []}
+    pend = (ga._lib.PendingFinalize * 3)()
+    keep = []
+    for mode in ("whole", "split"):
+        for k in range(3):
+            g = torch.Generator().manual_seed(10 + k)
+            wd = (torch.randn(r, d, generator=g) * .1).to(dev); bd = (torch.randn(r, generator=g) * .1).to(dev)
+            wu = (torch.randn(d, r, generator=g) * .1).to(dev); bu = (torch.randn(d, generator=g) * .1).to(dev)
+            sc = torch.full((1,), 0.7 + 0.1 * k, device=dev)
+            go = torch.randn(n, d, generator=g).to(dev)
+            P = ga._lib.AdapterParams(wd.data_ptr(), bd.data_ptr(), wu.data_ptr(), bu.data_ptr(), sc.data_ptr(),
+                                      d, r, 1, 1)
+            out = torch.empty_like(x); saved = torch.empty(2, n, fp, device=dev)
+            wF = torch.empty(wsf, dtype=torch.uint8, device=dev); wB = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            ga._lib.check(lib.gconv_adapter_fwd_f32(plan.ref(), C.byref(P), x.data_ptr(), out.data_ptr(),
+                                                    saved[0].data_ptr(), None, saved[1].data_ptr(),
+                                                    wF.data_ptr(), wsf, st), "fwd")
+            gx = torch.empty_like(x)
+            gp = [torch.empty_like(t) for t in (wd, bd, wu, bu, sc)]
+            args = (plan.ref(), C.byref(P), x.data_ptr(), go.data_ptr(), saved[0].data_ptr(), None,
+                    saved[1].data_ptr(), gx.data_ptr(), gp[0].data_ptr(), gp[1].data_ptr(), gp[2].data_ptr(),
+                    gp[3].data_ptr(), gp[4].data_ptr(), wB.data_ptr(), wsb)
+            if mode == "whole":
+                ga._lib.check(lib.gconv_adapter_bwd_f32(*args, st), "bwd")
+            else:
+                ga._lib.check(lib.gconv_adapter_bwd_partial_f32(*args, C.byref(pend[k]), st), "bwd_partial")
+            keep.append((wd, bd, wu, bu, sc, go, saved, wB, P))
+            results[mode].append([gx] + gp)
+    ga._lib.check(lib.gconv_adapter_bwd_finalize_f32(pend, 3, st), "bwd_finalize")
+    torch.cuda.synchronize()
+    for a, b in zip(results["whole"], results["split"]):
+        for ta, tb in zip(a, b):
+            assert torch.equal(ta, tb)
+    assert lib.gconv_adapter_bwd_finalize_f32(None, 0, st) == 0
+    assert lib.gconv_adapter_bwd_finalize_f32(None, 2, st) == -1     # GCONV_E_INVALID_ARG
+
+
 def test_direct_param_grad_deposit_equals_autograd_accumulation(dev):
     """C++ binding, two ways of storing the parameter gradients — written into p.grad by the
     node itself (default) or returned to AccumulateGrad nodes: bit-identical results; a second
