@@ -307,6 +307,10 @@ __global__ __launch_bounds__(FP >= 32 ? 512 : 640) void tile_fwd_kernel(TileFwdA
   }
   f32x4 bu = zero4f();
   if (a.b_up) { const f32x4 bv = ldg4(a.b_up + colc); bu = colvalid ? bv : zero4f(); }
+  f32x4 bdv = zero4f();   // this lane group's 4 entries of b_down (phase 2)
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (a.b_down && 4 * sub + k < a.r) bdv[k] = a.b_down[4 * sub + k];
   __syncthreads();
 
   TILE_STAMP(0);
@@ -356,12 +360,7 @@ __global__ __launch_bounds__(FP >= 32 ? 512 : 640) void tile_fwd_kernel(TileFwdA
 
     // ---- phase 2: H2' -> bufB (+ saved_h, saved_h1)
     for (int lr = grp; lr < nt; lr += ngrp) {
-      f32x4 v = tile_row_sum<FP, NORM>(bufA, rp, cl, dl, lr, sub);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int c = 4 * sub + k;
-        if (a.b_down && c < a.r) v[k] += a.b_down[c];
-      }
+      f32x4 v = tile_row_sum<FP, NORM>(bufA, rp, cl, dl, lr, sub) + bdv;
       const size_t off = static_cast<size_t>(ts + lr) * FP + 4 * sub;
       if (a.act == GCONV_ACT_SILU) stg4(a.saved_h1 + off, v);
 #pragma unroll
@@ -519,6 +518,9 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
     // (the tile's CSR slice and its P rows land in LDS meanwhile)
     TileCsrStage<NORM> csr{a.rowptr, a.col, a.dis, rp, cl, dl, ts, nt};
     csr.request();
+    // phase 2's saved activation of this lane group's first row, requested a phase early
+    const float* hsel = a.act == GCONV_ACT_SILU ? a.saved_h1 : a.saved_h;
+    const f32x4 hfirst = ldg4(hsel + static_cast<size_t>(ts + min(grp, nt - 1)) * FP + 4 * sub);
     const int np4 = nt * LPR;  // the P tile: np4 float4, the first blockDim of them via registers
     const f32x4 pfirst =
         ldg4(a.saved_p + static_cast<size_t>(ts) * FP + 4 * min(static_cast<int>(threadIdx.x), np4 - 1));
@@ -551,15 +553,14 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
     // ---- phase 2: dH1' = dis . (S^T dP . act') -> bufB ; bias gradient
     for (int lr = grp; lr < nt; lr += ngrp) {
       f32x4 v = tile_row_sum<FP, NORM>(bufA, rp, cl, dl, lr, sub);
-      const size_t off = static_cast<size_t>(ts + lr) * FP + 4 * sub;
+      f32x4 hv = hfirst;
+      if (lr != grp) hv = ldg4(hsel + static_cast<size_t>(ts + lr) * FP + 4 * sub);   // tiles > 256 rows
       if (a.act == GCONV_ACT_RELU) {
-        const f32x4 h2 = ldg4(a.saved_h + off);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = h2[k] > 0.f ? v[k] : 0.f;
+        for (int k = 0; k < 4; ++k) v[k] = hv[k] > 0.f ? v[k] : 0.f;
       } else if (a.act == GCONV_ACT_SILU) {
-        const f32x4 h1 = ldg4(a.saved_h1 + off);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] *= silu_grad(h1[k]);
+        for (int k = 0; k < 4; ++k) v[k] *= silu_grad(hv[k]);
       }
       bgrad += v;
       if (NORM) v *= dl[lr];
