@@ -32,8 +32,8 @@
 // Diagnostic build (-DGCONV_TILE_STAMPS): per-workgroup phase time stamps (100 MHz wall clock)
 // into a side buffer that nothing else reads; never compiled into the product library.
 #ifdef GCONV_TILE_STAMPS
-#define TILE_STAMP(k) do { if (threadIdx.x == 0) a.stamps[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
-#define TILE_STAMP_NT(v) do { if (threadIdx.x == 0) a.stamps[blockIdx.x * 8 + 7] = (v); } while (0)
+#define TILE_STAMP(k) do { if (threadIdx.x == 0) a.stamps[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#define TILE_STAMP_NT(v) do { if (threadIdx.x == 0) a.stamps[blockIdx.x * 16 + 7] = (v); } while (0)
 #else
 #define TILE_STAMP(k)
 #define TILE_STAMP_NT(v)
@@ -68,19 +68,46 @@ __device__ __forceinline__ void lds_rank_frag(const float* Z, int row, int t, bo
   }
 }
 
-// Stage Wt(k, c) (k < d, c < r) into MFMA fragment order [NQ][NCB][64] float4.
-template <int NCB, int NQ>
-__device__ __forceinline__ void stage_weights(f32x4* wl, const float* __restrict__ W, int d, int r,
-                                              bool down) {
-  float* wlf = reinterpret_cast<float*>(wl);
-  constexpr int kpad = NQ * 16, cpad = NCB * 16;
-  for (int idx = threadIdx.x; idx < kpad * cpad; idx += blockDim.x) {
-    int k, c;
-    if (down) { c = idx / kpad; k = idx % kpad; } else { k = idx / cpad; c = idx % cpad; }
-    float v = 0.f;
-    if (k < d && c < r) v = down ? W[static_cast<size_t>(c) * d + k] : W[static_cast<size_t>(k) * r + c];
-    const int q = k >> 4, kq = (k >> 2) & 3, t = k & 3, cb = c >> 4, ln = (c & 15) + 16 * kq;
-    wlf[((q * NCB + cb) * 64 + ln) * 4 + t] = v;
+// Keeps a loaded value opaque to the optimiser. `cond ? loaded : 0` is otherwise turned back
+// into a branch around the load (one exec-masked load + vmcnt(0) per value: the kernel
+// prologues were chains of 17 serialized L2 round trips, ~4 us per launch).
+__device__ __forceinline__ float keep(float v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ f32x4 keep(f32x4 v) { asm volatile("" : "+v"(v)); return v; }
+
+// Stage Wt(k, c) (k < d, c < r) into MFMA fragment order [NQ][NCB][64] float4: element
+// (k = 16 q + 4 kq + t, c = 16 cb + n) sits at float ((q * NCB + cb) * 64 + n + 16 kq) * 4 + t,
+// so the 4 consecutive k of one (c, k / 4) group are one 16-byte LDS word. Groups are handled
+// kStageBatch at a time per thread, all requests of a batch in flight before the first write.
+//   DOWN: Wt(k, c) = W_down[c][k]  (a group is one aligned float4 of a W_down row)
+//   else: Wt(k, c) = W_up[k][c]    (a group is 4 scalars, stride r)
+constexpr int kStageBatch = 4;
+template <int NCB, int NQ, bool DOWN>
+__device__ __forceinline__ void stage_weights(f32x4* wl, const float* __restrict__ W, int d, int r) {
+  constexpr int kgroups = NQ * 4, cpad = NCB * 16, total = kgroups * cpad;
+  const int stride = blockDim.x;
+  for (int base = threadIdx.x; base < total; base += kStageBatch * stride) {
+    f32x4 v[kStageBatch];
+#pragma unroll
+    for (int u = 0; u < kStageBatch; ++u) {
+      const int g = min(base + u * stride, total - 1);
+      const int c = g / kgroups, k4 = g % kgroups;
+      const int cc = min(c, r - 1), kk = min(4 * k4, d - 4);
+      if (DOWN) {
+        v[u] = ldg4(W + static_cast<size_t>(cc) * d + kk);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[u][t] = W[static_cast<size_t>(kk + t) * r + cc];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kStageBatch; ++u) {
+      const int g = base + u * stride;
+      const int c = g / kgroups, k4 = g % kgroups;
+      const bool ok = c < r && 4 * k4 < d;
+      const f32x4 val = keep(v[u]);
+      const int q = k4 >> 2, kq = k4 & 3, cb = c >> 4, ln = (c & 15) + 16 * kq;
+      if (g < total) wl[(q * NCB + cb) * 64 + ln] = ok ? val : zero4f();
+    }
   }
 }
 
@@ -265,11 +292,12 @@ struct TileCsrStage {
 // forward — persistent workgroups walk the tiles (weights staged / loaded once)
 // ===========================================================================
 template <int FP, int NQ, bool NORM>
-__global__ __launch_bounds__(FP >= 32 ? 512 : 640) void tile_fwd_kernel(TileFwdArgs a) {
+__global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_kernel(TileFwdArgs a) {
   extern __shared__ f32x4 lds4[];
   constexpr int NCB = FP >= 16 ? FP / 16 : 1;
   constexpr int KS = FP / 4;
   constexpr int LPR = FP / 4;
+  TILE_STAMP(8);
   f32x4* wl = lds4;                                              // [NQ][NCB][64]
   float* bufA = reinterpret_cast<float*>(lds4 + NQ * NCB * 64);  // [cap][FP]  H0', later P
   float* bufB = bufA + a.cap * FP;                               // [cap][FP]  H2'
@@ -282,9 +310,13 @@ __global__ __launch_bounds__(FP >= 32 ? 512 : 640) void tile_fwd_kernel(TileFwdA
   const int nwaves = blockDim.x >> 6;
   const int jj = lane & 15, t = lane >> 4;
   const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR, ngrp = blockDim.x / LPR;
-  const float sval = a.scalar ? a.scalar[0] : 1.f;
 
-  stage_weights<NCB, NQ>(wl, a.w_down, a.d, a.r, true);
+  // Every first-touch load of a launch misses L2 (the previous kernel streamed 30+ MB through
+  // it): the prologue requests ALL of them back to back — register fragments, scalar, the first
+  // tile's span — and only then stages the LDS weights, so it pays one cold round trip, not four.
+  TILE_STAMP(9);
+  const float sraw = (a.scalar ? a.scalar : a.w_down)[0];
+  const int2 span0 = reinterpret_cast<const int2*>(a.tile_order)[blockIdx.x];   // grid <= n_tiles
 
   // phase-4 ownership: a wave owns ONE 64-column chunk (W_up fragments in registers) and
   // every nslots-th node block of a tile (nchunks <= nwaves is guaranteed by the launcher)
@@ -295,33 +327,48 @@ __global__ __launch_bounds__(FP >= 32 ? 512 : 640) void tile_fwd_kernel(TileFwdA
   const int colbase = 64 * J + 4 * jj;
   const bool colvalid = colbase < a.d;
   const int colc = min(colbase, a.d - 4);
+  // all requests first, the selects (behind keep()) afterwards: one round trip, not one each
   float wb[KS][4];
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     const int k = rank_k_<FP>(s, t);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float w = a.w_up[static_cast<size_t>(colc + c) * a.r + min(k, a.r - 1)];
-      wb[s][c] = (colvalid && k < a.r) ? w : 0.f;
-    }
+    for (int c = 0; c < 4; ++c) wb[s][c] = a.w_up[static_cast<size_t>(colc + c) * a.r + min(k, a.r - 1)];
   }
-  f32x4 bu = zero4f();
-  if (a.b_up) { const f32x4 bv = ldg4(a.b_up + colc); bu = colvalid ? bv : zero4f(); }
-  f32x4 bdv = zero4f();   // this lane group's 4 entries of b_down (phase 2)
+  f32x4 bu = ldg4((a.b_up ? a.b_up : a.w_down) + colc);          // (any readable address if absent)
+  f32x4 bdv;                                                      // b_down entries of this lane group
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (a.b_down && 4 * sub + k < a.r) bdv[k] = a.b_down[4 * sub + k];
+  for (int k = 0; k < 4; ++k) bdv[k] = (a.b_down ? a.b_down : a.w_down)[min(4 * sub + k, a.r - 1)];
+  TILE_STAMP(10);
+  stage_weights<NCB, NQ, true>(wl, a.w_down, a.d, a.r);
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int k = rank_k_<FP>(s, t);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wb[s][c] = (colvalid && k < a.r) ? keep(wb[s][c]) : 0.f;
+  }
+  bu = (a.b_up && colvalid) ? keep(bu) : zero4f();
+  bdv = keep(bdv);
+  const float sval = a.scalar ? keep(sraw) : 1.f;
+  TILE_STAMP(11);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) bdv[k] = (a.b_down && 4 * sub + k < a.r) ? bdv[k] : 0.f;
   __syncthreads();
 
   TILE_STAMP(0);
   // tiles are dealt from the size-sorted list boustrophedon: pass 0 gives workgroup w the
   // w-th largest tile, pass 1 the (2 G - 1 - w)-th, ... — the big tiles end up alone
+  int2 span = span0;
   for (int pass = 0;; ++pass) {
     const int G = gridDim.x;
     const int idx = (pass & 1) ? (pass + 1) * G - 1 - static_cast<int>(blockIdx.x) : pass * G + static_cast<int>(blockIdx.x);
     if (idx >= a.n_tiles) break;
-    const int tile = uniform(a.tile_order[idx]);
-    const int ts = uniform(a.tile_ptr[tile]), nt = uniform(a.tile_ptr[tile + 1]) - ts;
+    const int ts = uniform(span.x), nt = uniform(span.y);   // (first node, count) of this pass
+    {   // the next pass's span is requested now (clamped index: always a valid entry)
+      const int nidx = ((pass + 1) & 1) ? (pass + 2) * G - 1 - static_cast<int>(blockIdx.x)
+                                        : (pass + 1) * G + static_cast<int>(blockIdx.x);
+      span = reinterpret_cast<const int2*>(a.tile_order)[min(nidx, a.n_tiles - 1)];
+    }
     if (nt <= 0) continue;  // uniform
     TILE_STAMP_NT(nt);
     TILE_STAMP(1);
@@ -431,6 +478,7 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
   constexpr int NCB = FP >= 16 ? FP / 16 : 1;
   constexpr int KS = FP / 4;
   constexpr int LPR = FP / 4;
+  TILE_STAMP(8);
   f32x4* wl = lds4;                                              // [NQ][NCB][64]  W_up^T frags
   float* bufA = reinterpret_cast<float*>(lds4 + NQ * NCB * 64);  // [cap][FP]  dP', later T
   float* bufB = bufA + a.cap * FP;                               // [cap][FP]  dH1'
@@ -443,12 +491,12 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
   const int lane = threadIdx.x & 63, wave = wave_id();
   const int nwaves = blockDim.x >> 6;
   const int pid = blockIdx.x;
-  const float sval = a.scalar ? a.scalar[0] : 1.f;
+  // (prologue: all first-touch requests back to back, LDS staging after them — see forward)
+  const float sraw = (a.scalar ? a.scalar : a.w_down)[0];
+  const int2 span0 = reinterpret_cast<const int2*>(a.tile_order)[blockIdx.x];   // grid <= n_tiles
   const int nchunks = ceil_div(a.d, 64);
   const int jj = lane & 15, t = lane >> 4;
   const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR, ngrp = blockDim.x / LPR;
-
-  stage_weights<NCB, NQ>(wl, a.w_up, a.d, a.r, false);
 
   // phase-4 ownership: wave J < nchunks is the primary owner of 64-column chunk J (its dW
   // accumulators live in that wave's registers for the whole kernel). Up to kExtra of the
@@ -469,11 +517,19 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
   const bool colvalid = owner && colbase < a.d;
   const int colc = min(colbase, a.d - 4);
   float wd[NEED_DX ? KS : 1][4];
+  f32x4 raw[NEED_DX ? KS : 1];
+  if constexpr (NEED_DX) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      raw[s] = ldg4(a.w_down + static_cast<size_t>(min(rank_k_<FP>(s, t), a.r - 1)) * a.d + colc);
+  }
+  stage_weights<NCB, NQ, false>(wl, a.w_up, a.d, a.r);
+  const float sval = a.scalar ? keep(sraw) : 1.f;
   if constexpr (NEED_DX) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int k = rank_k_<FP>(s, t);
-      const f32x4 v = ldg4(a.w_down + static_cast<size_t>(min(k, a.r - 1)) * a.d + colc);
+      const f32x4 v = keep(raw[s]);
 #pragma unroll
       for (int c = 0; c < 4; ++c) wd[s][c] = (colvalid && k < a.r) ? v[c] : 0.f;
     }
@@ -490,12 +546,17 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
   TILE_STAMP(0);
   // tiles are dealt from the size-sorted list boustrophedon: pass 0 gives workgroup w the
   // w-th largest tile, pass 1 the (2 G - 1 - w)-th, ... — the big tiles end up alone
+  int2 span = span0;
   for (int pass = 0;; ++pass) {
     const int G = gridDim.x;
     const int idx = (pass & 1) ? (pass + 1) * G - 1 - static_cast<int>(blockIdx.x) : pass * G + static_cast<int>(blockIdx.x);
     if (idx >= a.n_tiles) break;
-    const int tile = uniform(a.tile_order[idx]);
-    const int ts = uniform(a.tile_ptr[tile]), nt = uniform(a.tile_ptr[tile + 1]) - ts;
+    const int ts = uniform(span.x), nt = uniform(span.y);   // (first node, count) of this pass
+    {   // the next pass's span is requested now (clamped index: always a valid entry)
+      const int nidx = ((pass + 1) & 1) ? (pass + 2) * G - 1 - static_cast<int>(blockIdx.x)
+                                        : (pass + 1) * G + static_cast<int>(blockIdx.x);
+      span = reinterpret_cast<const int2*>(a.tile_order)[min(nidx, a.n_tiles - 1)];
+    }
     if (nt <= 0) continue;  // uniform
     TILE_STAMP_NT(nt);
     TILE_STAMP(1);
@@ -757,10 +818,11 @@ static int tile_nq(int d) {
 // Workgroup shapes. One workgroup per CU, walking its tiles; a tile's time is a chain of
 // memory latencies, so a workgroup carries as many waves as its registers allow:
 //   forward   nchunks * nslots waves (a wave owns a 64-column chunk and every nslots-th node
-//             block in phase 4), up to 12 (8 for rank 17..32, whose kernel needs more VGPRs)
+//             block in phase 4), up to 10 (8 for rank 17..32 and for d > 304, whose kernels
+//             need more VGPRs)
 //   backward  8 waves (the dW accumulators pin a chunk to one wave: nchunks owner waves)
 static int tile_threads_fwd(int d, int fp) {
-  const int nchunks = ceil_div(d, 64), cap = fp >= 32 ? 8 : 10;
+  const int nchunks = ceil_div(d, 64), cap = (fp >= 32 || tile_nq(d) > 19) ? 8 : 10;
   int nslots = cap / nchunks;
   if (nslots < 1) nslots = 1;
   int w = nchunks * nslots;

@@ -163,14 +163,16 @@ __global__ void tile_start_kernel(const int32_t* __restrict__ span_ps, int32_t n
 __global__ void tile_max_kernel(const int32_t* __restrict__ tile_ptr,
                                 const int32_t* __restrict__ rowptr, int ntiles,
                                 int32_t* __restrict__ info, uint32_t* __restrict__ size_key,
-                                int32_t* __restrict__ tile_id) {
+                                uint64_t* __restrict__ tile_span) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   int sz = 0, ed = 0;
   if (t < ntiles) {
     sz = tile_ptr[t + 1] - tile_ptr[t];
     ed = rowptr[tile_ptr[t + 1]] - rowptr[tile_ptr[t]];
     size_key[t] = static_cast<uint32_t>(kTileSizeMax - min(sz, kTileSizeMax));
-    tile_id[t] = t;
+    // (first node, node count) as one 64-bit sort value: low word = first node
+    tile_span[t] = static_cast<uint64_t>(static_cast<uint32_t>(tile_ptr[t])) |
+                   (static_cast<uint64_t>(static_cast<uint32_t>(sz)) << 32);
   }
   for (int off = 32; off > 0; off >>= 1) {
     sz = max(sz, __shfl_xor(sz, off));
@@ -209,8 +211,8 @@ static size_t cub_bytes_for(int64_t E, int32_t n) {
                                    static_cast<int32_t*>(nullptr), n + 2, nullptr);
   size_t st = 0;
   hipcub::DeviceRadixSort::SortPairs(nullptr, st, static_cast<const uint32_t*>(nullptr),
-                                     static_cast<uint32_t*>(nullptr), static_cast<const int32_t*>(nullptr),
-                                     static_cast<int32_t*>(nullptr), ceil_div(n > 0 ? n : 1, GCONV_TILE_NODES),
+                                     static_cast<uint32_t*>(nullptr), static_cast<const uint64_t*>(nullptr),
+                                     static_cast<uint64_t*>(nullptr), ceil_div(n > 0 ? n : 1, GCONV_TILE_NODES),
                                      0, kTileSizeBits, nullptr);
   size_t m = s64 > s32 ? s64 : s32;
   m = m > sc ? m : sc;
@@ -234,10 +236,10 @@ static BuildLayout build_layout(int64_t E, int32_t n) {
   L.ntiles = ceil_div(n > 0 ? n : 1, GCONV_TILE_NODES);
   L.dis = take((static_cast<size_t>(n) + 1) * 4);
   L.tile_ptr = take((static_cast<size_t>(L.ntiles) + 1) * 4);
-  L.tile_order = take(static_cast<size_t>(L.ntiles) * 4);
+  L.tile_order = take(static_cast<size_t>(L.ntiles) * 8);
   L.tile_key = take(static_cast<size_t>(L.ntiles) * 4);
   L.tile_key_out = take(static_cast<size_t>(L.ntiles) * 4);
-  L.tile_id = take(static_cast<size_t>(L.ntiles) * 4);
+  L.tile_id = take(static_cast<size_t>(L.ntiles) * 8);
   L.span = take((static_cast<size_t>(n) + 2) * 4);
   L.span_ps = take((static_cast<size_t>(n) + 2) * 4);
   L.keys_a = take(e1 * 8);
@@ -347,7 +349,7 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
     GCONV_LAUNCH_CHECK();
     tile_max_kernel<<<(L.ntiles + T - 1) / T, T, 0, stream>>>(
         tile_ptr, of.rowptr, L.ntiles, info, reinterpret_cast<uint32_t*>(arena + L.tile_key),
-        reinterpret_cast<int32_t*>(arena + L.tile_id));
+        reinterpret_cast<uint64_t*>(arena + L.tile_id));
     GCONV_LAUNCH_CHECK();
   }
   int32_t h[64];
@@ -385,8 +387,8 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
     size_t cub_bytes = L.cub_bytes;
     GCONV_HIP(hipcub::DeviceRadixSort::SortPairs(
         arena + L.cub, cub_bytes, reinterpret_cast<const uint32_t*>(arena + L.tile_key),
-        reinterpret_cast<uint32_t*>(arena + L.tile_key_out), reinterpret_cast<const int32_t*>(arena + L.tile_id),
-        reinterpret_cast<int32_t*>(arena + L.tile_order), L.ntiles, 0, kTileSizeBits, stream));
+        reinterpret_cast<uint32_t*>(arena + L.tile_key_out), reinterpret_cast<const uint64_t*>(arena + L.tile_id),
+        reinterpret_cast<uint64_t*>(arena + L.tile_order), L.ntiles, 0, kTileSizeBits, stream));
   }
   g->tile_nodes_max = h[INFO_TILEMAX];
   g->tile_edges_max = h[INFO_TILEEDGES];

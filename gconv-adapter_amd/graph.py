@@ -131,7 +131,8 @@ class GraphPlan:
 
     @property
     def tile_order(self) -> torch.Tensor:
-        return self.arena_view(self.struct.tile_order, self.n_tiles, torch.int32)
+        """``[n_tiles, 2]`` (first node, node count), largest tile first."""
+        return self.arena_view(self.struct.tile_order, 2 * self.n_tiles, torch.int32).view(-1, 2)
 
     @property
     def dis_ptr(self) -> Optional[int]:

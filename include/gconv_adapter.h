@@ -105,7 +105,8 @@ typedef struct gconv_graph {
   gconv_csr_t    bwd;            /* rows = sources: S^T (a copy of `fwd` if symmetric)  */
   const float*   dis;            /* [num_nodes] (in-degree + 1)^-1/2; NULL if !normalize */
   const int32_t* tile_ptr;       /* [n_tiles + 1] node offsets of the component tiles   */
-  const int32_t* tile_order;     /* [n_tiles] tile ids, largest tile first (stable): the
+  const int32_t* tile_order;     /* [n_tiles][2] (first node, node count) of every tile, largest
+                                  * tile first (stable sort; 8-byte aligned): the
                                   * persistent workgroups deal themselves tiles from this
                                   * list boustrophedon, big ones first, so that no
                                   * workgroup ends up with two big tiles               */

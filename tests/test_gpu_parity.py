@@ -92,10 +92,11 @@ def test_graph_build_component_tiles(dev):
     for t, q in enumerate(tp[:-1]):
         assert q in gptr and q <= t * ga._lib.TILE_NODES
         assert gptr[gptr <= t * ga._lib.TILE_NODES].max() == q
-    # tile_order: every tile once, largest first, ties in tile order (stable sort)
+    # tile_order: (first node, node count) of every tile once, largest first, ties in tile
+    # order (stable sort)
     order = plan.tile_order.cpu().numpy()
     want = np.argsort(-np.diff(tp), kind="stable")
-    assert (order == want).all()
+    assert (order[:, 0] == tp[:-1][want]).all() and (order[:, 1] == np.diff(tp)[want]).all()
     # no edge crosses a tile boundary
     ei = batch.edge_index.numpy()
     tile_of = np.searchsorted(tp, np.arange(n), side="right") - 1

@@ -35,12 +35,17 @@ for _ in range(4):
                               gp[0].data_ptr(), gp[1].data_ptr(), gp[2].data_ptr(), gp[3].data_ptr(), gp[4].data_ptr(), wsB.data_ptr(), wsb, st)
 torch.cuda.synchronize()
 grid = min(plan.n_tiles, 256)
+ENTRY = {}
 def show(tag, ws, off):
-    st = ws[off:off + grid * 64].view(torch.int64).cpu().numpy().reshape(-1, 8)
+    st = ws[off:off + grid * 128].view(torch.int64).cpu().numpy().reshape(-1, 16)
     t0 = st[:, 0].min(); nt = st[:, 7]
     last = 6 if tag == "bwd" else 5
     print(f"{tag}: tiles {plan.n_tiles} grid {grid} max nodes {nt.max()} span {(st[:, last].max() - t0) / 100.0:.1f} us; starts: "
           f"{np.percentile((st[:,0]-t0)/100.0,[0,50,90,100]).round(1)}")
+    print(f"     kernel entry -> first tile: {np.percentile((st[:,0]-st[:,8])/100.0,[0,50,100]).round(1)} us; first entry at {(st[:,8].min()-t0)/100.0:.1f}, "
+          f"last end at {(st[:, last].max()-t0)/100.0:.1f} (relative to the first workgroup's stamp 0)")
+    ENTRY[tag] = (st[:, 8].min(), st[:, last].max())
+    if tag == "fwd": print("     prologue pieces (median us): entry->9 %.2f, stage_weights %.2f, fragment loads %.2f, barrier->0 %.2f" % tuple(np.median((st[:, b] - st[:, a]) / 100.0) for a, b in ((8, 9), (9, 10), (10, 11), (11, 0))))
     print("     nt | start | setup  ph1   ph2   ph3   ph4  " + ("tail" if tag == "bwd" else ""))
     order = np.argsort(-nt)
     for i in list(order[:4]) + list(order[len(order) // 2: len(order) // 2 + 3]):
@@ -49,3 +54,5 @@ def show(tag, ws, off):
 show("fwd", wsF, 0)
 tw = wsb - (1 << 20)
 show("bwd", wsB, tw)
+
+print("kernel boundary: forward's last stamp -> backward's first entry: %.1f us" % ((ENTRY["bwd"][0] - ENTRY["fwd"][1]) / 100.0))
