@@ -69,8 +69,24 @@ __device__ __forceinline__ f32x4 buf_ld4(rsrc_t r, int byte_off) {
   const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
   return __builtin_bit_cast(f32x4, v);
 }
+// Cache policy of the streamed-once accesses of the tile kernels (aux bit 1 = nt): the output
+// rows (out, dX) are written once and never re-read by the kernel; written with the default
+// policy they push the rows that ARE re-read (X between phases 1 and 4, G likewise) and the
+// small hot arrays out of L2. nt stores: HIV-512 forward 17.2 -> 16.0 us, HIV-4096 backward
+// 129 -> 114 us.
+#ifndef GCONV_STORE_AUX
+#define GCONV_STORE_AUX 2
+#endif
+// (nt on the rows' final READS was tried as well — backward 32.9 -> 36.4 us — and stays off)
+#ifndef GCONV_LAST_USE_LOAD_AUX
+#define GCONV_LAST_USE_LOAD_AUX 0
+#endif
+__device__ __forceinline__ f32x4 buf_ld4_last(rsrc_t r, int byte_off) {   // a row's final read
+  const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, GCONV_LAST_USE_LOAD_AUX);
+  return __builtin_bit_cast(f32x4, v);
+}
 __device__ __forceinline__ void buf_st4(rsrc_t r, int byte_off, f32x4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), r, byte_off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), r, byte_off, 0, GCONV_STORE_AUX);
 }
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 

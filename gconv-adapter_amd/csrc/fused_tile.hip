@@ -399,7 +399,7 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
     const int nb4 = ceil_div(nt, 16);
     auto load_x = [&](int blk, f32x4 (&xq)[4]) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m) xq[m] = buf_ld4(rx, voff4 + (16 * blk + m) * rowb);
+      for (int m = 0; m < 4; ++m) xq[m] = buf_ld4_last(rx, voff4 + (16 * blk + m) * rowb);
     };
     f32x4 xa[4], xb[4];
     load_x(slot, xa);
@@ -602,8 +602,8 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int off = voff4 + (16 * blk + m) * rowb;
-        gq[m] = buf_ld4(rg, off);
-        xq[m] = buf_ld4(rx, off);
+        gq[m] = buf_ld4_last(rg, off);
+        xq[m] = buf_ld4_last(rx, off);
       }
     };
     constexpr bool DEEP = FP < 32;  // rank 17..32: no registers left for the second pair
