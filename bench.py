@@ -263,6 +263,35 @@ def measure_arxiv(device, iters: int = 50, banded_control: bool = False) -> dict
     return {"roofline": roof, "extra": extra}
 
 
+def measure_tile_kernels(device, name: str = "hiv4096") -> dict:
+    """Device time of ONE adapter forward / backward on the whole 4096-molecule batch of
+    configs[2] resident on one GPU (fused tile kernels through the module, HIP events), at
+    algorithmic bytes: what the kernels sustain when a workgroup has a dozen tiles
+    to walk instead of one or two (the 512-molecule shard is bounded by its largest tile)."""
+    batch, cfg = ga.synth.make_workload(name)
+    n, d, r = batch.num_nodes, cfg["d"], cfg["r"]
+    ei = batch.edge_index.to(device)
+    plan = ga.get_plan(ei, n, True)
+    mod = build_adapters(dict(d=d, r=r, adapters=1), True, device)[0]
+    x = batch.x.to(device).requires_grad_(True)
+    gout = torch.randn(n, d, device=device)
+    out = mod(x, ei)
+    fwd_ms = event_time_ms(lambda: mod(x, ei), 30)
+    leaves = [x] + list(mod.parameters())
+
+    def bwd():
+        for q in leaves:
+            q.grad = None
+        out.backward(gout, retain_graph=True)
+    bwd_ms = event_time_ms(bwd, 30)
+    fb, bb = adapter_algorithmic_bytes(n, plan.fwd.nnz, d, r)
+    ga.PLAN_CACHE.clear()
+    return {f"{name}_adapter_fwd_us": round(fwd_ms * 1e3, 1), f"{name}_adapter_bwd_us": round(bwd_ms * 1e3, 1),
+            f"{name}_adapter_fwd_GBs": round(fb / (fwd_ms * 1e-3) / 1e9, 1),
+            f"{name}_adapter_bwd_GBs": round(bb / (bwd_ms * 1e-3) / 1e9, 1),
+            f"{name}_adapter_frac_of_hbm_peak": round((fb + bb) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)}
+
+
 def measure_banded(device, r: int, flags: int, lib) -> dict:
     """Control (`--banded`): the SAME SpMM kernel on a graph of the same average degree whose
     neighbours are local (banded, 1 M nodes): how close it gets to HBM when gathers hit L2.
@@ -440,6 +469,7 @@ def main() -> None:
             ax = measure_arxiv(device, banded_control=args.banded)
             line["roofline"] = ax["roofline"]
             extra.update(ax["extra"])
+            extra.update(measure_tile_kernels(device))
             other = "esol" if args.workload != "esol" else "hiv"
             o = run_workload(other, normalize, max(20, args.steps // 2), args.warmup, rank, world,
                              device, with_cpu=not args.no_cpu_baseline)
