@@ -100,8 +100,9 @@ __device__ __forceinline__ void block_bias_partial(f32x4 bias_grad, float* part_
 }
 
 // ---------------------------------------------------------------------------
-// Row kernel: blocks [0, row_blocks) walk rows, blocks [row_blocks, grid) reduce
-// long-row segments (one wave per segment).
+// Row kernel: blocks [0, seg_blocks) reduce long-row segments (one wave per segment; they
+// carry the longest dependent-load chain, so they are dispatched FIRST and run under the row
+// blocks instead of forming the tail of the launch), blocks [seg_blocks, grid) walk rows.
 // ---------------------------------------------------------------------------
 template <int F, bool NORM, int EPI>
 __global__ __launch_bounds__(256) void spmm_rows_kernel(SpmmArgs a) {
@@ -113,9 +114,10 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(SpmmArgs a) {
   const float* __restrict__ H = a.H;
   const int32_t* __restrict__ col = a.col;
 
-  if (static_cast<int>(blockIdx.x) >= a.row_blocks) {
+  const int seg_blocks = (a.n_seg + 3) >> 2;
+  if (static_cast<int>(blockIdx.x) < seg_blocks) {
     // ---- long-row segment: the 64/LPR lane groups stride over the segment's edges
-    const int s = (blockIdx.x - a.row_blocks) * 4 + wave;
+    const int s = blockIdx.x * 4 + wave;
     if (s >= a.n_seg) return;
     const int lr = a.seg_long[s];
     const int row = a.long_rows[lr];
@@ -139,7 +141,8 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(SpmmArgs a) {
   }
 
   f32x4 bias_grad = zero4();
-  const int row = (blockIdx.x * 4 + wave) * RPW + grp;
+  const int rblock = blockIdx.x - seg_blocks;
+  const int row = (rblock * 4 + wave) * RPW + grp;
   const int rowc = min(row, a.n - 1);
   const int e0 = a.rowptr[rowc], e1 = a.rowptr[rowc + 1];
   const bool mine = row < a.n && (e1 - e0) <= GCONV_LONG_ROW;  // long rows: segment path
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(SpmmArgs a) {
     acc1 += (h[4] + h[5]) + (h[6] + h[7]);
   }
   if (mine) spmm_epilogue<F, NORM, EPI>(a, row, sub, acc0 + acc1, bias_grad);
-  if (EPI == EPI_BWD1) block_bias_partial<F>(bias_grad, a.bias_partial + static_cast<size_t>(blockIdx.x) * F);
+  if (EPI == EPI_BWD1) block_bias_partial<F>(bias_grad, a.bias_partial + static_cast<size_t>(rblock) * F);
 }
 
 // ---------------------------------------------------------------------------
