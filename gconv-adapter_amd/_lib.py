@@ -36,6 +36,7 @@ class CsrStruct(C.Structure):
         ("long_rows", C.c_void_p),
         ("long_seg_base", C.c_void_p),
         ("seg_long", C.c_void_p),
+        ("long_sync", C.c_void_p),
     ]
 
 
@@ -128,7 +129,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.gconv_abi_version() != 3:
+    if lib.gconv_abi_version() != 4:
         raise RuntimeError("gconv_adapter_amd: ABI version mismatch, rebuild the library")
     _lib = lib
     return lib

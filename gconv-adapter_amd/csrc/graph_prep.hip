@@ -96,7 +96,8 @@ __global__ void build_csr_kernel(const K* __restrict__ keys, int64_t E, int32_t 
 __global__ void row_stats_kernel(const int32_t* __restrict__ rowptr, int32_t n,
                                  float* __restrict__ dis, int32_t* __restrict__ long_rows,
                                  int32_t* __restrict__ long_seg_base,
-                                 int32_t* __restrict__ seg_long, int32_t* __restrict__ counters) {
+                                 int32_t* __restrict__ seg_long, uint32_t* __restrict__ long_sync,
+                                 int32_t* __restrict__ counters) {
   // counters: [0] n_long, [1] n_seg, [2] max degree
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int deg = 0;
@@ -109,6 +110,7 @@ __global__ void row_stats_kernel(const int32_t* __restrict__ rowptr, int32_t n,
       int base = atomicAdd(&counters[1], nseg);
       long_rows[lr] = i;
       long_seg_base[lr] = base;
+      long_sync[lr] = 0u;
       for (int k = 0; k < nseg; ++k) seg_long[base + k] = lr;
     }
   }
@@ -188,7 +190,7 @@ __global__ void tile_max_kernel(const int32_t* __restrict__ tile_ptr,
 // arena layout
 // ---------------------------------------------------------------------------
 struct CsrSlots {
-  size_t rowptr, col, long_rows, long_seg_base, seg_long;
+  size_t rowptr, col, long_rows, long_seg_base, seg_long, long_sync;
 };
 struct BuildLayout {
   CsrSlots f, b;
@@ -230,6 +232,7 @@ static BuildLayout build_layout(int64_t E, int32_t n) {
     c.long_rows = take(static_cast<size_t>(max_long_rows(E)) * 4);
     c.long_seg_base = take(static_cast<size_t>(max_long_rows(E)) * 4);
     c.seg_long = take(static_cast<size_t>(max_segments(E)) * 4);
+    c.long_sync = take(static_cast<size_t>(max_long_rows(E)) * 4);
   };
   csr(L.f);
   csr(L.b);
@@ -253,6 +256,7 @@ static BuildLayout build_layout(int64_t E, int32_t n) {
 
 struct CsrOut {
   int32_t *rowptr, *col, *long_rows, *long_seg_base, *seg_long;
+  uint32_t* long_sync;
 };
 
 // sort + CSR + row statistics for one direction; counters land in info[base .. base + 3]
@@ -280,7 +284,7 @@ static gconv_status_t build_direction(const int64_t* ei, int64_t E, int32_t n, i
   GCONV_LAUNCH_CHECK();
   if (n > 0) {
     row_stats_kernel<<<(n + T - 1) / T, T, 0, stream>>>(o.rowptr, n, dis, o.long_rows,
-                                                        o.long_seg_base, o.seg_long,
+                                                        o.long_seg_base, o.seg_long, o.long_sync,
                                                         info + base + 1);
     GCONV_LAUNCH_CHECK();
   }
@@ -315,7 +319,8 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
     return CsrOut{reinterpret_cast<int32_t*>(arena + c.rowptr), reinterpret_cast<int32_t*>(arena + c.col),
                   reinterpret_cast<int32_t*>(arena + c.long_rows),
                   reinterpret_cast<int32_t*>(arena + c.long_seg_base),
-                  reinterpret_cast<int32_t*>(arena + c.seg_long)};
+                  reinterpret_cast<int32_t*>(arena + c.seg_long),
+                  reinterpret_cast<uint32_t*>(arena + c.long_sync)};
   };
   const CsrOut of = slots(L.f), ob = slots(L.b);
   float* dis = normalize ? reinterpret_cast<float*>(arena + L.dis) : nullptr;
@@ -365,6 +370,7 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
     c.rowptr = o.rowptr; c.col = o.col;
     c.n_long = cnt[1]; c.n_seg = cnt[2];
     c.long_rows = o.long_rows; c.long_seg_base = o.long_seg_base; c.seg_long = o.seg_long;
+    c.long_sync = o.long_sync;
   };
   fill(g->fwd, of, h + FWD);
   g->max_degree = h[FWD + 3];

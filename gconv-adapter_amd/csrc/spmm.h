@@ -21,6 +21,7 @@ struct SpmmArgs {
   const int32_t* long_rows;
   const int32_t* long_seg_base;
   const int32_t* seg_long;
+  uint32_t* long_sync;
   int row_blocks;
   // operands
   const float* dis;     // nullptr -> unnormalised

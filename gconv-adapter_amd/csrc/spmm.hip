@@ -30,7 +30,7 @@ struct RowShape {
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 
 // ---------------------------------------------------------------------------
-// Epilogue shared by the row kernel and the long-row fix-up kernel.
+// Epilogue shared by the row path and the long-row completion of the row kernel.
 //   `sum` = plain sum over the row's stored edges of the gathered rows.
 // ---------------------------------------------------------------------------
 template <int F, bool NORM, int EPI>
@@ -116,27 +116,62 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(SpmmArgs a) {
 
   const int seg_blocks = (a.n_seg + 3) >> 2;
   if (static_cast<int>(blockIdx.x) < seg_blocks) {
-    // ---- long-row segment: the 64/LPR lane groups stride over the segment's edges
+    // ---- long-row segment: the 64/LPR lane groups stride over the segment's edges. The wave
+    // that completes a row (last arrival at the row's counter) adds the row's segment sums in
+    // segment order and runs the epilogue: no second launch, still no float atomics, and the
+    // result does not depend on which wave arrives last.
+    f32x4 bias_grad = zero4();
     const int s = blockIdx.x * 4 + wave;
-    if (s >= a.n_seg) return;
-    const int lr = a.seg_long[s];
-    const int row = a.long_rows[lr];
-    const int k = s - a.long_seg_base[lr];
-    const int e0 = a.rowptr[row] + k * GCONV_SEG_EDGES;
-    const int e1 = min(e0 + GCONV_SEG_EDGES, a.rowptr[row + 1]);
-    f32x4 acc = zero4();
+    if (s < a.n_seg) {   // wave-uniform
+      const int lr = a.seg_long[s];
+      const int row = a.long_rows[lr];
+      const int base = a.long_seg_base[lr];
+      const int r0 = a.rowptr[row], r1 = a.rowptr[row + 1];
+      const int e0 = r0 + (s - base) * GCONV_SEG_EDGES;
+      const int e1 = min(e0 + GCONV_SEG_EDGES, r1);
+      const int nseg = (r1 - r0 + GCONV_SEG_EDGES - 1) / GCONV_SEG_EDGES;
+      f32x4 acc = zero4();
 #pragma unroll 4
-    for (int e = e0 + grp; e < e1; e += RPW) {
-      int c = col[e];
-      f32x4 h = ldg4(H + static_cast<size_t>(c) * F + 4 * sub);
-      if (gather_scale) h *= a.dis[c];
-      acc += h;
-    }
+      for (int e = e0 + grp; e < e1; e += RPW) {
+        int c = col[e];
+        f32x4 h = ldg4(H + static_cast<size_t>(c) * F + 4 * sub);
+        if (gather_scale) h *= a.dis[c];
+        acc += h;
+      }
 #pragma unroll
-    for (int off = LPR; off < kWave; off <<= 1) {
-      for (int q = 0; q < 4; ++q) acc[q] += __shfl_xor(acc[q], off);
+      for (int off = LPR; off < kWave; off <<= 1) {
+        for (int q = 0; q < 4; ++q) acc[q] += __shfl_xor(acc[q], off);
+      }
+      // publish the partial: write-through (sc1) store — the other segments of the row may run
+      // on other XCDs, whose L2s are private — drained before the ticket is taken; the wave
+      // that completes the row reads all partials with sc1 loads (no fences on either side)
+      const rsrc_t rpart = make_rsrc(a.seg_partial, static_cast<uint32_t>(a.n_seg) * F * 4u);
+      if (grp == 0)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, acc), rpart, (s * F + 4 * sub) * 4, 0, 16);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      unsigned ticket = 0;
+      if (lane == 0)
+        ticket = __hip_atomic_fetch_add(a.long_sync + lr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ticket = __builtin_amdgcn_readfirstlane(ticket);
+      if (ticket == static_cast<unsigned>(nseg - 1)) {   // wave-uniform: every segment has landed
+        f32x4 sum = zero4();
+        for (int k = grp; k < nseg; k += RPW)
+          sum += __builtin_bit_cast(
+              f32x4, __builtin_amdgcn_raw_buffer_load_b128(rpart, ((base + k) * F + 4 * sub) * 4, 0, 16));
+#pragma unroll
+        for (int off = LPR; off < kWave; off <<= 1) {
+          for (int q = 0; q < 4; ++q) sum[q] += __shfl_xor(sum[q], off);
+        }
+        if (grp == 0) {
+          spmm_epilogue<F, NORM, EPI>(a, row, sub, sum, bias_grad);
+          // the row's bias-gradient term goes to the row's OWN partial slot, whichever wave
+          // completes it: the later reduction adds the same numbers in the same order every run
+          if (EPI == EPI_BWD1) stg4(a.bias_partial + static_cast<size_t>(a.row_blocks + lr) * F + 4 * sub, bias_grad);
+        }
+        if (lane == 0)   // ready for the next launch on this CSR
+          __hip_atomic_store(a.long_sync + lr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
-    if (grp == 0) stg4(a.seg_partial + static_cast<size_t>(s) * F + 4 * sub, acc);
     return;
   }
 
@@ -188,36 +223,6 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(SpmmArgs a) {
   if (EPI == EPI_BWD1) block_bias_partial<F>(bias_grad, a.bias_partial + static_cast<size_t>(rblock) * F);
 }
 
-// ---------------------------------------------------------------------------
-// Long-row fix-up: one wave per long row adds the row's segment sums (lane
-// groups stride over segments, fixed shuffle tree) and runs the epilogue.
-// ---------------------------------------------------------------------------
-template <int F, bool NORM, int EPI>
-__global__ __launch_bounds__(256) void spmm_fixup_kernel(SpmmArgs a) {
-  constexpr int LPR = RowShape<F>::LPR;
-  constexpr int RPW = RowShape<F>::RPW;
-  const int lane = threadIdx.x & 63, wave = wave_id();
-  const int sub = lane % LPR, grp = lane / LPR;
-  const int lr = blockIdx.x * 4 + wave;
-  f32x4 bias_grad = zero4();
-  if (lr < a.n_long) {
-    const int row = a.long_rows[lr];
-    const int base = a.long_seg_base[lr];
-    const int deg = a.rowptr[row + 1] - a.rowptr[row];
-    const int nseg = (deg + GCONV_SEG_EDGES - 1) / GCONV_SEG_EDGES;
-    f32x4 acc = zero4();
-    for (int k = grp; k < nseg; k += RPW)
-      acc += ldg4(a.seg_partial + static_cast<size_t>(base + k) * F + 4 * sub);
-#pragma unroll
-    for (int off = LPR; off < kWave; off <<= 1) {
-      for (int q = 0; q < 4; ++q) acc[q] += __shfl_xor(acc[q], off);
-    }
-    if (grp == 0) spmm_epilogue<F, NORM, EPI>(a, row, sub, acc, bias_grad);
-  }
-  if (EPI == EPI_BWD1)
-    block_bias_partial<F>(bias_grad, a.bias_partial + static_cast<size_t>(a.row_blocks + blockIdx.x) * F);
-}
-
 template <int F, bool NORM, int EPI>
 static gconv_status_t launch_spmm_t(SpmmArgs& a, hipStream_t stream) {
   constexpr int RPW = RowShape<F>::RPW;
@@ -226,10 +231,6 @@ static gconv_status_t launch_spmm_t(SpmmArgs& a, hipStream_t stream) {
   const int grid = a.row_blocks + seg_blocks;
   if (grid > 0) {
     spmm_rows_kernel<F, NORM, EPI><<<grid, 256, 0, stream>>>(a);
-    GCONV_LAUNCH_CHECK();
-  }
-  if (a.n_long > 0) {
-    spmm_fixup_kernel<F, NORM, EPI><<<ceil_div(a.n_long, 4), 256, 0, stream>>>(a);
     GCONV_LAUNCH_CHECK();
   }
   return GCONV_OK;
@@ -253,7 +254,7 @@ static gconv_status_t launch_spmm_n(SpmmArgs& a, int epi, hipStream_t stream) {
 
 int spmm_bias_partial_rows(const gconv_csr_t* g, int width) {
   const int rpw = kWave / (width / 4);
-  return ceil_div(g->num_nodes, 4 * rpw) + ceil_div(g->n_long, 4);
+  return ceil_div(g->num_nodes, 4 * rpw) + g->n_long;
 }
 
 gconv_status_t launch_spmm(const gconv_csr_t* g, SpmmArgs a, int width, int epi,
@@ -266,6 +267,7 @@ gconv_status_t launch_spmm(const gconv_csr_t* g, SpmmArgs a, int width, int epi,
   a.long_rows = g->long_rows;
   a.long_seg_base = g->long_seg_base;
   a.seg_long = g->seg_long;
+  a.long_sync = g->long_sync;
   if (a.n == 0) return GCONV_OK;
   if (a.n_seg > 0 && !a.seg_partial) return GCONV_E_WORKSPACE;
   switch (width) {

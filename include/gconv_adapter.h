@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GCONV_ABI_VERSION 3
+#define GCONV_ABI_VERSION 4
 
 typedef int32_t gconv_status_t;
 typedef void*   gconv_stream_t; /* hipStream_t */
@@ -89,6 +89,10 @@ typedef struct gconv_csr {
   const int32_t* long_rows;     /* [n_long] row ids                           */
   const int32_t* long_seg_base; /* [n_long] first segment of each long row    */
   const int32_t* seg_long;      /* [n_seg]  segment -> index into long_rows   */
+  uint32_t*      long_sync;     /* [n_long] arrival counters of a long row's segment waves:
+                                 * zero between launches (the wave that completes a row adds
+                                 * the row's segment sums and resets its counter). Launches
+                                 * that share a CSR must therefore be stream-ordered.      */
 } gconv_csr_t;
 
 /* Component tiles: molecule batches are block-diagonal, so the node range splits into

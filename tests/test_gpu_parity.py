@@ -517,6 +517,35 @@ def test_plan_cache_shared_across_adapters(dev):
 # ---------------------------------------------------------------------------
 # Full benchmark size: size-independent properties (oracle too slow / fp64 too big)
 # ---------------------------------------------------------------------------
+def test_long_row_completion_under_load(dev):
+    """Long rows are cut into segments summed by different waves (different XCDs, private L2s);
+    the wave that arrives last at the row's counter adds the partial sums. Repeated at
+    S-arxiv scale with another stream hammering memory: every launch must match the fp64
+    reference (a stale partial would show as an O(1) error), and the counters must be back at
+    zero for the next launch."""
+    batch, cfg = ga.synth.make_workload("arxiv")
+    n, r = batch.num_nodes, cfg["r"]
+    ei = batch.edge_index.to(dev)
+    plan = ga.get_plan(ei, n, True)
+    assert plan.fwd.n_long > 100 and plan.fwd.n_seg > plan.fwd.n_long
+    dis = plan.dis[:n].double()
+    side = torch.cuda.Stream()
+    hog = torch.randn(32 << 20, device=dev)
+    g = torch.Generator().manual_seed(0)
+    for it in range(12):
+        h = torch.randn(n, r, generator=g).to(dev)
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                hog.mul_(1.0001)
+        y = ga.spmm(plan, h)
+        hd = h.double() * dis[:, None]
+        ref = dis[:, None] * (torch.zeros(n, r, device=dev, dtype=torch.float64).index_add_(0, ei[1], hd[ei[0]]) + hd)
+        assert (y.double() - ref).abs().max().item() < 1e-4, f"launch {it}"
+    torch.cuda.synchronize()
+    sync = plan.arena_view(plan.fwd.struct.long_sync, plan.fwd.n_long, torch.int32)
+    assert int(sync.abs().sum()) == 0
+
+
 def test_arxiv_scale_properties(dev):
     batch, cfg = ga.synth.make_workload("arxiv")
     n, d, r = batch.num_nodes, cfg["d"], cfg["r"]
