@@ -234,6 +234,9 @@ def measure_arxiv(device, iters: int = 50, banded_control: bool = False) -> dict
         with open(pmc) as fh:
             dv = json.load(fh)["derived"]
         roof["traffic"] = round(dv["traffic_bytes_per_launch"])
+        # the bytes that actually crossed L2 <-> memory per launch, at the live launch time
+        roof["traffic_GBs"] = round(dv["traffic_bytes_per_launch"] / (ms * 1e-3) / 1e9, 1)
+        roof["traffic_frac_of_measured_copy_peak"] = round(roof["traffic_GBs"] / HBM_MEASURED_GBS, 3)
         roof["traffic_source"] = ("profiles/r01_spmm_arxiv_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE per launch "
                                   "(separate rocprofv3 --pmc passes, gfx950 x2 fetch correction); L2 hit rate "
                                   f"{dv['l2_hit_rate']:.2f}")
