@@ -106,6 +106,8 @@ SIGNATURES = {
                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                                              C.POINTER(PendingFinalize), _vp]),
     "gconv_adapter_bwd_finalize_f32": (_i32, [C.POINTER(PendingFinalize), _i32, _vp]),
+    "gconv_adam_step_f32": (_i32, [_vp, _vp, _vp, _vp, C.c_int64, C.c_float, C.c_float, C.c_float,
+                                   C.c_float, C.c_float, C.c_int64, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

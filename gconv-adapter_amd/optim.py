@@ -1,0 +1,134 @@
+"""Fused Adam over the trainable set.
+
+Drop-in for the ``torch.optim.Adam(param_groups, lr=..., weight_decay=...)`` of the reference's
+fine-tuning loops (``/root/reference/scripts/finetune_inductive_learning.py:375-379``,
+``scripts/finetune_transductive_learning.py:205``): same constructor arguments (per-group
+``lr`` / ``weight_decay`` / ``betas`` / ``eps``), same update rule, ``state_dict()`` in the
+same per-parameter format — but the trainable parameters of a group live in ONE flat buffer
+(``p.data`` of every parameter becomes a view of it; ``Parameter`` objects, names and
+``state_dict`` keys of the model are untouched) and a step is ONE ``torch.cat`` of the
+gradients plus ONE ``gconv_adam_step_f32`` launch per group instead of ~10 multi-tensor
+launches. Frozen parameters (``requires_grad=False``) are ignored, as torch's Adam ignores
+parameters without a gradient. There is no CPU path.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List
+
+import torch
+
+from . import _lib
+from .functional import _stream
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params: Iterable, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0):
+        if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
+            raise ValueError("FusedAdam: invalid hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        self._lib = _lib.load()
+        self._flat: List[dict] = []
+        for group in self.param_groups:
+            self._flat.append(self._flatten(group))
+
+    # ------------------------------------------------------------------ construction
+    def _flatten(self, group: dict) -> dict:
+        ps = [p for p in group["params"] if p.requires_grad]
+        if not ps:
+            return dict(params=[], total=0)
+        dev, dt = ps[0].device, ps[0].dtype
+        for p in ps:
+            if not p.is_cuda or p.dtype != torch.float32 or p.device != dev:
+                raise RuntimeError("FusedAdam needs fp32 parameters on one HIP device (no CPU path)")
+        total = sum(p.numel() for p in ps)
+        flat = torch.empty(total, dtype=dt, device=dev)
+        m = torch.zeros_like(flat)
+        v = torch.zeros_like(flat)
+        off = 0
+        offsets = []
+        with torch.no_grad():
+            for p in ps:
+                n = p.numel()
+                flat[off:off + n].copy_(p.data.reshape(-1))
+                p.data = flat[off:off + n].view_as(p)          # same Parameter, storage moved
+                self.state[p] = {"step": torch.zeros((), dtype=torch.float32),
+                                 "exp_avg": m[off:off + n].view_as(p),
+                                 "exp_avg_sq": v[off:off + n].view_as(p)}
+                offsets.append(off)
+                off += n
+        return dict(params=ps, offsets=offsets, total=total, flat=flat, grad=torch.empty_like(flat),
+                    exp_avg=m, exp_avg_sq=v, step=0)
+
+    # ------------------------------------------------------------------ step
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group, fl in zip(self.param_groups, self._flat):
+            ps = fl["params"]
+            if not ps:
+                continue
+            grads = [p.grad for p in ps]
+            if all(g is None for g in grads):
+                continue
+            fl["step"] += 1     # (the per-parameter "step" tensors are refreshed by state_dict())
+            beta1, beta2 = group["betas"]
+            dev = fl["flat"].device
+            if not any(g is None for g in grads):   # the normal case: one cat, one launch
+                torch.cat([g.reshape(-1) for g in grads], out=fl["grad"])
+                st = self._lib.gconv_adam_step_f32(
+                    fl["flat"].data_ptr(), fl["grad"].data_ptr(), fl["exp_avg"].data_ptr(),
+                    fl["exp_avg_sq"].data_ptr(), fl["total"], float(group["lr"]), float(beta1), float(beta2),
+                    float(group["eps"]), float(group["weight_decay"]), fl["step"], _stream(dev.index))
+                _lib.check(st, "adam_step")
+                continue
+            # contiguous runs of parameters that have a gradient
+            i = 0
+            while i < len(ps):
+                if grads[i] is None:
+                    i += 1
+                    continue
+                j = i
+                while j < len(ps) and grads[j] is not None:
+                    j += 1
+                lo = fl["offsets"][i]
+                hi = fl["offsets"][j - 1] + ps[j - 1].numel()
+                torch.cat([g.reshape(-1) for g in grads[i:j]], out=fl["grad"][lo:hi])
+                st = self._lib.gconv_adam_step_f32(
+                    fl["flat"].data_ptr() + 4 * lo, fl["grad"].data_ptr() + 4 * lo,
+                    fl["exp_avg"].data_ptr() + 4 * lo, fl["exp_avg_sq"].data_ptr() + 4 * lo, hi - lo,
+                    float(group["lr"]), float(beta1), float(beta2), float(group["eps"]),
+                    float(group["weight_decay"]), fl["step"], _stream(dev.index))
+                _lib.check(st, "adam_step")
+                i = j
+        return loss
+
+    # ------------------------------------------------------------------ (de)serialisation
+    def state_dict(self):
+        """``torch.optim.Adam``-compatible: per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``
+        (the moments are views of the flat buffers: deep-copy before loading it elsewhere, as with
+        any optimizer state dict that is not going through ``torch.save``)."""
+        for fl in self._flat:
+            for p in fl.get("params", []):
+                self.state[p]["step"] = torch.tensor(float(fl["step"]))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict) -> None:
+        """Accepts a ``torch.optim.Adam`` / ``FusedAdam`` state dict: moments are copied INTO the
+        flat buffers (the per-parameter state tensors stay views of them)."""
+        views = {id(p): dict(self.state[p]) for fl in self._flat for p in fl.get("params", [])}
+        super().load_state_dict(state_dict)
+        for group, fl in zip(self.param_groups, self._flat):
+            for p in fl.get("params", []):
+                loaded, mine = self.state.get(p, {}), views[id(p)]
+                if loaded and loaded.get("exp_avg") is not mine["exp_avg"]:
+                    mine["exp_avg"].copy_(loaded["exp_avg"])
+                    mine["exp_avg_sq"].copy_(loaded["exp_avg_sq"])
+                    mine["step"] = torch.as_tensor(float(loaded["step"]))
+                    self.state[p] = mine
+            steps = [int(self.state[p]["step"]) for p in fl.get("params", [])]
+            if steps:
+                fl["step"] = max(steps)

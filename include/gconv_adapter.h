@@ -253,6 +253,19 @@ gconv_status_t gconv_adapter_bwd_partial_f32(const gconv_graph_t* graph,
 gconv_status_t gconv_adapter_bwd_finalize_f32(const gconv_pending_finalize_t* pending,
                                               int32_t count, gconv_stream_t stream);
 
+/* ---- next to the path: the optimizer step over the trainable set -------------
+ * replaces: `optim.Adam(...)` + `optimizer.step()`
+ *   (`scripts/finetune_inductive_learning.py:379,67`, `scripts/finetune_transductive_learning.py:205,230`)
+ * for parameters kept in ONE flat fp32 range (adapters + head + norm affine, ~29 k floats): one
+ * launch instead of torch's ~10 multi-tensor launches. Non-amsgrad Adam with L2 weight decay,
+ * torch's update rule and operation order; `step` is the 1-based step count of this call
+ * (bias corrections are computed from it in double on the host, as torch does). All four
+ * arrays have `count` floats; param / exp_avg / exp_avg_sq are updated in place.            */
+gconv_status_t gconv_adam_step_f32(float* param, const float* grad, float* exp_avg,
+                                   float* exp_avg_sq, int64_t count, float lr, float beta1,
+                                   float beta2, float eps, float weight_decay, int64_t step,
+                                   gconv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -517,6 +517,71 @@ def test_plan_cache_shared_across_adapters(dev):
 # ---------------------------------------------------------------------------
 # Full benchmark size: size-independent properties (oracle too slow / fp64 too big)
 # ---------------------------------------------------------------------------
+def test_fused_adam_matches_torch_adam(dev):
+    """FusedAdam (one launch per group over flat buffers) vs torch.optim.Adam on the CPU in
+    fp64 and on the GPU in fp32: two parameter groups with their own lr / weight decay (the
+    reference's head group, finetune_inductive_learning.py:375-379), a frozen parameter, six
+    steps; state_dict round trip into a torch Adam."""
+    torch.manual_seed(0)
+    shapes = [(8, 300), (8,), (300, 8), (300,), (1,), (300, 2)]
+    base = [torch.randn(s) * 0.1 for s in shapes]
+    grads = [[torch.randn(s) for s in shapes] for _ in range(6)]
+
+    def make(device, dtype):
+        ps = [torch.nn.Parameter(b.to(device=device, dtype=dtype).clone()) for b in base]
+        frozen = torch.nn.Parameter(torch.ones(3, device=device, dtype=dtype), requires_grad=False)
+        groups = [{"params": ps[:5] + [frozen]}, {"params": ps[5:], "lr": 3e-3, "weight_decay": 0.0}]
+        return ps, groups
+
+    ps_ref, groups_ref = make("cpu", torch.float64)
+    opt_ref = torch.optim.Adam(groups_ref, lr=1e-3, weight_decay=1e-2)
+    ps_t, groups_t = make(dev, torch.float32)
+    opt_t = torch.optim.Adam(groups_t, lr=1e-3, weight_decay=1e-2)
+    ps_f, groups_f = make(dev, torch.float32)
+    opt_f = ga.FusedAdam(groups_f, lr=1e-3, weight_decay=1e-2)
+    for step in range(6):
+        for ps, opt in ((ps_ref, opt_ref), (ps_t, opt_t), (ps_f, opt_f)):
+            for p, g in zip(ps, grads[step]):
+                p.grad = g.to(device=p.device, dtype=p.dtype)
+            opt.step()
+    for pr, pt, pf in zip(ps_ref, ps_t, ps_f):
+        assert torch.allclose(pf.detach().cpu().double(), pr.detach(), rtol=1e-5, atol=1e-7)
+        assert torch.allclose(pf.detach(), pt.detach(), rtol=1e-6, atol=1e-7)   # 1e-7 = 3e-5 of one step
+    # the parameters are views of one flat buffer per group, still the same Parameter objects
+    assert ps_f[0].data_ptr() + 4 * ps_f[0].numel() == ps_f[1].data_ptr()
+    # state_dict is torch-Adam compatible: continue in a torch Adam, one more identical step
+    import copy
+    sd = copy.deepcopy(opt_f.state_dict())   # (state_dict() hands out references, as torch's does)
+    ps_c, groups_c = make(dev, torch.float32)
+    with torch.no_grad():
+        for pc, pf in zip(ps_c, ps_f):
+            pc.copy_(pf)
+    opt_c = torch.optim.Adam(groups_c, lr=1e-3, weight_decay=1e-2)
+    opt_c.load_state_dict(sd)
+    g7 = [torch.randn(s) for s in shapes]
+    for ps, opt in ((ps_c, opt_c), (ps_f, opt_f)):
+        for p, g in zip(ps, g7):
+            p.grad = g.to(dev)
+        opt.step()
+    for pc, pf in zip(ps_c, ps_f):
+        assert torch.allclose(pc.detach(), pf.detach(), rtol=1e-6, atol=1e-7), \
+            f"max abs diff {(pc - pf).abs().max().item():.3e} on {tuple(pc.shape)}"
+    # and the other way round: a torch state dict loaded into a FusedAdam
+    ps_g, groups_g = make(dev, torch.float32)
+    with torch.no_grad():
+        for pg, pc in zip(ps_g, ps_c):
+            pg.copy_(pc)
+    opt_g = ga.FusedAdam(groups_g, lr=1e-3, weight_decay=1e-2)
+    opt_g.load_state_dict(copy.deepcopy(opt_c.state_dict()))
+    g8 = [torch.randn(s) for s in shapes]
+    for ps, opt in ((ps_c, opt_c), (ps_g, opt_g)):
+        for p, g in zip(ps, g8):
+            p.grad = g.to(dev)
+        opt.step()
+    for pc, pg in zip(ps_c, ps_g):
+        assert torch.allclose(pc.detach(), pg.detach(), rtol=1e-6, atol=1e-7)
+
+
 def test_long_row_completion_under_load(dev):
     """Long rows are cut into segments summed by different waves (different XCDs, private L2s);
     the wave that arrives last at the row's counter adds the partial sums. Repeated at
