@@ -88,7 +88,23 @@ __device__ __forceinline__ f32x4 buf_ld4_last(rsrc_t r, int byte_off) {   // a r
 __device__ __forceinline__ void buf_st4(rsrc_t r, int byte_off, f32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), r, byte_off, 0, GCONV_STORE_AUX);
 }
+__device__ __forceinline__ float buf_ld1(rsrc_t r, int byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ void buf_st1(rsrc_t r, int byte_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, byte_off, 0, GCONV_STORE_AUX);
+}
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// 16 independent 4x4 outer-product accumulations (v_mfma_f32_4x4x1_16b_f32), exact fp32:
+//   D_b[i][j] += A_b[i] * B_b[j] for the 16 blocks b.
+//   A: lane l holds A_(l/4)[l%4];  B: lane l holds B_(l/4)[l%4];  D: lane l, reg v = D_(l/4)[v][l%4]
+// (layout verified on gfx950 by tools/mfma4_probe.hip). With the same A in every block it
+// multiplies a 4-vector by 64 per-lane scalars: M = 4 wastes nothing at rank 4 or 8, where the
+// 16x16x4 form pads the rank dimension to 16.
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
 
 // Wave index inside the workgroup as a provably wave-uniform (SGPR) value. Without the
 // readfirstlane hipcc treats `threadIdx.x >> 6` as divergent, turns every branch that

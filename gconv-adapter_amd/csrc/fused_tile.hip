@@ -482,8 +482,9 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
   f32x4* wl = lds4;                                              // [NQ][NCB][64]  W_up^T frags
   float* bufA = reinterpret_cast<float*>(lds4 + NQ * NCB * 64);  // [cap][FP]  dP', later T
   float* bufB = bufA + a.cap * FP;                               // [cap][FP]  dH1'
-  float* bufC = bufB + a.cap * FP;                               // [cap][FP]  P tile
-  float* red = bufC + a.cap * FP;                                // [nwaves][FP + 2] scratch
+  float* bufC = bufB + a.cap * FP;                               // [FP][cap]  P tile, transposed
+  float* bufD = bufC + a.cap * FP;                               // [FP][cap]  T, transposed
+  float* red = bufD + a.cap * FP;                                // [nwaves][FP + 2] scratch
   int32_t* rp = reinterpret_cast<int32_t*>(red + 8 * (FP + 2));  // [cap + 1]
   float* dl = reinterpret_cast<float*>(rp + a.cap + 16);         // [cap]  dis of the tile
   int32_t* cl = reinterpret_cast<int32_t*>(dl + a.cap);          // [ecap]
@@ -513,33 +514,30 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
   const int jr = nchunks - 1 - J;
   const int slot = primary ? 0 : 1 + ex / nchunks;
   const int nslots = 1 + (extras > jr ? (extras - 1 - jr) / nchunks + 1 : 0);
-  const int colbase = 64 * J + 4 * jj;
-  const bool colvalid = owner && colbase < a.d;
-  const int colc = min(colbase, a.d - 4);
-  float wd[NEED_DX ? KS : 1][4];
-  f32x4 raw[NEED_DX ? KS : 1];
+  // Phase 4 works in the "column per lane" layout of the 4x4x1 MFMA: lane l of the wave that
+  // owns chunk J holds column 64 J + l of a row (256 contiguous bytes per row and instruction),
+  // the rank-width operand (4 of the FP values of a node) is the same in all 16 blocks.
+  constexpr int MT = FP / 4;            // 4-row tiles of the rank dimension
+  const int l4 = lane & 3;
+  const int col1 = 64 * J + lane;
+  const bool colvalid = owner && col1 < a.d;
+  const int colc = min(col1, a.d - 1);
+  float wd[NEED_DX ? FP : 1];          // W_down[k][col] of this lane's column
   if constexpr (NEED_DX) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s)
-      raw[s] = ldg4(a.w_down + static_cast<size_t>(min(rank_k_<FP>(s, t), a.r - 1)) * a.d + colc);
+    for (int k = 0; k < FP; ++k) wd[k] = a.w_down[static_cast<size_t>(min(k, a.r - 1)) * a.d + colc];
   }
   stage_weights<NCB, NQ, false>(wl, a.w_up, a.d, a.r);
   const float sval = a.scalar ? keep(sraw) : 1.f;
   if constexpr (NEED_DX) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int k = rank_k_<FP>(s, t);
-      const f32x4 v = keep(raw[s]);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) wd[s][c] = (colvalid && k < a.r) ? v[c] : 0.f;
-    }
+    for (int k = 0; k < FP; ++k) wd[k] = (colvalid && k < a.r) ? keep(wd[k]) : 0.f;
   }
-  f32x4 awd[NCB][4], awu[NCB][4];
+  f32x4 awd[MT], awu[MT];              // dWd^T[4 mt + v][col], dWu^T[4 mt + v][col] in reg v
 #pragma unroll
-  for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) awd[cb][c] = awu[cb][c] = zero4f();
-  f32x4 cs = zero4f(), bgrad = zero4f();
+  for (int mt = 0; mt < MT; ++mt) awd[mt] = awu[mt] = zero4f();
+  float cs = 0.f;                      // colsum(G)[col]
+  f32x4 bgrad = zero4f();
   float ds1 = 0.f, dsx = 0.f;
   __syncthreads();
 
@@ -565,10 +563,10 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
     // for the whole kernel instead of being recomputed with one or two VALU ops.
     int rowb = 4 * a.d;
     asm volatile("" : "+s"(rowb));
-    // phase-4 byte offset of this lane inside a tile: row 4t of a node block, its 4 columns;
-    // a lane past the last column, and every lane of a wave that owns no chunk, is pushed out
-    // of the tile's range (loads 0 without traffic, stores nothing)
-    const int voff4 = 4 * t * rowb + (colvalid ? 4 * colbase : kBufOob);
+    // phase-4 byte offset of this lane's column inside a row; a lane past the last column, and
+    // every lane of a wave that owns no chunk, is pushed out of the tile's range (loads 0
+    // without traffic, stores nothing)
+    const int voff1 = colvalid ? 4 * col1 : kBufOob;
     // the tile's rows of G, X and dX as range-checked buffers
     const uint32_t tbytes = static_cast<uint32_t>(nt) * rowb;
     const rsrc_t rg = make_rsrc(a.g + static_cast<size_t>(ts) * a.d, tbytes);
@@ -588,9 +586,16 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
     ds1 += tile_rowsA<FP, NQ, NORM, true>(rg, a.g, wl, bufA, a.dis, a.want_ds ? a.saved_p : nullptr, sval, ts,
                                           nt, a.d, rowb, nwaves, wave, lane, [&]() { csr.advance(); });
     csr.finish();
-    if (static_cast<int>(threadIdx.x) < np4) *reinterpret_cast<f32x4*>(bufC + 4 * threadIdx.x) = pfirst;
-    for (int i = threadIdx.x + blockDim.x; i < np4; i += blockDim.x)
-      *reinterpret_cast<f32x4*>(bufC + 4 * i) = ldg4(a.saved_p + static_cast<size_t>(ts) * FP + 4 * i);
+    // P goes to LDS transposed (rank-major): phase 4 reads 4 consecutive nodes of one rank row
+    // with one 16-byte LDS load; rows between nt and the end of the last node block are zeros
+    const int np4pad = ceil_div(nt, 16) * 16 * LPR;
+    for (int i = threadIdx.x; i < np4pad; i += blockDim.x) {
+      f32x4 pv = zero4f();
+      if (i < np4) pv = i == static_cast<int>(threadIdx.x) ? pfirst : ldg4(a.saved_p + static_cast<size_t>(ts) * FP + 4 * i);
+      const int lr = i / LPR, sb = i % LPR;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bufC[(4 * sb + k) * a.cap + lr] = pv[k];
+    }
     __syncthreads();
 
     TILE_STAMP(2);
@@ -598,16 +603,16 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
     // phases 2 / 3. Unconditional requests (a conditional prefetch makes the compiler drain
     // vmcnt): a node block past the tile lies outside the buffers and costs no traffic.
     const int nb4 = ceil_div(nt, 16);
-    auto load_gx = [&](int blk, f32x4 (&gq)[4], f32x4 (&xq)[4]) {
+    auto load_gx = [&](int blk, float (&gq)[16], float (&xq)[16]) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int off = voff4 + (16 * blk + m) * rowb;
-        gq[m] = buf_ld4_last(rg, off);
-        xq[m] = buf_ld4_last(rx, off);
+      for (int n = 0; n < 16; ++n) {
+        const int off = voff1 + (16 * blk + n) * rowb;
+        gq[n] = buf_ld1(rg, off);
+        xq[n] = buf_ld1(rx, off);
       }
     };
     constexpr bool DEEP = FP < 32;  // rank 17..32: no registers left for the second pair
-    f32x4 ga[4], xa[4], gb[DEEP ? 4 : 1], xb[DEEP ? 4 : 1];
+    float ga[16], xa[16], gb[DEEP ? 16 : 1], xb[DEEP ? 16 : 1];
     load_gx(slot, ga, xa);
     if constexpr (DEEP) load_gx(slot + nslots, gb, xb);
 
@@ -630,10 +635,16 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
     __syncthreads();
 
     TILE_STAMP(3);
-    // ---- phase 3: T = S^T dH1 -> bufA
-    for (int lr = grp; lr < nt; lr += ngrp) {
-      const f32x4 v = tile_row_sum<FP, NORM>(bufB, rp, cl, dl, lr, sub);
-      *reinterpret_cast<f32x4*>(bufA + lr * FP + 4 * sub) = v;
+    // ---- phase 3: T = S^T dH1 -> bufA (row-major: the dX operand) and bufD (rank-major:
+    // the dW operand; rows up to the end of the last node block are zeros)
+    for (int lr = grp; lr < ceil_div(nt, 16) * 16; lr += ngrp) {
+      f32x4 v = zero4f();
+      if (lr < nt) {
+        v = tile_row_sum<FP, NORM>(bufB, rp, cl, dl, lr, sub);
+        *reinterpret_cast<f32x4*>(bufA + lr * FP + 4 * sub) = v;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bufD[(4 * sub + k) * a.cap + lr] = v[k];
     }
     __syncthreads();
 
@@ -644,51 +655,46 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
     // loads; saying so gives the loop one known state on entry and around its back edge)
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     if (owner && slot < nb4) {
-      auto step = [&](int b, f32x4 (&gv)[4], f32x4 (&xv)[4], int refill) {
-        float at[4][NCB], ap[4][NCB];
+      const float skipf = a.skip ? sval : 0.f;
+      auto step = [&](int b, float (&gv)[16], float (&xv)[16], int refill) {
+        // dWd^T += T^T X, dWu^T += P^T G: one node per MFMA, the node's 4 rank values of tile mt
+        // (the same in all 16 blocks) times this lane's column of the node's row
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const int lr = 16 * b + 4 * t + m, lrc = min(lr, nt - 1);
+        for (int ng = 0; ng < 4; ++ng) {   // 4 nodes per 16-byte LDS read of a rank row
+          f32x4 tq[MT], pq[MT];
 #pragma unroll
-          for (int cb = 0; cb < NCB; ++cb) {
-            const int rc = 16 * cb + jj, rcc = min(rc, FP - 1);
-            const float vt = bufA[lrc * FP + rcc];
-            const float vp = bufC[lrc * FP + rcc];
-            const bool ok = lr < nt && rc < FP;
-            at[m][cb] = ok ? vt : 0.f;
-            ap[m][cb] = ok ? vp : 0.f;
+          for (int mt = 0; mt < MT; ++mt) {
+            tq[mt] = *reinterpret_cast<const f32x4*>(bufD + (4 * mt + l4) * a.cap + 16 * b + 4 * ng);
+            pq[mt] = *reinterpret_cast<const f32x4*>(bufC + (4 * mt + l4) * a.cap + 16 * b + 4 * ng);
           }
-        }
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+          for (int i = 0; i < 4; ++i) {
+            const int n = 4 * ng + i;
 #pragma unroll
-          for (int cb = 0; cb < NCB; ++cb) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              awd[cb][c] = mfma16(at[m][cb], xv[m][c], awd[cb][c]);
-              awu[cb][c] = mfma16(ap[m][cb], gv[m][c], awu[cb][c]);
+            for (int mt = 0; mt < MT; ++mt) {
+              awd[mt] = mfma4(tq[mt][i], xv[n], awd[mt]);
+              awu[mt] = mfma4(pq[mt][i], gv[n], awu[mt]);
             }
+            cs += gv[n];
+            dsx += gv[n] * xv[n];
           }
-          cs += gv[m];
-          if (a.skip) dsx += gv[m][0] * xv[m][0] + gv[m][1] * xv[m][1] + gv[m][2] * xv[m][2] + gv[m][3] * xv[m][3];
         }
         if constexpr (NEED_DX) {
-          float ta[KS];
-          lds_rank_frag<FP>(bufA, min(16 * b + jj, nt - 1), t, 16 * b + jj < nt, ta);
-          f32x4 acc[4];
+          // dX[node][col] = sum_k T[node][k] Wd[k][col] + s G: 4 nodes per accumulator
 #pragma unroll
-          for (int c = 0; c < 4; ++c) acc[c] = zero4f();
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int lrc = min(16 * b + 4 * g4 + l4, nt - 1);   // (rows past the tile: dropped below)
+            f32x4 tk[MT];
 #pragma unroll
-          for (int s = 0; s < KS; ++s) {
+            for (int mt = 0; mt < MT; ++mt) tk[mt] = *reinterpret_cast<const f32x4*>(bufA + lrc * FP + 4 * mt);
+            f32x4 acc = zero4f();
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = mfma16(ta[s], wd[s][c], acc[c]);
-          }
+            for (int k = 0; k < FP; ++k) acc = mfma4(tk[k >> 2][k & 3], wd[k], acc);
 #pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            f32x4 o;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) o[c] = acc[c][m] + (a.skip ? sval * gv[m][c] : 0.f);
-            buf_st4(rdx, voff4 + (16 * b + m) * rowb, o);  // rows / columns past the tile: dropped
+            for (int v = 0; v < 4; ++v) {
+              const int n = 4 * g4 + v;
+              buf_st1(rdx, voff1 + (16 * b + n) * rowb, acc[v] + skipf * gv[n]);
+            }
           }
         }
         load_gx(refill, gv, xv);
@@ -713,69 +719,50 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
   // ---- co-owners hand their accumulators to the chunk's primary owner through LDS (the
   // tile buffers are dead: the loop ends on a barrier); summed in slot order
   {
-    constexpr int kSlab = (2 * NCB * 16 + 4) * 64;  // floats per co-owner wave
+    constexpr int kSlab = (2 * FP + 1) * 64;  // floats per co-owner wave
     float* slabs = reinterpret_cast<float*>(lds4);
     if (owner && !primary) {
       float* sl = slabs + ex * kSlab + lane;
 #pragma unroll
-      for (int cb = 0; cb < NCB; ++cb)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            sl[((cb * 4 + c) * 4 + m) * 64] = awd[cb][c][m];
-            sl[(NCB * 16 + (cb * 4 + c) * 4 + m) * 64] = awu[cb][c][m];
-          }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) sl[(2 * NCB * 16 + c) * 64] = cs[c];
+        for (int v = 0; v < 4; ++v) {
+          sl[(4 * mt + v) * 64] = awd[mt][v];
+          sl[(FP + 4 * mt + v) * 64] = awu[mt][v];
+        }
+      sl[2 * FP * 64] = cs;
     }
     __syncthreads();
     if (primary) {
       for (int s = 1; s < nslots; ++s) {
         const float* sl = slabs + ((s - 1) * nchunks + jr) * kSlab + lane;
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-              awd[cb][c][m] += sl[((cb * 4 + c) * 4 + m) * 64];
-              awu[cb][c][m] += sl[(NCB * 16 + (cb * 4 + c) * 4 + m) * 64];
-            }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) cs[c] += sl[(2 * NCB * 16 + c) * 64];
+          for (int v = 0; v < 4; ++v) {
+            awd[mt][v] += sl[(4 * mt + v) * 64];
+            awu[mt][v] += sl[(FP + 4 * mt + v) * 64];
+          }
+        cs += sl[2 * FP * 64];
       }
     }
     __syncthreads();  // the slabs may overlap the reduction scratch used below
   }
 
-  // ---- one partial row per workgroup (primary owners)
-  // colsum(G): add the four lane quarters (fixed order); quarter 0 stores
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    cs[c] += __shfl_xor(cs[c], 16);
-    cs[c] += __shfl_xor(cs[c], 32);
-  }
+  // ---- one partial row per workgroup (primary owners): lane = column, register = rank row
   // b_up . colsum(G) of this wave's chunk joins the scalar-gradient partial
   float bdot = 0.f;
-  if (primary && colvalid && t == 0 && a.b_up) {
-    const f32x4 bv = ldg4(a.b_up + colbase);
-    bdot = bv[0] * cs[0] + bv[1] * cs[1] + bv[2] * cs[2] + bv[3] * cs[3];
-  }
+  if (primary && colvalid && a.b_up) bdot = a.b_up[col1] * cs;
   if (primary && colvalid) {
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) {
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int rk = 16 * cb + 4 * t + m;
-        if (rk < FP) {
-          const size_t o = (static_cast<size_t>(pid) * FP + rk) * a.d + colbase;
-          stg4(a.part_wd + o, f32x4{awd[cb][0][m], awd[cb][1][m], awd[cb][2][m], awd[cb][3][m]});
-          stg4(a.part_wu + o, f32x4{awu[cb][0][m], awu[cb][1][m], awu[cb][2][m], awu[cb][3][m]});
-        }
+      for (int v = 0; v < 4; ++v) {
+        const size_t o = (static_cast<size_t>(pid) * FP + 4 * mt + v) * a.d + col1;
+        a.part_wd[o] = awd[mt][v];
+        a.part_wu[o] = awu[mt][v];
       }
-    }
-    if (t == 0) stg4(a.part_cs + static_cast<size_t>(pid) * a.d + colbase, cs);
+    a.part_cs[static_cast<size_t>(pid) * a.d + col1] = cs;
   }
   // bias gradient and d(scalar): lanes -> wave -> workgroup, fixed order
 #pragma unroll
@@ -840,11 +827,11 @@ size_t tile_lds_bytes(int d, int fp, int tile_nodes_max, int tile_edges_max) {
   const int cap = ceil_div(tile_nodes_max > 0 ? tile_nodes_max : 1, 16) * 16;
   const size_t tiles =
       static_cast<size_t>(nq) * ncb * 64 * sizeof(f32x4) +              // weight fragments
-      static_cast<size_t>(3) * cap * fp * sizeof(float) +                // rank-width tiles
+      static_cast<size_t>(4) * cap * fp * sizeof(float) +                // rank-width tiles (backward: 4)
       8 * (fp + 2) * sizeof(float) +                                     // reduction scratch
       (static_cast<size_t>(2) * cap + 16 + (tile_edges_max > 0 ? tile_edges_max : 1)) * 4 + 64;  // rp, dl, cl
   // the backward's co-owner slabs reuse the same space after the last tile
-  const size_t slabs = static_cast<size_t>(fp >= 32 ? 1 : 3) * (2 * ncb * 16 + 4) * 64 * sizeof(float);
+  const size_t slabs = static_cast<size_t>(fp >= 32 ? 1 : 3) * (2 * fp + 1) * 64 * sizeof(float);
   return tiles > slabs ? tiles : slabs;
 }
 
