@@ -148,16 +148,36 @@ __global__ void sym_check_kernel(const int32_t* __restrict__ rowptr,
   if (q >= rowptr[j + 1] || col[q] != i) atomicOr(asym, 1);
 }
 
-// tile_ptr[t] = last boundary q <= t * B that no edge spans (span_ps[q] == 0).
-__global__ void tile_start_kernel(const int32_t* __restrict__ span_ps, int32_t n, int ntiles,
-                                  int32_t* __restrict__ tile_ptr, int32_t* __restrict__ info) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+// tile_ptr[t] = last boundary q <= t * B that no edge spans (span_ps[q] == 0), searched at most
+// GCONV_TILE_BACK positions back. One wave per tile: 64 candidate boundaries per step
+// (coalesced load + ballot) instead of a serial walk of up to 480 dependent loads per thread.
+__global__ __launch_bounds__(256) void tile_start_kernel(const int32_t* __restrict__ span_ps, int32_t n,
+                                                         int ntiles, int32_t* __restrict__ tile_ptr,
+                                                         int32_t* __restrict__ info) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t > ntiles) return;
-  if (t == ntiles) { tile_ptr[t] = n; return; }
-  int q = t * GCONV_TILE_NODES, steps = 0;
-  while (q > 0 && span_ps[q] != 0 && steps < GCONV_TILE_BACK) { --q; ++steps; }
-  if (q > 0 && span_ps[q] != 0) atomicOr(&info[INFO_NOTILE], 1);
-  tile_ptr[t] = q;
+  if (t == ntiles) {
+    if (lane == 0) tile_ptr[t] = n;
+    return;
+  }
+  const int q0 = t * GCONV_TILE_NODES;
+  int found = -1;
+  for (int base = 0; base <= GCONV_TILE_BACK && found < 0; base += 64) {
+    const int q = q0 - base - lane;                       // lane 0 = the highest candidate
+    const bool cand = q >= 0 && base + lane <= GCONV_TILE_BACK;
+    const bool ok = cand && (q == 0 || span_ps[q] == 0);
+    const unsigned long long m = __ballot(ok);
+    if (m) found = q0 - base - (__ffsll(static_cast<long long>(m)) - 1);
+    if (q0 - base - 63 <= 0) break;                       // reached the start of the graph
+  }
+  if (lane == 0) {
+    if (found < 0) {   // no edge-free boundary within reach: the graph is not tileable
+      atomicOr(&info[INFO_NOTILE], 1);
+      found = max(q0 - GCONV_TILE_BACK, 0);
+    }
+    tile_ptr[t] = found;
+  }
 }
 
 // Largest tile (nodes, stored edges) for the LDS budget of the fused kernels, and the keys of
@@ -350,7 +370,7 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
   {
     size_t cub_bytes = L.cub_bytes;
     GCONV_HIP(hipcub::DeviceScan::InclusiveSum(arena + L.cub, cub_bytes, span, span_ps, n + 2, stream));
-    tile_start_kernel<<<(L.ntiles + 1 + T - 1) / T, T, 0, stream>>>(span_ps, n, L.ntiles, tile_ptr, info);
+    tile_start_kernel<<<(L.ntiles + 1 + 3) / 4, 256, 0, stream>>>(span_ps, n, L.ntiles, tile_ptr, info);
     GCONV_LAUNCH_CHECK();
     tile_max_kernel<<<(L.ntiles + T - 1) / T, T, 0, stream>>>(
         tile_ptr, of.rowptr, L.ntiles, info, reinterpret_cast<uint32_t*>(arena + L.tile_key),
