@@ -1,5 +1,5 @@
 """Host-side phases of the bench step (fresh plan per step, prefetch thread), per workload:
-    python tools/stepprof.py [esol|hiv]"""
+    python tools/stepprof.py [esol|hiv] [fresh|cached] [heat] [nopin]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,6 +12,7 @@ fresh = (sys.argv[2] != "cached") if len(sys.argv) > 2 else True
 if "heat" in sys.argv:   # what a preceding heavy phase (S-arxiv measurement) does to the step
     bench.measure_arxiv(dev, banded_control=False)
 stream = bench.BatchStream(name, 0, dev, 4, fresh)
+pinned = [] if "nopin" in sys.argv else ga.dist.pin_to_local_cores()   # as bench.py does
 cfg = stream.cfg
 mods = [ga.GConvAdapter(cfg["d"], cfg["r"], learnable_scalar=True).to(dev) for _ in range(cfg["adapters"])]
 params = [p for m in mods for p in m.parameters()]
@@ -37,5 +38,5 @@ for it in range(N + 30):
     for i, (a, b) in enumerate(((t0, t1), (t1, t2), (t2, t3), (t3, t4), (t4, t5), (t5, t6))): acc[i] += b - a
 torch.cuda.synchronize()
 tot = (time.perf_counter() - T0) / N * 1e6
-print(name, "fresh" if fresh else "cached", "| next+prefetch %.0f | grad=None %.0f | fwd[0] (plan wait) %.0f | fwd[1:] %.0f | backward %.0f | discard %.0f | total/step %.0f us"
+print(name, "fresh" if fresh else "cached", "pinned" if pinned else "not pinned", "| next+prefetch %.0f | grad=None %.0f | fwd[0] (plan wait) %.0f | fwd[1:] %.0f | backward %.0f | discard %.0f | total/step %.0f us"
       % tuple([a / N * 1e6 for a in acc] + [tot]))
