@@ -14,7 +14,8 @@
 //   backward  phase 1  dP' = dis . s (G_t Wu) ; sum (G Wu) . P  MFMA, A layout
 //             phase 2  dH1' = dis . (S^T dP) . act' ; dbd
 //             phase 3  T = S^T dH1
-//             phase 4  dX_t = T Wd + s G_t ; dWd^T, dWu^T, colsum(G), sum G.X   MFMA, L layout
+//             phase 4  dX_t = T Wd + s G_t ; dWd^T, dWu^T, colsum(G), sum G.X   4x4x1 MFMA,
+//                      one column per lane, T / P rank-major in LDS
 //
 // Same math, same epilogues and the same deterministic B5 finalize as the four-launch
 // path (adapter.hip); replaces /root/reference/src/finetune/gconv_adapter.py:80-108 and

@@ -214,8 +214,19 @@ struct Deferred {
   std::vector<at::Tensor> keep;      // workspaces and gradient buffers of the pending entries
   std::vector<PendingAdd> adds;
   int64_t stream = 0;
+  int device = 0;                    // the stream's device (the callback may run elsewhere)
   bool callback_queued = false;
 };
+
+// Runs `fn` with `device` current (kernel launches need the stream's device), restores after.
+template <class F>
+void on_device(int device, F&& fn) {
+  int cur = device;
+  (void)hipGetDevice(&cur);
+  if (cur != device) (void)hipSetDevice(device);
+  fn();
+  if (cur != device) (void)hipSetDevice(cur);
+}
 std::mutex g_def_mu;
 Deferred g_def;
 
@@ -226,9 +237,11 @@ void flush_deferred() {
     std::swap(d, g_def);
   }
   if (d.pending.empty()) return;
-  check(g_lib.bwd_finalize(d.pending.data(), static_cast<int32_t>(d.pending.size()),
-                           reinterpret_cast<void*>(d.stream)),
-        "adapter_bwd_finalize");
+  on_device(d.device, [&] {
+    check(g_lib.bwd_finalize(d.pending.data(), static_cast<int32_t>(d.pending.size()),
+                             reinterpret_cast<void*>(d.stream)),
+          "adapter_bwd_finalize");
+  });
   at::NoGradGuard no_grad;
   for (auto& a : d.adds) a.param.mutable_grad().add_(a.grad);
 }
@@ -319,12 +332,15 @@ struct AdapterFnDirect : public torch::autograd::Function<AdapterFnDirect> {
         Deferred other;
         std::swap(other, g_def);
         g_def.callback_queued = other.callback_queued;
-        check(g_lib.bwd_finalize(other.pending.data(), static_cast<int32_t>(other.pending.size()),
-                                 reinterpret_cast<void*>(other.stream)),
-              "adapter_bwd_finalize");
+        on_device(other.device, [&] {
+          check(g_lib.bwd_finalize(other.pending.data(), static_cast<int32_t>(other.pending.size()),
+                                   reinterpret_cast<void*>(other.stream)),
+                "adapter_bwd_finalize");
+        });
         for (auto& a : other.adds) a.param.mutable_grad().add_(a.grad);
       }
       g_def.stream = stream;
+      g_def.device = x.get_device();
       g_def.pending.push_back(pend);
       g_def.keep.push_back(ws);
       deposit_grad(pk->w_down, std::move(gwd), g_def);
