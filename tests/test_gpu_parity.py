@@ -331,6 +331,17 @@ def test_adapter_tile_path_large_components(dev):
         _check_workload(dev, batch, 300, 8, flags)
 
 
+def test_adapter_many_tiles_per_workgroup(dev):
+    """1500 molecules = ~1200 component tiles on 256 persistent workgroups: every workgroup walks
+    4-5 tiles (boustrophedon passes over the size-sorted tile list, spans requested a pass
+    ahead, accumulators carried across tiles) — vs the fp64 oracle."""
+    batch = ga.synth.molecule_batch("hiv", 1500, hidden=300, seed=21)
+    plan = ga.GraphPlan(batch.edge_index.to(dev), batch.num_nodes, True)
+    assert plan.n_tiles > 4 * 256
+    flags = oracle.AdapterFlags(learnable_scalar=True, normalize=True)
+    _check_workload(dev, batch, 300, 8, flags, seed=5)
+
+
 def test_adapter_cora_3d_input(dev):
     batch, cfg = ga.synth.make_workload("cora")
     assert batch.x.dim() == 3
