@@ -4,7 +4,7 @@
 // into component tiles that no edge crosses (gconv_graph_t::tile_ptr). ONE workgroup then
 // runs the whole adapter for its tile — the three rank-width intermediates (H0', H2', P,
 // resp. dP', dH1', T) never leave LDS, the grid-wide dependencies of the four-launch path
-// become __syncthreads(), and X is read from HBM once (its second read, for the
+// become lds_barrier(), and X is read from HBM once (its second read, for the
 // residual, comes out of L2 a few microseconds later):
 //
 //   forward   phase 1  H0' = dis . (X_t Wd^T)                   MFMA, A layout, W_d frags in LDS
@@ -45,6 +45,15 @@ namespace gconv {
 namespace {
 
 __device__ __forceinline__ f32x4 zero4f() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+// Workgroup barrier for LDS hand-offs only. hipcc's __syncthreads() is a workgroup-scope fence
+// plus s_barrier and drains vmcnt as well: every global request in flight — the phase-4 tiles
+// requested two phases early, a neighbour wave's refills — would have to land at each of the
+// five barriers of a tile. Nothing in these kernels passes data between waves through global
+// memory, so only LDS traffic (lgkmcnt) has to be complete.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 template <int FP>
 __device__ __forceinline__ int rank_k_(int s, int t) {
@@ -354,7 +363,7 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
   TILE_STAMP(11);
 #pragma unroll
   for (int k = 0; k < 4; ++k) bdv[k] = (a.b_down && 4 * sub + k < a.r) ? bdv[k] : 0.f;
-  __syncthreads();
+  lds_barrier();
 
   TILE_STAMP(0);
   // tiles are dealt from the size-sorted list boustrophedon: pass 0 gives workgroup w the
@@ -391,7 +400,7 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
     tile_rowsA<FP, NQ, NORM, false>(rx, a.x, wl, bufA, a.dis, nullptr, 1.f, ts, nt, a.d, rowb, nwaves, wave,
                                     lane, [&]() { csr.advance(); });
     csr.finish();
-    __syncthreads();
+    lds_barrier();
     TILE_STAMP(2);
 
     // phase 4's first two X tiles are requested now: their latency passes under phases 2 / 3.
@@ -417,7 +426,7 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
       *reinterpret_cast<f32x4*>(bufB + lr * FP + 4 * sub) = v;
       stg4(a.saved_h + off, v);
     }
-    __syncthreads();
+    lds_barrier();
 
     TILE_STAMP(3);
     // ---- phase 3: P -> bufA (+ saved_p)
@@ -426,7 +435,7 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
       *reinterpret_cast<f32x4*>(bufA + lr * FP + 4 * sub) = v;
       stg4(a.saved_p + static_cast<size_t>(ts + lr) * FP + 4 * sub, v);
     }
-    __syncthreads();
+    lds_barrier();
 
     TILE_STAMP(4);
     // ---- phase 4: out = s (P Wu^T + bu + X); two X tiles per wave in flight. Everything
@@ -463,7 +472,7 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
         if (b >= nb4) break;
       }
     }
-    __syncthreads();  // bufA / bufB are reused by the next tile
+    lds_barrier();  // bufA / bufB are reused by the next tile
     TILE_STAMP(5);
   }
 }
@@ -540,7 +549,7 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
   float cs = 0.f;                      // colsum(G)[col]
   f32x4 bgrad = zero4f();
   float ds1 = 0.f, dsx = 0.f;
-  __syncthreads();
+  lds_barrier();
 
   TILE_STAMP(0);
   // tiles are dealt from the size-sorted list boustrophedon: pass 0 gives workgroup w the
@@ -597,7 +606,7 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
 #pragma unroll
       for (int k = 0; k < 4; ++k) bufC[(4 * sb + k) * a.cap + lr] = pv[k];
     }
-    __syncthreads();
+    lds_barrier();
 
     TILE_STAMP(2);
     // phase 4's first two (G, X) tile pairs are requested now: their latency passes under
@@ -633,7 +642,7 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
       if (NORM) v *= dl[lr];
       *reinterpret_cast<f32x4*>(bufB + lr * FP + 4 * sub) = v;
     }
-    __syncthreads();
+    lds_barrier();
 
     TILE_STAMP(3);
     // ---- phase 3: T = S^T dH1 -> bufA (row-major: the dX operand) and bufD (rank-major:
@@ -647,7 +656,7 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
 #pragma unroll
       for (int k = 0; k < 4; ++k) bufD[(4 * sub + k) * a.cap + lr] = v[k];
     }
-    __syncthreads();
+    lds_barrier();
 
     TILE_STAMP(4);
     // ---- phase 4 (owner waves): dX = T Wd + s G ; dWd^T += T^T X ; dWu^T += P^T G ;
@@ -713,7 +722,7 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
         for (int b = slot; b < nb4; b += nslots) step(b, ga, xa, b + nslots);
       }
     }
-    __syncthreads();  // bufA / bufB are reused by the next tile
+    lds_barrier();  // bufA / bufB are reused by the next tile
     TILE_STAMP(5);
   }
 
@@ -733,7 +742,7 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
         }
       sl[2 * FP * 64] = cs;
     }
-    __syncthreads();
+    lds_barrier();
     if (primary) {
       for (int s = 1; s < nslots; ++s) {
         const float* sl = slabs + ((s - 1) * nchunks + jr) * kSlab + lane;
@@ -747,7 +756,7 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
         cs += sl[2 * FP * 64];
       }
     }
-    __syncthreads();  // the slabs may overlap the reduction scratch used below
+    lds_barrier();  // the slabs may overlap the reduction scratch used below
   }
 
   // ---- one partial row per workgroup (primary owners): lane = column, register = rank row
@@ -778,7 +787,7 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
     for (int k = 0; k < 4; ++k) red[wave * (FP + 2) + 4 * lane + k] = bgrad[k];
   }
   if (lane == 0) red[wave * (FP + 2) + FP] = dsum;
-  __syncthreads();
+  lds_barrier();
   if (threadIdx.x < FP) {
     float v = 0.f;
     for (int w = 0; w < nwaves; ++w) v += red[w * (FP + 2) + threadIdx.x];
