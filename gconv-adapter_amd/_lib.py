@@ -106,6 +106,9 @@ SIGNATURES = {
                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                                              C.POINTER(PendingFinalize), _vp]),
     "gconv_adapter_bwd_finalize_f32": (_i32, [C.POINTER(PendingFinalize), _i32, _vp]),
+    "gconv_collate_workspace_bytes": (_sz, [_i32]),
+    "gconv_collate_f32": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, C.c_int64, _vp, _vp, _vp, _vp,
+                                 _vp, _sz, _vp]),
     "gconv_adam_step_f32": (_i32, [_vp, _vp, _vp, _vp, C.c_int64, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_float, C.c_int64, _vp]),
 }

@@ -261,6 +261,25 @@ gconv_status_t gconv_adapter_bwd_finalize_f32(const gconv_pending_finalize_t* pe
  * torch's update rule and operation order; `step` is the 1-based step count of this call
  * (bias corrections are computed from it in double on the host, as torch does). All four
  * arrays have `count` floats; param / exp_avg / exp_avg_sq are updated in place.            */
+/* ---- next to the path: collation of a batch from a device-resident dataset -----
+ * replaces: PyG `DataLoader` -> `Batch.from_data_list` -> `batch.to(device)`
+ *   (`scripts/finetune_inductive_learning.py:291-293,45`) for datasets kept in HBM: the chosen
+ * graphs' feature rows are concatenated, their (graph-local) edge ids offset and widened to
+ * int64 [2, E], the graph offsets and the node -> graph vector written; two launches, no
+ * synchronisation. Dataset layout: graphs back to back, `node_ptr` / `edge_ptr` [G + 1] device
+ * int32 offsets, `edge_src` / `edge_dst` graph-LOCAL node ids with each graph's edges contiguous.
+ * `num_edges_out` (= sum of the chosen graphs' edge counts, known to the host from its copy of
+ * edge_ptr) is the row stride of `edge_index_out`; `x_out` has sum-of-nodes rows of `hidden`
+ * floats; `batch_out` (node -> position in the batch) is optional.                             */
+size_t gconv_collate_workspace_bytes(int32_t num_graphs);
+gconv_status_t gconv_collate_f32(const float* x_all, int32_t hidden, const int32_t* node_ptr,
+                                 const int32_t* edge_ptr, const int32_t* edge_src,
+                                 const int32_t* edge_dst, const int32_t* graph_ids,
+                                 int32_t num_graphs, int64_t num_edges_out, float* x_out,
+                                 int64_t* edge_index_out, int32_t* graph_ptr_out,
+                                 int32_t* batch_out, void* workspace, size_t workspace_bytes,
+                                 gconv_stream_t stream);
+
 gconv_status_t gconv_adam_step_f32(float* param, const float* grad, float* exp_avg,
                                    float* exp_avg_sq, int64_t count, float lr, float beta1,
                                    float beta2, float eps, float weight_decay, int64_t step,

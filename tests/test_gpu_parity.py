@@ -579,6 +579,40 @@ def test_plan_cache_shared_across_adapters(dev):
 # ---------------------------------------------------------------------------
 # Full benchmark size: size-independent properties (oracle too slow / fp64 too big)
 # ---------------------------------------------------------------------------
+def test_device_collation_equals_cpu_collation(dev):
+    """MoleculeStore.collate (two launches on the device) == concatenating the chosen graphs on
+    the CPU the way PyG's Batch.from_data_list does: bit-exact features, edge ids, offsets and
+    node -> graph vector; repeated and empty selections; the adapter runs on the result."""
+    whole = ga.synth.molecule_batch("hiv", 300, hidden=64, seed=13)
+    store = ga.MoleculeStore.from_batch(whole, dev)
+    ptr = whole.graph_ptr
+    src, dst = whole.edge_index
+    gid = torch.bucketize(dst, ptr[1:], right=True)
+    g = torch.Generator().manual_seed(1)
+    for ids in (torch.randperm(300, generator=g)[:77].tolist(), [5, 5, 299, 0], list(range(300)), []):
+        xs, es, gp, bv = [], [], [0], []
+        for p, k in enumerate(ids):
+            n0, n1 = int(ptr[k]), int(ptr[k + 1])
+            m = gid == k                                    # the graph's edges, in dataset order
+            xs.append(whole.x[n0:n1])
+            es.append(torch.stack([src[m], dst[m]]) - n0 + gp[-1])
+            bv += [p] * (n1 - n0)
+            gp.append(gp[-1] + n1 - n0)
+        want_x = torch.cat(xs) if xs else torch.empty(0, 64)
+        want_e = torch.cat(es, dim=1) if es else torch.empty(2, 0, dtype=torch.long)
+        batch, bvec = store.collate(ids, with_batch_vector=True)
+        assert torch.equal(batch.x.cpu(), want_x) and torch.equal(batch.edge_index.cpu(), want_e)
+        assert batch.graph_ptr.cpu().tolist() == gp and bvec.cpu().tolist() == bv
+    ids = torch.randperm(300, generator=g)[:64].tolist()
+    batch = store.collate(ids, normalize=True)               # plan prefetched
+    mod = ga.GConvAdapter(64, 4, learnable_scalar=True).to(dev)
+    out = mod(batch.x, batch.edge_index)
+    ref = mod(batch.x.clone(), batch.edge_index.clone())     # same inputs, plan built directly
+    assert torch.equal(out, ref)
+    with pytest.raises(RuntimeError):
+        store.collate([300])
+
+
 def test_fused_adam_matches_torch_adam(dev):
     """FusedAdam (one launch per group over flat buffers) vs torch.optim.Adam on the CPU in
     fp64 and on the GPU in fp32: two parameter groups with their own lr / weight decay (the
