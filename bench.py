@@ -48,6 +48,7 @@ import torch.distributed as dist  # noqa: E402
 
 import gconv_adapter_amd as ga  # noqa: E402
 
+RESIDENT = 0
 _FULL_AFFINITY = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
 _PINNED = []
 
@@ -115,6 +116,35 @@ class BatchStream:
         return batch, x, ei, gout
 
 
+class StoreStream:
+    """`--resident`: the whole dataset lives in HBM (`MoleculeStore`); every step draws a fresh
+    random batch, collates it on the device and assembles its graph plan from the dataset's plan
+    (no sort, no host synchronisation) — an epoch of the reference's shuffled DataLoader without
+    the CPU collation and the H2D copies."""
+    fresh = False   # (plans are registered by the store; nothing to prefetch or discard)
+
+    def __init__(self, name: str, rank: int, device, dataset_graphs: int):
+        import numpy as np
+        cfg = dict(ga.synth.WORKLOADS[name])
+        whole = ga.synth.molecule_batch(cfg["mol"], dataset_graphs, hidden=cfg["d"], seed=rank * 1000)
+        self.store = ga.MoleculeStore.from_batch(whole, device)
+        self.cfg, self.per_batch = cfg, cfg["graphs"]
+        self.rng = np.random.default_rng(rank)
+        biggest = int((whole.graph_ptr[1:] - whole.graph_ptr[:-1]).sort().values[-self.per_batch:].sum())
+        self.gout_all = torch.randn(biggest, cfg["d"], generator=torch.Generator().manual_seed(2)).to(device)
+        self.nodes = self.edges = self.count = 0
+        self.store._dataset_plan(True); self.store._dataset_plan(False)
+
+    def avg(self, attr) -> float:
+        return {"num_graphs": self.per_batch, "num_nodes": self.nodes / max(self.count, 1)}[attr]
+
+    def next(self, normalize: bool):
+        ids = self.rng.choice(self.store.num_graphs, self.per_batch, replace=False)
+        batch = self.store.collate(ids, normalize=normalize)
+        self.nodes += batch.num_nodes; self.edges += batch.edge_index.shape[1]; self.count += 1
+        return batch, batch.x, batch.edge_index, self.gout_all[:batch.num_nodes]
+
+
 def adapter_step(mods, params, stream: BatchStream, normalize: bool, bucket=None):
     """fwd + bwd of the adapter chain on the next batch (+ gradient all-reduce)."""
     batch, x, ei, gout = stream.next(normalize)
@@ -126,7 +156,7 @@ def adapter_step(mods, params, stream: BatchStream, normalize: bool, bucket=None
     h.backward(gout)
     if bucket is not None:
         bucket.all_reduce_grads()   # one cat + ONE flat all-reduce + one multi-tensor copy
-    if stream.fresh:
+    if stream.fresh or isinstance(stream, StoreStream):
         ga.PLAN_CACHE.discard(ei, x.shape[-2], normalize)   # a training batch is seen once
     return batch.num_graphs
 
@@ -374,7 +404,10 @@ def cpu_baseline(batch, cfg: dict, normalize: bool, budget_s: float = 20.0) -> d
 def run_workload(name: str, normalize: bool, steps: int, warmup: int, rank: int, world: int,
                  device, with_cpu: bool) -> dict:
     fresh = ga.synth.WORKLOADS[name]["kind"] == "molecule"   # transductive graphs are static
-    stream = BatchStream(name, rank, device, k=4, fresh=fresh)
+    if RESIDENT and fresh:
+        stream = StoreStream(name, rank, device, RESIDENT)
+    else:
+        stream = BatchStream(name, rank, device, k=4, fresh=fresh)
     cfg = stream.cfg
     mods = build_adapters(cfg, normalize, device)
     params = list(mods.parameters())
@@ -390,11 +423,16 @@ def run_workload(name: str, normalize: bool, steps: int, warmup: int, rank: int,
     graphs[0] = 0
     dt = timed_steps(step, steps, warmup, world, device)
     ga.PLAN_CACHE.clear()
-    batch0 = stream.items[0][0]
+    if isinstance(stream, StoreStream):
+        batch0 = ga.synth.molecule_batch(cfg["mol"], cfg["graphs"], hidden=cfg["d"], seed=rank * 1000)
+        edges = round(stream.edges / max(stream.count, 1))
+    else:
+        batch0 = stream.items[0][0]
+        edges = round(sum(b.edge_index.shape[1] for b, *_ in stream.items) / len(stream.items))
     graphs_per_step = stream.avg("num_graphs")
     res = {"value": graphs_per_step * world * steps / dt, "ms_per_step": dt / steps * 1e3, "cfg": cfg,
            "nodes_per_rank": round(stream.avg("num_nodes")),
-           "edges_per_rank": round(sum(b.edge_index.shape[1] for b, *_ in stream.items) / len(stream.items)),
+           "edges_per_rank": edges,
            "graphs_per_rank": round(graphs_per_step), "settle_steps": settled}
     if with_cpu:
         res["cpu"] = cpu_baseline(batch0, cfg, normalize)
@@ -412,7 +450,12 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--banded", action="store_true", help="also time the SpMM on a banded 1M-node graph")
+    ap.add_argument("--resident", type=int, default=0, metavar="G",
+                    help="keep a G-molecule dataset in HBM and draw a fresh random batch every step "
+                         "(device-side collation + plan assembly) instead of rotating 4 fixed batches")
     args = ap.parse_args()
+    global RESIDENT
+    RESIDENT = args.resident
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

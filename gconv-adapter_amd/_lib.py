@@ -109,6 +109,9 @@ SIGNATURES = {
     "gconv_collate_workspace_bytes": (_sz, [_i32]),
     "gconv_collate_f32": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, C.c_int64, _vp, _vp, _vp, _vp,
                                  _vp, _sz, _vp]),
+    "gconv_graph_from_store_bytes": (_sz, [_i32, C.c_int64, _i32]),
+    "gconv_graph_from_store": (_i32, [_graph_p, _vp, _vp, _vp, _i32, _i32, C.c_int64, _i32, _vp, _sz,
+                                      _graph_p, _vp]),
     "gconv_adam_step_f32": (_i32, [_vp, _vp, _vp, _vp, C.c_int64, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_float, C.c_int64, _vp]),
 }

@@ -10,6 +10,8 @@
 // Dataset layout (built once by gconv_adapter_amd.data.MoleculeStore): graphs stored back to
 // back; node_ptr / edge_ptr [G + 1] are their node / edge offsets; edge_src / edge_dst hold
 // LOCAL node ids, each graph's edges contiguous, in the graph's own edge order.
+#include <hipcub/hipcub.hpp>
+
 #include "common.h"
 
 namespace gconv {
@@ -80,9 +82,141 @@ __global__ __launch_bounds__(256) void collate_copy_kernel(
   }
 }
 
+// ---- graph plan of a collated batch, assembled from the dataset's plan (no sort, no sync) ----
+// one workgroup per chosen graph: CSR rows re-based, columns offset, dis copied
+__global__ __launch_bounds__(256) void plan_copy_kernel(
+    const int32_t* __restrict__ rowptr_all, const int32_t* __restrict__ col_all,
+    const float* __restrict__ dis_all, const int32_t* __restrict__ node_ptr,
+    const int32_t* __restrict__ ids, const int32_t* __restrict__ noff, const int32_t* __restrict__ eoff,
+    int32_t* __restrict__ rowptr_b, int32_t* __restrict__ col_b, float* __restrict__ dis_b, int nb) {
+  const int p = blockIdx.x;
+  const int g = ids[p];
+  const int n0 = node_ptr[g], nn = node_ptr[g + 1] - n0, no = noff[p], eo = eoff[p];
+  const int r0 = rowptr_all[n0], ne = rowptr_all[n0 + nn] - r0;
+  for (int i = threadIdx.x; i < nn; i += 256) {
+    rowptr_b[no + i] = rowptr_all[n0 + i] - r0 + eo;
+    if (dis_b) dis_b[no + i] = dis_all[n0 + i];
+  }
+  for (int k = threadIdx.x; k < ne; k += 256) col_b[eo + k] = col_all[r0 + k] - n0 + no;
+  if (p == nb - 1 && threadIdx.x == 0) rowptr_b[no + nn] = eo + ne;
+}
+
+// tile t starts at the last graph boundary at or below t * GCONV_TILE_NODES (graphs are the
+// components: no edge crosses a graph boundary); spans + size keys for the size sort
+__global__ void plan_tiles_kernel(const int32_t* __restrict__ noff, int nb, int n, int ntiles,
+                                  int32_t* __restrict__ tile_ptr) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > ntiles) return;
+  if (t == ntiles) { tile_ptr[t] = n; return; }
+  const int q = t * GCONV_TILE_NODES;
+  int lo = 0, hi = nb;                       // largest p with noff[p] <= q  (noff[0] = 0)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (noff[mid] <= q) lo = mid; else hi = mid - 1;
+  }
+  tile_ptr[t] = noff[lo];
+}
+__global__ void plan_spans_kernel(const int32_t* __restrict__ tile_ptr, int ntiles,
+                                  uint32_t* __restrict__ size_key, uint64_t* __restrict__ tile_span) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntiles) return;
+  const int sz = tile_ptr[t + 1] - tile_ptr[t];
+  size_key[t] = static_cast<uint32_t>(1023 - min(sz, 1023));
+  tile_span[t] = static_cast<uint64_t>(static_cast<uint32_t>(tile_ptr[t])) |
+                 (static_cast<uint64_t>(static_cast<uint32_t>(sz)) << 32);
+}
+
+struct StoreLayout {
+  size_t rowptr, col, dis, tile_ptr, tile_order, key, key_out, span, noff, cub, total, cub_bytes;
+  int ntiles;
+};
+static StoreLayout store_layout(int32_t n, int64_t nnz, int32_t nb) {
+  StoreLayout L{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes + 16, 256); return o; };
+  L.ntiles = ceil_div(n > 0 ? n : 1, GCONV_TILE_NODES);
+  L.rowptr = take((static_cast<size_t>(n) + 1) * 4);
+  L.col = take(static_cast<size_t>(nnz > 0 ? nnz : 1) * 4);
+  L.dis = take((static_cast<size_t>(n) + 1) * 4);
+  L.tile_ptr = take((static_cast<size_t>(L.ntiles) + 1) * 4);
+  L.tile_order = take(static_cast<size_t>(L.ntiles) * 8);
+  L.key = take(static_cast<size_t>(L.ntiles) * 4);
+  L.key_out = take(static_cast<size_t>(L.ntiles) * 4);
+  L.span = take(static_cast<size_t>(L.ntiles) * 8);
+  L.noff = take(2 * (static_cast<size_t>(nb) + 1) * 4);
+  size_t cb = 0;
+  hipcub::DeviceRadixSort::SortPairs(nullptr, cb, static_cast<const uint32_t*>(nullptr),
+                                     static_cast<uint32_t*>(nullptr), static_cast<const uint64_t*>(nullptr),
+                                     static_cast<uint64_t*>(nullptr), L.ntiles, 0, 10, nullptr);
+  L.cub_bytes = cb;
+  L.cub = take(cb + 256);
+  L.total = off;
+  return L;
+}
+
 }  // namespace gconv
 
 using namespace gconv;
+
+extern "C" size_t gconv_graph_from_store_bytes(int32_t num_nodes, int64_t nnz, int32_t num_graphs) {
+  if (num_nodes < 0 || nnz < 0 || num_graphs < 0) return 0;
+  return store_layout(num_nodes, nnz, num_graphs).total;
+}
+
+extern "C" gconv_status_t gconv_graph_from_store(const gconv_graph_t* dataset, const int32_t* node_ptr,
+                                                 const int32_t* nnz_ptr, const int32_t* graph_ids,
+                                                 int32_t num_graphs, int32_t num_nodes, int64_t nnz,
+                                                 int32_t max_graph_nodes, void* arena_, size_t arena_bytes,
+                                                 gconv_graph_t* g, gconv_stream_t stream_) {
+  if (!dataset || !g || !arena_ || num_graphs <= 0 || num_nodes <= 0 || nnz < 0) return GCONV_E_INVALID_ARG;
+  if (!node_ptr || !nnz_ptr || !graph_ids) return GCONV_E_INVALID_ARG;
+  // the shortcut needs what molecule datasets have: a symmetric edge list and no long rows
+  if (!dataset->symmetric || dataset->fwd.n_long != 0) return GCONV_E_UNSUPPORTED;
+  if (!aligned16(arena_)) return GCONV_E_ALIGNMENT;
+  const StoreLayout L = store_layout(num_nodes, nnz, num_graphs);
+  if (arena_bytes < L.total) return GCONV_E_WORKSPACE;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  char* arena = static_cast<char*>(arena_);
+  int32_t* rowptr = reinterpret_cast<int32_t*>(arena + L.rowptr);
+  int32_t* col = reinterpret_cast<int32_t*>(arena + L.col);
+  float* dis = dataset->normalize ? reinterpret_cast<float*>(arena + L.dis) : nullptr;
+  int32_t* tile_ptr = reinterpret_cast<int32_t*>(arena + L.tile_ptr);
+  int32_t* noff = reinterpret_cast<int32_t*>(arena + L.noff);
+  int32_t* eoff = noff + num_graphs + 1;
+  collate_offsets_kernel<<<1, 1024, 0, stream>>>(node_ptr, nnz_ptr, graph_ids, num_graphs, noff, eoff);
+  GCONV_LAUNCH_CHECK();
+  plan_copy_kernel<<<num_graphs, 256, 0, stream>>>(dataset->fwd.rowptr, dataset->fwd.col, dataset->dis, node_ptr,
+                                                   graph_ids, noff, eoff, rowptr, col, dis, num_graphs);
+  GCONV_LAUNCH_CHECK();
+  const int T = 256;
+  plan_tiles_kernel<<<(L.ntiles + 1 + T - 1) / T, T, 0, stream>>>(noff, num_graphs, num_nodes, L.ntiles, tile_ptr);
+  GCONV_LAUNCH_CHECK();
+  plan_spans_kernel<<<(L.ntiles + T - 1) / T, T, 0, stream>>>(
+      tile_ptr, L.ntiles, reinterpret_cast<uint32_t*>(arena + L.key), reinterpret_cast<uint64_t*>(arena + L.span));
+  GCONV_LAUNCH_CHECK();
+  size_t cub_bytes = L.cub_bytes;
+  GCONV_HIP(hipcub::DeviceRadixSort::SortPairs(
+      arena + L.cub, cub_bytes, reinterpret_cast<const uint32_t*>(arena + L.key),
+      reinterpret_cast<uint32_t*>(arena + L.key_out), reinterpret_cast<const uint64_t*>(arena + L.span),
+      reinterpret_cast<uint64_t*>(arena + L.tile_order), L.ntiles, 0, 10, stream));
+  *g = gconv_graph_t{};
+  g->fwd.num_nodes = num_nodes; g->fwd.nnz = static_cast<int32_t>(nnz);
+  g->fwd.rowptr = rowptr; g->fwd.col = col;
+  g->bwd = g->fwd;
+  g->dis = dis;
+  g->tile_ptr = tile_ptr;
+  g->tile_order = reinterpret_cast<int32_t*>(arena + L.tile_order);
+  g->n_tiles = L.ntiles;
+  // upper bounds known without reading anything back: a tile starts at most
+  // GCONV_TILE_NODES - 1 nodes before its nominal start and ends inside the graph that covers
+  // its nominal end (they only size the LDS of the fused kernels)
+  const int bound = GCONV_TILE_NODES + max_graph_nodes;
+  g->tile_nodes_max = bound < num_nodes ? bound : num_nodes;
+  const int64_t eb = static_cast<int64_t>(g->tile_nodes_max) * (dataset->max_degree > 0 ? dataset->max_degree : 1);
+  g->tile_edges_max = static_cast<int32_t>(eb < nnz ? eb : nnz);
+  g->symmetric = 1; g->normalize = dataset->normalize; g->max_degree = dataset->max_degree; g->bad_index = 0;
+  return GCONV_OK;
+}
 
 extern "C" size_t gconv_collate_workspace_bytes(int32_t num_graphs) {
   return num_graphs < 0 ? 0 : align_up(2 * (static_cast<size_t>(num_graphs) + 1) * sizeof(int32_t), 256);

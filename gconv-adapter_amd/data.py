@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from .functional import _stream
-from .graph import prefetch_plan
+from .graph import GraphPlan, PLAN_CACHE, prefetch_plan
 from .synth import GraphBatch
 
 
@@ -42,6 +42,8 @@ class MoleculeStore:
         self.edge_dst = edge_dst.to(device=self.device, dtype=torch.int32).contiguous()
         self.num_graphs = int(node_ptr.numel()) - 1
         self._lib = _lib.load()
+        self._edge_index_all = None     # set by from_batch: global-id edge list of the dataset
+        self._ds_plans = {}             # normalize -> (dataset GraphPlan, nnz_ptr device, nnz_ptr host)
 
     @classmethod
     def from_batch(cls, batch: GraphBatch, device) -> "MoleculeStore":
@@ -54,7 +56,23 @@ class MoleculeStore:
         src, dst, gid = src[order], dst[order], gid[order]
         edge_ptr = torch.zeros(ptr.numel(), dtype=torch.long)
         edge_ptr[1:] = torch.bincount(gid, minlength=ptr.numel() - 1).cumsum(0)
-        return cls(batch.x.to(device), ptr, edge_ptr, src - ptr[gid], dst - ptr[gid])
+        store = cls(batch.x.to(device), ptr, edge_ptr, src - ptr[gid], dst - ptr[gid])
+        store._edge_index_all = torch.stack([src, dst]).to(device)
+        return store
+
+    def _dataset_plan(self, normalize: bool):
+        """Plan of the whole dataset's edge list (ONE gconv_graph_build, at first use): the source
+        of every batch plan. None if the dataset does not qualify for the shortcut."""
+        hit = self._ds_plans.get(normalize)
+        if hit is None:
+            hit = (None, None, None)
+            if self._edge_index_all is not None and int(self.node_ptr_host[-1]) > 0:
+                plan = GraphPlan(self._edge_index_all, int(self.node_ptr_host[-1]), normalize)
+                if plan.symmetric and plan.fwd.n_long == 0:
+                    nnz_ptr = plan.fwd.rowptr[self.node_ptr.long()].contiguous()
+                    hit = (plan, nnz_ptr, nnz_ptr.cpu().numpy().astype(np.int64))
+            self._ds_plans[normalize] = hit
+        return hit
 
     def collate(self, graph_ids: Sequence[int], with_batch_vector: bool = False,
                 normalize: Optional[bool] = None):
@@ -83,5 +101,29 @@ class MoleculeStore:
         _lib.check(st, "collate")
         batch = GraphBatch(x=x, edge_index=ei, graph_ptr=gptr, num_graphs=nb)
         if normalize is not None and n_out > 0:
-            prefetch_plan(ei, n_out, normalize)
+            self._plan_for(ei, ids, ids_host, n_out, bool(normalize))
         return (batch, bvec) if with_batch_vector else batch
+
+    def _plan_for(self, ei, ids, ids_host, n_out: int, normalize: bool) -> None:
+        """Graph plan of the collated batch, registered for `ei` in the plan cache. Assembled from
+        the dataset's plan (no sort, no synchronisation) when the dataset allows it, otherwise
+        built from the edge list on the prefetch worker."""
+        ds, nnz_ptr, nnz_host = self._dataset_plan(normalize)
+        if ds is None:
+            prefetch_plan(ei, n_out, normalize)
+            return
+        nb = int(ids_host.size)
+        nnz = int((nnz_host[ids_host + 1] - nnz_host[ids_host]).sum())
+        biggest = int((self.node_ptr_host[ids_host + 1] - self.node_ptr_host[ids_host]).max())
+        nbytes = int(self._lib.gconv_graph_from_store_bytes(n_out, nnz, nb))
+        arena = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        out = _lib.GraphStruct()
+        import ctypes as C
+        st = self._lib.gconv_graph_from_store(ds.ref(), self.node_ptr.data_ptr(), nnz_ptr.data_ptr(),
+                                              ids.data_ptr(), nb, n_out, nnz, biggest, arena.data_ptr(), nbytes,
+                                              C.byref(out), _stream(self.device.index))
+        if st == -2:   # GCONV_E_UNSUPPORTED
+            prefetch_plan(ei, n_out, normalize)
+            return
+        _lib.check(st, "graph_from_store")
+        PLAN_CACHE.put(ei, n_out, normalize, GraphPlan(ei, n_out, normalize, _built=(arena, out, 0)))

@@ -77,9 +77,12 @@ class GraphPlan:
         self.num_edges = int(ei.shape[1])
         self.device = ei.device
         self.struct = _lib.GraphStruct()
-        if _built is not None:   # (arena, gconv_graph_t bytes, status) from the native prefetch worker
+        if _built is not None:   # (arena, gconv_graph_t bytes | GraphStruct, status): built elsewhere
             self.arena, raw, st = _built
-            C.memmove(C.addressof(self.struct), raw, C.sizeof(self.struct))
+            if isinstance(raw, _lib.GraphStruct):
+                C.memmove(C.addressof(self.struct), C.addressof(raw), C.sizeof(self.struct))
+            else:
+                C.memmove(C.addressof(self.struct), raw, C.sizeof(self.struct))
         else:
             with torch.cuda.device(ei.device):
                 nbytes = int(lib.gconv_graph_build_bytes(self.num_edges, self.num_nodes))
@@ -197,6 +200,10 @@ class PlanCache:
             plan = GraphPlan(edge_index, num_nodes, normalize)
         self._store(key, edge_index, plan)
         return plan
+
+    def put(self, edge_index: torch.Tensor, num_nodes: int, normalize: bool, plan: GraphPlan) -> None:
+        """Registers a plan that was built elsewhere (``data.MoleculeStore``) for this tensor."""
+        self._store(self._key(edge_index, num_nodes, normalize), edge_index, plan)
 
     def prefetch(self, edge_index: torch.Tensor, num_nodes: int, normalize: bool) -> None:
         """Starts building the plan of a future batch; returns immediately."""

@@ -280,6 +280,22 @@ gconv_status_t gconv_collate_f32(const float* x_all, int32_t hidden, const int32
                                  int32_t* batch_out, void* workspace, size_t workspace_bytes,
                                  gconv_stream_t stream);
 
+/* The graph plan of such a batch without building it: `dataset` is the plan of the WHOLE
+ * dataset's edge list (one gconv_graph_build at load time); the chosen graphs' CSR rows are
+ * re-based, their columns offset, `dis` copied, tiles cut at graph boundaries and sorted by size.
+ * No sort of the edges, no host synchronisation: `*graph_host_out` is complete when the call
+ * returns, its arrays when `stream` reaches this point. `nnz_ptr[g]` = dataset rowptr at graph
+ * g's first node ([G + 1], device); `num_nodes`, `nnz`, `max_graph_nodes` (largest chosen graph)
+ * come from the host's copy of the dataset offsets. Needs what molecule datasets have — a
+ * symmetric edge list and no row above GCONV_LONG_ROW edges — else GCONV_E_UNSUPPORTED
+ * (use gconv_graph_build on the collated edge_index).                                         */
+size_t gconv_graph_from_store_bytes(int32_t num_nodes, int64_t nnz, int32_t num_graphs);
+gconv_status_t gconv_graph_from_store(const gconv_graph_t* dataset, const int32_t* node_ptr,
+                                      const int32_t* nnz_ptr, const int32_t* graph_ids,
+                                      int32_t num_graphs, int32_t num_nodes, int64_t nnz,
+                                      int32_t max_graph_nodes, void* arena, size_t arena_bytes,
+                                      gconv_graph_t* graph_host_out, gconv_stream_t stream);
+
 gconv_status_t gconv_adam_step_f32(float* param, const float* grad, float* exp_avg,
                                    float* exp_avg_sq, int64_t count, float lr, float beta1,
                                    float beta2, float eps, float weight_decay, int64_t step,

@@ -603,12 +603,37 @@ def test_device_collation_equals_cpu_collation(dev):
         batch, bvec = store.collate(ids, with_batch_vector=True)
         assert torch.equal(batch.x.cpu(), want_x) and torch.equal(batch.edge_index.cpu(), want_e)
         assert batch.graph_ptr.cpu().tolist() == gp and bvec.cpu().tolist() == bv
+    # the batch's graph plan, assembled from the dataset's plan (no sort, no sync) == the plan
+    # gconv_graph_build makes of the collated edge list
     ids = torch.randperm(300, generator=g)[:64].tolist()
-    batch = store.collate(ids, normalize=True)               # plan prefetched
-    mod = ga.GConvAdapter(64, 4, learnable_scalar=True).to(dev)
-    out = mod(batch.x, batch.edge_index)
-    ref = mod(batch.x.clone(), batch.edge_index.clone())     # same inputs, plan built directly
-    assert torch.equal(out, ref)
+    for normalize in (True, False):
+        ga.PLAN_CACHE.clear()
+        batch = store.collate(ids, normalize=normalize)
+        fast = ga.get_plan(batch.edge_index, batch.num_nodes, normalize)
+        assert ga.PLAN_CACHE.misses == 0 or fast.arena is not None
+        direct = ga.GraphPlan(batch.edge_index, batch.num_nodes, normalize)
+        assert fast is not direct and fast.fwd.nnz == direct.fwd.nnz and fast.symmetric
+        assert torch.equal(fast.fwd.rowptr, direct.fwd.rowptr) and torch.equal(fast.fwd.col, direct.fwd.col)
+        assert torch.equal(fast.tile_ptr, direct.tile_ptr) and torch.equal(fast.tile_order, direct.tile_order)
+        if normalize:
+            assert torch.equal(fast.dis, direct.dis)
+        assert fast.tile_nodes_max >= direct.tile_nodes_max
+        mod = ga.GConvAdapter(64, 4, learnable_scalar=True, normalize=normalize).to(dev)
+        with torch.no_grad():
+            for prm in mod.parameters():
+                prm.normal_(0, 0.1)
+        xg = batch.x.clone().requires_grad_(True)
+        out = mod(xg, batch.edge_index)                       # runs on the assembled plan
+        out.sum().backward()
+        ei2 = batch.edge_index.clone()                        # another tensor: plan built directly
+        x2 = batch.x.clone().requires_grad_(True)
+        grads = [prm.grad.clone() for prm in mod.parameters()]
+        mod.zero_grad(set_to_none=True)
+        ref = mod(x2, ei2)
+        ref.sum().backward()
+        assert torch.equal(out, ref) and torch.equal(xg.grad, x2.grad)
+        for ga_, gb_ in zip(grads, [prm.grad for prm in mod.parameters()]):
+            assert torch.equal(ga_, gb_)
     with pytest.raises(RuntimeError):
         store.collate([300])
 
