@@ -191,14 +191,19 @@ extern "C" gconv_status_t gconv_graph_from_store(const gconv_graph_t* dataset, c
   const int T = 256;
   plan_tiles_kernel<<<(L.ntiles + 1 + T - 1) / T, T, 0, stream>>>(noff, num_graphs, num_nodes, L.ntiles, tile_ptr);
   GCONV_LAUNCH_CHECK();
-  plan_spans_kernel<<<(L.ntiles + T - 1) / T, T, 0, stream>>>(
-      tile_ptr, L.ntiles, reinterpret_cast<uint32_t*>(arena + L.key), reinterpret_cast<uint64_t*>(arena + L.span));
-  GCONV_LAUNCH_CHECK();
-  size_t cub_bytes = L.cub_bytes;
-  GCONV_HIP(hipcub::DeviceRadixSort::SortPairs(
-      arena + L.cub, cub_bytes, reinterpret_cast<const uint32_t*>(arena + L.key),
-      reinterpret_cast<uint32_t*>(arena + L.key_out), reinterpret_cast<const uint64_t*>(arena + L.span),
-      reinterpret_cast<uint64_t*>(arena + L.tile_order), L.ntiles, 0, 10, stream));
+  if (L.ntiles <= kSmallSortMax) {
+    small_tile_sort_kernel<<<1, 1024, 0, stream>>>(tile_ptr, L.ntiles, reinterpret_cast<uint64_t*>(arena + L.tile_order));
+    GCONV_LAUNCH_CHECK();
+  } else {
+    plan_spans_kernel<<<(L.ntiles + T - 1) / T, T, 0, stream>>>(
+        tile_ptr, L.ntiles, reinterpret_cast<uint32_t*>(arena + L.key), reinterpret_cast<uint64_t*>(arena + L.span));
+    GCONV_LAUNCH_CHECK();
+    size_t cub_bytes = L.cub_bytes;
+    GCONV_HIP(hipcub::DeviceRadixSort::SortPairs(
+        arena + L.cub, cub_bytes, reinterpret_cast<const uint32_t*>(arena + L.key),
+        reinterpret_cast<uint32_t*>(arena + L.key_out), reinterpret_cast<const uint64_t*>(arena + L.span),
+        reinterpret_cast<uint64_t*>(arena + L.tile_order), L.ntiles, 0, 10, stream));
+  }
   *g = gconv_graph_t{};
   g->fwd.num_nodes = num_nodes; g->fwd.nnz = static_cast<int32_t>(nnz);
   g->fwd.rowptr = rowptr; g->fwd.col = col;

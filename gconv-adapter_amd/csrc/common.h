@@ -106,6 +106,28 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
 
+// Size-sorted tile list for small tile counts (a molecule batch has a few hundred tiles): ONE
+// workgroup ranks every tile by (size descending, tile index ascending) — exactly the order of
+// the stable radix sort used for large counts — instead of the four launches rocprim spends on
+// a 400-element sort. span[t] = first node | size << 32.
+constexpr int kSmallSortMax = 2048;
+static __global__ __launch_bounds__(1024) void small_tile_sort_kernel(const int32_t* __restrict__ tile_ptr, int ntiles,
+                                                               uint64_t* __restrict__ order_out) {
+  __shared__ int32_t start[kSmallSortMax + 1];
+  for (int t = threadIdx.x; t <= ntiles; t += 1024) start[t] = tile_ptr[t];
+  __syncthreads();
+  for (int t = threadIdx.x; t < ntiles; t += 1024) {
+    const int sz = start[t + 1] - start[t];
+    int rank = 0;
+    for (int u = 0; u < ntiles; ++u) {
+      const int su = start[u + 1] - start[u];
+      rank += (su > sz) || (su == sz && u < t);
+    }
+    order_out[rank] = static_cast<uint64_t>(static_cast<uint32_t>(start[t])) |
+                      (static_cast<uint64_t>(static_cast<uint32_t>(sz)) << 32);
+  }
+}
+
 // Wave index inside the workgroup as a provably wave-uniform (SGPR) value. Without the
 // readfirstlane hipcc treats `threadIdx.x >> 6` as divergent, turns every branch that
 // depends on it into an exec-masked one and fences each load under it with vmcnt(0).

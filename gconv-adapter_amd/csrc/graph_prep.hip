@@ -409,7 +409,11 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
   g->tile_ptr = tile_ptr;
   g->tile_order = reinterpret_cast<int32_t*>(arena + L.tile_order);
   g->n_tiles = (h[INFO_NOTILE] || n == 0) ? 0 : L.ntiles;
-  if (g->n_tiles > 0) {  // largest tile first; stable, so the order is a function of the graph alone
+  if (g->n_tiles > 0 && L.ntiles <= kSmallSortMax) {
+    small_tile_sort_kernel<<<1, 1024, 0, stream>>>(tile_ptr, L.ntiles,
+                                                   reinterpret_cast<uint64_t*>(arena + L.tile_order));
+    GCONV_LAUNCH_CHECK();
+  } else if (g->n_tiles > 0) {  // largest tile first; stable, so the order is a function of the graph alone
     size_t cub_bytes = L.cub_bytes;
     GCONV_HIP(hipcub::DeviceRadixSort::SortPairs(
         arena + L.cub, cub_bytes, reinterpret_cast<const uint32_t*>(arena + L.tile_key),
