@@ -342,6 +342,38 @@ def test_adapter_many_tiles_per_workgroup(dev):
     _check_workload(dev, batch, 300, 8, flags, seed=5)
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_adapter_random_configurations(dev, seed):
+    """Seeded random sweep over what the reference can be handed: component structure (one blob,
+    many small components, isolated nodes), directed / symmetrised edge lists with duplicates
+    and self-loops, hidden width, rank, activation, normalisation, skip, scalar — vs the oracle.
+    Covers both execution paths (block-diagonal inputs take the fused tile kernels)."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    ncomp = [1, 1, 3, 12, 40][seed % 5]
+    sizes = [ri(1, max(1, [150, 40, 30, 12, 6][seed % 5])) for _ in range(ncomp)]
+    src, dst, off = [], [], 0
+    for n in sizes:
+        e = ri(0, 4 * n)
+        if e and n > 0:
+            a = torch.randint(n, (e,), generator=g) + off
+            b = torch.randint(n, (e,), generator=g) + off      # self-loops and duplicates welcome
+            src.append(a); dst.append(b)
+        off += n
+    n = off
+    ei = torch.stack([torch.cat(src), torch.cat(dst)]) if src else torch.zeros(2, 0, dtype=torch.long)
+    if seed % 3 != 0 and ei.shape[1]:
+        ei = torch.cat([ei, ei.flip(0)], dim=1)                 # symmetrised (duplicates kept)
+    d = 4 * ri(1, 16)
+    r = ri(1, min(16, d))
+    flags = oracle.AdapterFlags(non_linearity=["relu", "silu", "none"][seed % 3],
+                                learnable_scalar=seed % 2 == 0, skip_connection=seed % 4 != 3,
+                                normalize=seed % 5 != 4)
+    x = torch.randn(n, d, generator=g)
+    batch = ga.synth.GraphBatch(x=x, edge_index=ei, graph_ptr=torch.tensor([0, n]), num_graphs=1)
+    _check_workload(dev, batch, d, r, flags, seed=seed)
+
+
 def test_adapter_cora_3d_input(dev):
     batch, cfg = ga.synth.make_workload("cora")
     assert batch.x.dim() == 3
