@@ -88,6 +88,7 @@ _graph_p = C.POINTER(GraphStruct)
 #: name -> (restype, argtypes); must list every function declared in include/gconv_adapter.h
 SIGNATURES = {
     "gconv_abi_version": (_i32, []),
+    "gconv_abi_struct_bytes": (_i32, [_i32]),
     "gconv_status_string": (C.c_char_p, [_i32]),
     "gconv_padded_rank": (_i32, [_i32]),
     "gconv_graph_build_bytes": (_sz, [_i64, _i32]),
@@ -137,6 +138,10 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = restype
         fn.argtypes = argtypes
+    mirrors = (CsrStruct, GraphStruct, AdapterParams, PendingFinalize)
+    if lib.gconv_abi_version() == 4 and any(lib.gconv_abi_struct_bytes(i) != C.sizeof(t)
+                                            for i, t in enumerate(mirrors)):
+        raise RuntimeError("gconv_adapter_amd: ctypes struct mirrors do not match the library's structs")
     if lib.gconv_abi_version() != 4:
         raise RuntimeError("gconv_adapter_amd: ABI version mismatch, rebuild the library")
     _lib = lib

@@ -126,6 +126,15 @@ static gconv_status_t check_common(const gconv_csr_t* g, const gconv_adapter_par
 using namespace gconv;
 
 extern "C" int32_t gconv_abi_version(void) { return GCONV_ABI_VERSION; }
+extern "C" int32_t gconv_abi_struct_bytes(int32_t which) {
+  switch (which) {
+    case 0: return sizeof(gconv_csr_t);
+    case 1: return sizeof(gconv_graph_t);
+    case 2: return sizeof(gconv_adapter_params_t);
+    case 3: return sizeof(gconv_pending_finalize_t);
+    default: return -1;
+  }
+}
 
 extern "C" int32_t gconv_padded_rank(int32_t rank) { return padded_rank(rank); }
 

@@ -63,6 +63,9 @@ enum { GCONV_ACT_NONE = 0, GCONV_ACT_RELU = 1, GCONV_ACT_SILU = 2 };
 /* Introspection                                                             */
 /* ------------------------------------------------------------------------- */
 int32_t     gconv_abi_version(void);
+/* sizeof of the ABI's POD structs as compiled into the library, for bindings to check their
+ * mirrors: 0 gconv_csr_t, 1 gconv_graph_t, 2 gconv_adapter_params_t, 3 gconv_pending_finalize_t */
+int32_t     gconv_abi_struct_bytes(int32_t which);
 const char* gconv_status_string(gconv_status_t status);
 /* Fp for a bottleneck rank r (0 if r is unsupported: r < 1 or r > 64). */
 int32_t     gconv_padded_rank(int32_t rank);

@@ -213,3 +213,26 @@ def test_host_thread_pinning_helpers():
         assert gd.pin_to_local_cores() == []
     finally:
         del os.environ["GCONV_NO_PIN"]
+
+
+def test_ctypes_structs_match_the_header():
+    """Field names and order of the POD structs in include/gconv_adapter.h == the ctypes mirrors
+    (a silent drift here would hand the kernels shifted pointers)."""
+    text = open(os.path.join(ROOT, "include", "gconv_adapter.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+
+    def fields(name):
+        chunk = [c for c in text.split("typedef struct") if re.search(r"\}\s*%s;" % name, c)][0]
+        body = chunk[chunk.index("{") + 1:chunk.index("}")]
+        return [m.group(1) for m in re.finditer(r"\b(\w+)(?:\[\d+\])?\s*;", body)]
+
+    for cname, ctype in (("gconv_csr_t", ga._lib.CsrStruct), ("gconv_graph_t", ga._lib.GraphStruct),
+                         ("gconv_adapter_params_t", ga._lib.AdapterParams),
+                         ("gconv_pending_finalize_t", ga._lib.PendingFinalize)):
+        assert fields(cname) == [f[0] for f in ctype._fields_], cname
+    # and the sizes the C compiler sees (from the library, which was built from the same header)
+    assert ctypes.sizeof(ga._lib.PendingFinalize) == 24 * 8
+    lib = ga._lib.load()
+    for i, ctype in enumerate((ga._lib.CsrStruct, ga._lib.GraphStruct, ga._lib.AdapterParams,
+                               ga._lib.PendingFinalize)):
+        assert lib.gconv_abi_struct_bytes(i) == ctypes.sizeof(ctype)
