@@ -161,18 +161,21 @@ def adapter_step(mods, params, stream: BatchStream, normalize: bool, bucket=None
     return batch.num_graphs
 
 
-def settle(fn, device, world: int = 1, chunk: int = 100, max_seconds: float = 3.0) -> int:
+def settle(fn, device, world: int = 1, chunk: int = 100, min_seconds: float = 1.5,
+           max_seconds: float = 4.0) -> int:
     """Untimed pre-roll until the step rate is steady. A fresh process on the GPU box runs the
     same step 1.3–1.8x slower for its first 0.1–0.7 s (hundreds to ~2000 steps; host-side
     ramp-up of the box: the step is host-bound, back-to-back kernel time does not change) —
-    longer than any sensible --warmup. Runs chunks of `chunk` steps until two consecutive
-    chunks agree within 3 % (or `max_seconds`); returns the number of steps it ran."""
+    longer than any sensible --warmup. Runs chunks of `chunk` steps for at least `min_seconds`,
+    until two consecutive chunks agree within 3 % (or `max_seconds`); returns the number of steps."""
     if world > 1:   # the step contains a collective: every rank must run the same number of steps
-        for _ in range(5 * chunk):
+        for _ in range(40 * chunk):
             fn()
         torch.cuda.synchronize(device)
-        return 5 * chunk
-    ran, prev, t_end = 0, None, time.perf_counter() + max_seconds
+        return 40 * chunk
+    ran, prev = 0, None
+    t_begin = time.perf_counter()
+    t_end = t_begin + max_seconds
     while time.perf_counter() < t_end:
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
@@ -181,7 +184,8 @@ def settle(fn, device, world: int = 1, chunk: int = 100, max_seconds: float = 3.
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t0
         ran += chunk
-        if prev is not None and abs(dt - prev) <= 0.03 * prev and ran >= 4 * chunk:
+        if prev is not None and abs(dt - prev) <= 0.03 * prev and \
+                time.perf_counter() - t_begin >= min_seconds:   # (plateaus of ~0.7 s were seen)
             break
         prev = dt
     return ran
