@@ -64,6 +64,7 @@ class PendingFinalize(C.Structure):
 
 
 FINALIZE_BATCH = 8
+ABI_VERSION = 5   # GCONV_ABI_VERSION of include/gconv_adapter.h this binding was written against
 
 
 class AdapterParams(C.Structure):
@@ -107,6 +108,13 @@ SIGNATURES = {
                                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                                              C.POINTER(PendingFinalize), _vp]),
     "gconv_adapter_bwd_finalize_f32": (_i32, [C.POINTER(PendingFinalize), _i32, _vp]),
+    "gconv_adapter_slab_fwd_workspace_bytes": (_sz, [_graph_p, _i32]),
+    "gconv_adapter_slab_bwd_workspace_bytes": (_sz, [_graph_p, _i32, _i32, _i32, _i32]),
+    "gconv_adapter_slab_fwd_f32": (_i32, [_graph_p, C.POINTER(AdapterParams), _i32, _i32, _i32, _vp, _vp,
+                                          _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "gconv_adapter_slab_bwd_f32": (_i32, [_graph_p, C.POINTER(AdapterParams), _i32, _i32, _i32, _vp, _vp,
+                                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                          _vp, _sz, _vp]),
     "gconv_collate_workspace_bytes": (_sz, [_i32]),
     "gconv_collate_f32": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, C.c_int64, _vp, _vp, _vp, _vp,
                                  _vp, _sz, _vp]),
@@ -139,10 +147,10 @@ def load() -> C.CDLL:
         fn.restype = restype
         fn.argtypes = argtypes
     mirrors = (CsrStruct, GraphStruct, AdapterParams, PendingFinalize)
-    if lib.gconv_abi_version() == 4 and any(lib.gconv_abi_struct_bytes(i) != C.sizeof(t)
+    if lib.gconv_abi_version() == ABI_VERSION and any(lib.gconv_abi_struct_bytes(i) != C.sizeof(t)
                                             for i, t in enumerate(mirrors)):
         raise RuntimeError("gconv_adapter_amd: ctypes struct mirrors do not match the library's structs")
-    if lib.gconv_abi_version() != 4:
+    if lib.gconv_abi_version() != ABI_VERSION:
         raise RuntimeError("gconv_adapter_amd: ABI version mismatch, rebuild the library")
     _lib = lib
     return lib

@@ -65,13 +65,15 @@ struct BwdWs {
   BwdMainGeom geom;
   size_t bytes;
 };
-static BwdWs carve_bwd(void* ws, const gconv_csr_t* gt, int d, int fp) {
+// `rows` = rows this device produces (the whole graph, or its row slab: then the two
+// full-height rank-width buffers are the caller's — they are exchanged between stages)
+static BwdWs carve_bwd(void* ws, const gconv_csr_t* gt, int d, int fp, int rows, bool slab) {
   Carver c(ws);
   BwdWs w;
-  const size_t n = gt->num_nodes;
-  w.geom = bwd_main_geom(gt->num_nodes, d);
-  w.n_ds1 = rowsA_grid(gt->num_nodes);
-  w.n_bd = spmm_bias_partial_rows(gt, fp);
+  const size_t n = slab ? 0 : gt->num_nodes;
+  w.geom = bwd_main_geom(rows, d);
+  w.n_ds1 = rowsA_grid(rows);
+  w.n_bd = spmm_bias_partial_rows(gt, fp, rows);
   w.dp = c.take<float>(n * fp);
   w.dh1 = c.take<float>(n * fp);
   w.seg = c.take<float>(static_cast<size_t>(gt->n_seg) * fp);
@@ -172,7 +174,50 @@ extern "C" size_t gconv_adapter_bwd_workspace_bytes(const gconv_graph_t* graph, 
   if (tile_path_ok(graph, hidden, fp)) return carve_bwd_tile(nullptr, graph->n_tiles, hidden, fp).bytes + (1 << 20);
 #endif
   if (tile_path_ok(graph, hidden, fp)) return carve_bwd_tile(nullptr, graph->n_tiles, hidden, fp).bytes;
-  return carve_bwd(nullptr, &graph->bwd, hidden, fp).bytes;
+  return carve_bwd(nullptr, &graph->bwd, hidden, fp, graph->bwd.num_nodes, false).bytes;
+}
+
+// The four-launch forward on the rows [lo, hi) of the graph, `stages` = bit set of
+//   1: K1   2: K2   4: K2' + K3
+// x / out hold the rows [lo, hi) only (row 0 = global row lo); h0, saved_* are full-height
+// arrays in global row coordinates. The single-device path is lo = 0, hi = n, stages = 7.
+static gconv_status_t fwd_stages(const gconv_graph_t* gr, const gconv_adapter_params_t* p, int lo,
+                                 int hi, int stages, const float* x, float* out, float* h0,
+                                 float* saved_h, float* saved_h1, float* saved_p, float* seg,
+                                 hipStream_t stream) {
+  const gconv_csr_t* graph = &gr->fwd;
+  const float* dis = gr->dis;
+  const int rows = hi - lo, d = p->hidden, r = p->rank, fp = padded_rank(r);
+  const size_t shift = static_cast<size_t>(lo) * fp;
+  gconv_status_t st = GCONV_OK;
+  if (stages & 1) {
+    RowsAArgs k1{};
+    k1.X = x; k1.W = p->w_down; k1.row_scale = dis ? dis + lo : nullptr; k1.out = h0 + shift;
+    k1.n = rows; k1.d = d; k1.r = r; k1.fp = fp; k1.mode = ROWSA_DOWN;
+    st = launch_rowsA(k1, stream);
+    if (st != GCONV_OK) return st;
+  }
+  if (stages & 2) {
+    SpmmArgs k2{};
+    k2.dis = dis; k2.H = h0; k2.Y = saved_h; k2.Y2 = saved_h1;
+    k2.bias = p->b_down; k2.act = p->act; k2.rank = r; k2.seg_partial = seg;
+    k2.row_lo = lo; k2.row_hi = hi;
+    st = launch_spmm(graph, k2, fp, EPI_FWD1, stream);
+    if (st != GCONV_OK) return st;
+  }
+  if (stages & 4) {
+    SpmmArgs k2b{};
+    k2b.dis = dis; k2b.H = saved_h; k2b.Y = saved_p; k2b.rank = r; k2b.seg_partial = seg;
+    k2b.row_lo = lo; k2b.row_hi = hi;
+    st = launch_spmm(graph, k2b, fp, EPI_STORE, stream);
+    if (st != GCONV_OK) return st;
+
+    UpArgs k3{};
+    k3.P = saved_p + shift; k3.W_up = p->w_up; k3.b_up = p->b_up; k3.scalar = p->scalar;
+    k3.X = x; k3.out = out; k3.n = rows; k3.d = d; k3.r = r; k3.fp = fp; k3.skip = p->skip;
+    st = launch_up_fwd(k3, stream);
+  }
+  return st;
 }
 
 extern "C" gconv_status_t gconv_adapter_fwd_f32(const gconv_graph_t* gr,
@@ -207,32 +252,83 @@ extern "C" gconv_status_t gconv_adapter_fwd_f32(const gconv_graph_t* gr,
   }
   const FwdWs ws = carve_fwd(workspace, graph, fp);
   if (workspace_bytes < ws.bytes) return GCONV_E_WORKSPACE;
-
-  RowsAArgs k1{};
-  k1.X = x; k1.W = p->w_down; k1.row_scale = dis; k1.out = ws.h0;
-  k1.n = n; k1.d = d; k1.r = r; k1.fp = fp; k1.mode = ROWSA_DOWN;
-  st = launch_rowsA(k1, stream);
-  if (st != GCONV_OK) return st;
-
-  SpmmArgs k2{};
-  k2.dis = dis; k2.H = ws.h0; k2.Y = saved_h; k2.Y2 = saved_h1;
-  k2.bias = p->b_down; k2.act = p->act; k2.rank = r; k2.seg_partial = ws.seg;
-  st = launch_spmm(graph, k2, fp, EPI_FWD1, stream);
-  if (st != GCONV_OK) return st;
-
-  SpmmArgs k2b{};
-  k2b.dis = dis; k2b.H = saved_h; k2b.Y = saved_p; k2b.rank = r; k2b.seg_partial = ws.seg;
-  st = launch_spmm(graph, k2b, fp, EPI_STORE, stream);
-  if (st != GCONV_OK) return st;
-
-  UpArgs k3{};
-  k3.P = saved_p; k3.W_up = p->w_up; k3.b_up = p->b_up; k3.scalar = p->scalar;
-  k3.X = x; k3.out = out; k3.n = n; k3.d = d; k3.r = r; k3.fp = fp; k3.skip = p->skip;
-  return launch_up_fwd(k3, stream);
+  return fwd_stages(gr, p, 0, n, 7, x, out, ws.h0, saved_h, saved_h1, saved_p, ws.seg, stream);
 }
 
 static_assert(sizeof(FinalizeArgs) <= sizeof(gconv_pending_finalize_t),
               "gconv_pending_finalize_t must be able to hold a FinalizeArgs");
+
+// The general-path backward on the rows [lo, hi), `stages` = bit set of
+//   1: B1   2: B2 (+ bias-partial pre-reduction)   4: B3, B4, B5
+// x / grad_out / grad_x hold the rows [lo, hi) only; saved_*, dp, dh1 are full-height arrays in
+// global row coordinates; `ws` was carved for hi - lo rows. Single device: lo = 0, hi = n, 7.
+static gconv_status_t bwd_stages(const gconv_graph_t* gr, const gconv_adapter_params_t* p, int lo,
+                                 int hi, int stages, const float* x, const float* grad_out,
+                                 const float* saved_h, const float* saved_h1, const float* saved_p,
+                                 float* dp, float* dh1, float* grad_x, float* grad_w_down,
+                                 float* grad_b_down, float* grad_w_up, float* grad_b_up,
+                                 float* grad_scalar, const BwdWs& ws, FinalizeArgs* pending,
+                                 hipStream_t stream) {
+  const gconv_csr_t* graph_t = &gr->bwd;
+  const float* dis = gr->dis;
+  const int n = hi - lo, d = p->hidden, r = p->rank, fp = padded_rank(r);
+  const size_t shift = static_cast<size_t>(lo) * fp;
+  gconv_status_t st = GCONV_OK;
+  if (n > 0 && (stages & 1)) {
+    RowsAArgs b1{};
+    b1.X = grad_out; b1.W = p->w_up; b1.row_scale = dis ? dis + lo : nullptr; b1.scalar = p->scalar;
+    b1.P = grad_scalar ? saved_p + shift : nullptr;
+    b1.ds_partial = grad_scalar ? ws.part_ds1 : nullptr;
+    b1.out = dp + shift; b1.n = n; b1.d = d; b1.r = r; b1.fp = fp; b1.mode = ROWSA_DP;
+    st = launch_rowsA(b1, stream);
+    if (st != GCONV_OK) return st;
+  }
+  if (n > 0 && (stages & 2)) {
+    SpmmArgs b2{};
+    b2.dis = dis; b2.H = dp; b2.Y = dh1;
+    b2.saved = (p->act == GCONV_ACT_SILU) ? saved_h1 : saved_h;
+    b2.act = p->act; b2.rank = r; b2.seg_partial = ws.seg; b2.bias_partial = ws.part_bd;
+    b2.row_lo = lo; b2.row_hi = hi;
+    st = launch_spmm(graph_t, b2, fp, EPI_BWD1, stream);
+    if (st != GCONV_OK) return st;
+    if (ws.n_bd > 2 * kReduceBlocks) {  // tall partial array: parallel stage-1 column sums
+      st = launch_reduce_rows(ws.part_bd, ws.n_bd, fp, ws.part_bd2, stream);
+      if (st != GCONV_OK) return st;
+    }
+  }
+  if (!(stages & 4)) return GCONV_OK;
+  if (n > 0) {
+    SpmmArgs b3{};
+    b3.dis = dis; b3.H = dh1; b3.Y = dp; b3.rank = r; b3.seg_partial = ws.seg;
+    b3.row_lo = lo; b3.row_hi = hi;
+    st = launch_spmm(graph_t, b3, fp, EPI_STORE, stream);
+    if (st != GCONV_OK) return st;
+
+    BwdMainArgs b4{};
+    b4.G = grad_out; b4.X = x; b4.T = dp + shift; b4.P = saved_p + shift; b4.W_down = p->w_down;
+    b4.scalar = p->scalar; b4.dX = grad_x;
+    b4.part_wd = ws.part_wd; b4.part_wu = ws.part_wu; b4.part_cs = ws.part_cs;
+    b4.part_dsx = ws.part_dsx;
+    b4.n = n; b4.d = d; b4.r = r; b4.fp = fp; b4.skip = p->skip;
+    st = launch_bwd_main(b4, stream);
+    if (st != GCONV_OK) return st;
+  }
+
+  FinalizeArgs f{};
+  f.part_wd = ws.part_wd; f.part_wu = ws.part_wu; f.part_cs = ws.part_cs;
+  f.nparts = n > 0 ? ws.geom.nparts : 0;
+  f.part_dsx = ws.part_dsx; f.n_dsx = n > 0 ? ws.geom.nparts * ws.geom.nchunks * ws.geom.nslots : 0;
+  f.part_ds1 = ws.part_ds1; f.n_ds1 = n > 0 ? ws.n_ds1 : 0;
+  const bool bd_staged = n > 0 && ws.n_bd > 2 * kReduceBlocks;
+  f.part_bd = bd_staged ? ws.part_bd2 : ws.part_bd;
+  f.n_bd = n > 0 ? (bd_staged ? kReduceBlocks : ws.n_bd) : 0;
+  f.scalar = p->scalar; f.b_up = p->b_up; f.cs_tmp = ws.cs_tmp;
+  f.g_wd = grad_w_down; f.g_bd = grad_b_down; f.g_wu = grad_w_up; f.g_bu = grad_b_up;
+  f.g_s = grad_scalar;
+  f.d = d; f.r = r; f.fp = fp; f.skip = p->skip;
+  if (pending) { *pending = f; return GCONV_OK; }
+  return launch_finalize(f, stream);
+}
 
 // The whole backward; the last reduction is either launched (pending == nullptr) or described
 // in *pending for gconv_adapter_bwd_finalize_f32.
@@ -284,58 +380,10 @@ static gconv_status_t adapter_bwd(const gconv_graph_t* gr, const gconv_adapter_p
     if (pending) { *pending = f; return GCONV_OK; }
     return launch_finalize(f, stream);
   }
-  const BwdWs ws = carve_bwd(workspace, graph_t, d, fp);
+  const BwdWs ws = carve_bwd(workspace, graph_t, d, fp, n, false);
   if (workspace_bytes < ws.bytes) return GCONV_E_WORKSPACE;
-
-  if (n > 0) {
-    RowsAArgs b1{};
-    b1.X = grad_out; b1.W = p->w_up; b1.row_scale = dis; b1.scalar = p->scalar;
-    b1.P = grad_scalar ? saved_p : nullptr;
-    b1.ds_partial = grad_scalar ? ws.part_ds1 : nullptr;
-    b1.out = ws.dp; b1.n = n; b1.d = d; b1.r = r; b1.fp = fp; b1.mode = ROWSA_DP;
-    st = launch_rowsA(b1, stream);
-    if (st != GCONV_OK) return st;
-
-    SpmmArgs b2{};
-    b2.dis = dis; b2.H = ws.dp; b2.Y = ws.dh1;
-    b2.saved = (p->act == GCONV_ACT_SILU) ? saved_h1 : saved_h;
-    b2.act = p->act; b2.rank = r; b2.seg_partial = ws.seg; b2.bias_partial = ws.part_bd;
-    st = launch_spmm(graph_t, b2, fp, EPI_BWD1, stream);
-    if (st != GCONV_OK) return st;
-    if (ws.n_bd > 2 * kReduceBlocks) {  // tall partial array: parallel stage-1 column sums
-      st = launch_reduce_rows(ws.part_bd, ws.n_bd, fp, ws.part_bd2, stream);
-      if (st != GCONV_OK) return st;
-    }
-
-    SpmmArgs b3{};
-    b3.dis = dis; b3.H = ws.dh1; b3.Y = ws.dp; b3.rank = r; b3.seg_partial = ws.seg;
-    st = launch_spmm(graph_t, b3, fp, EPI_STORE, stream);
-    if (st != GCONV_OK) return st;
-
-    BwdMainArgs b4{};
-    b4.G = grad_out; b4.X = x; b4.T = ws.dp; b4.P = saved_p; b4.W_down = p->w_down;
-    b4.scalar = p->scalar; b4.dX = grad_x;
-    b4.part_wd = ws.part_wd; b4.part_wu = ws.part_wu; b4.part_cs = ws.part_cs;
-    b4.part_dsx = ws.part_dsx;
-    b4.n = n; b4.d = d; b4.r = r; b4.fp = fp; b4.skip = p->skip;
-    st = launch_bwd_main(b4, stream);
-    if (st != GCONV_OK) return st;
-  }
-
-  FinalizeArgs f{};
-  f.part_wd = ws.part_wd; f.part_wu = ws.part_wu; f.part_cs = ws.part_cs;
-  f.nparts = n > 0 ? ws.geom.nparts : 0;
-  f.part_dsx = ws.part_dsx; f.n_dsx = n > 0 ? ws.geom.nparts * ws.geom.nchunks * ws.geom.nslots : 0;
-  f.part_ds1 = ws.part_ds1; f.n_ds1 = n > 0 ? ws.n_ds1 : 0;
-  const bool bd_staged = n > 0 && ws.n_bd > 2 * kReduceBlocks;
-  f.part_bd = bd_staged ? ws.part_bd2 : ws.part_bd;
-  f.n_bd = n > 0 ? (bd_staged ? kReduceBlocks : ws.n_bd) : 0;
-  f.scalar = p->scalar; f.b_up = p->b_up; f.cs_tmp = ws.cs_tmp;
-  f.g_wd = grad_w_down; f.g_bd = grad_b_down; f.g_wu = grad_w_up; f.g_bu = grad_b_up;
-  f.g_s = grad_scalar;
-  f.d = d; f.r = r; f.fp = fp; f.skip = p->skip;
-  if (pending) { *pending = f; return GCONV_OK; }
-  return launch_finalize(f, stream);
+  return bwd_stages(gr, p, 0, n, 7, x, grad_out, saved_h, saved_h1, saved_p, ws.dp, ws.dh1, grad_x,
+                    grad_w_down, grad_b_down, grad_w_up, grad_b_up, grad_scalar, ws, pending, stream);
 }
 
 extern "C" gconv_status_t gconv_adapter_bwd_f32(const gconv_graph_t* gr,
@@ -381,4 +429,72 @@ extern "C" gconv_status_t gconv_adapter_bwd_finalize_f32(const gconv_pending_fin
     if (st != GCONV_OK) return st;
   }
   return GCONV_OK;
+}
+
+// ---- one big graph over several devices: row slabs (include/gconv_adapter.h) -------
+static gconv_status_t check_slab(const gconv_graph_t* gr, const gconv_csr_t* g,
+                                 const gconv_adapter_params_t* p, int lo, int hi, int stage) {
+  if (!gr) return GCONV_E_INVALID_ARG;
+  const gconv_status_t st = check_common(g, p);
+  if (st != GCONV_OK) return st;
+  if (lo < 0 || hi < lo || hi > g->num_nodes || stage < 0 || stage > 2) return GCONV_E_INVALID_ARG;
+  return GCONV_OK;
+}
+
+extern "C" size_t gconv_adapter_slab_fwd_workspace_bytes(const gconv_graph_t* graph, int32_t rank) {
+  const int fp = padded_rank(rank);
+  if (!graph || fp == 0) return 0;
+  return align_up(static_cast<size_t>(graph->fwd.n_seg) * fp * sizeof(float) + 16, 256);
+}
+
+extern "C" size_t gconv_adapter_slab_bwd_workspace_bytes(const gconv_graph_t* graph, int32_t row_lo,
+                                                         int32_t row_hi, int32_t hidden,
+                                                         int32_t rank) {
+  const int fp = padded_rank(rank);
+  if (!graph || fp == 0 || hidden <= 0 || row_lo < 0 || row_hi < row_lo) return 0;
+  return carve_bwd(nullptr, &graph->bwd, hidden, fp, row_hi - row_lo, true).bytes;
+}
+
+extern "C" gconv_status_t gconv_adapter_slab_fwd_f32(
+    const gconv_graph_t* gr, const gconv_adapter_params_t* p, int32_t row_lo, int32_t row_hi,
+    int32_t stage, const float* x, float* out, float* h0, float* saved_h, float* saved_h1,
+    float* saved_p, void* workspace, size_t workspace_bytes, gconv_stream_t stream) {
+  gconv_status_t st = check_slab(gr, gr ? &gr->fwd : nullptr, p, row_lo, row_hi, stage);
+  if (st != GCONV_OK) return st;
+  if (row_hi == row_lo) return GCONV_OK;   // a device without rows only takes part in the exchanges
+  if (!x || !out || !h0 || !saved_h || !saved_p) return GCONV_E_INVALID_ARG;
+  if (p->act == GCONV_ACT_SILU && !saved_h1) return GCONV_E_INVALID_ARG;
+  if (!aligned16(x) || !aligned16(out) || !aligned16(h0) || !aligned16(saved_h) ||
+      !aligned16(saved_p) || (saved_h1 && !aligned16(saved_h1)) ||
+      (workspace && !aligned16(workspace)) || (p->b_up && !aligned16(p->b_up)) ||
+      !aligned16(p->w_down))
+    return GCONV_E_ALIGNMENT;
+  if (gr->fwd.n_seg > 0 &&
+      (!workspace || workspace_bytes < gconv_adapter_slab_fwd_workspace_bytes(gr, p->rank)))
+    return GCONV_E_WORKSPACE;
+  return fwd_stages(gr, p, row_lo, row_hi, 1 << stage, x, out, h0, saved_h, saved_h1, saved_p,
+                    static_cast<float*>(workspace), static_cast<hipStream_t>(stream));
+}
+
+extern "C" gconv_status_t gconv_adapter_slab_bwd_f32(
+    const gconv_graph_t* gr, const gconv_adapter_params_t* p, int32_t row_lo, int32_t row_hi,
+    int32_t stage, const float* x, const float* grad_out, const float* saved_h,
+    const float* saved_h1, const float* saved_p, float* dp, float* dh1, float* grad_x,
+    float* grad_w_down, float* grad_b_down, float* grad_w_up, float* grad_b_up, float* grad_scalar,
+    void* workspace, size_t workspace_bytes, gconv_stream_t stream) {
+  gconv_status_t st = check_slab(gr, gr ? &gr->bwd : nullptr, p, row_lo, row_hi, stage);
+  if (st != GCONV_OK) return st;
+  const int rows = row_hi - row_lo;
+  if (!grad_w_down || !grad_w_up || !workspace) return GCONV_E_INVALID_ARG;
+  if (rows > 0 && (!x || !grad_out || !saved_h || !saved_p || !dp || !dh1)) return GCONV_E_INVALID_ARG;
+  if (p->act == GCONV_ACT_SILU && rows > 0 && !saved_h1) return GCONV_E_INVALID_ARG;
+  if (!aligned16(x) || !aligned16(grad_out) || !aligned16(saved_h) || !aligned16(saved_p) ||
+      (saved_h1 && !aligned16(saved_h1)) || (grad_x && !aligned16(grad_x)) || !aligned16(dp) ||
+      !aligned16(dh1) || !aligned16(workspace) || !aligned16(p->w_down))
+    return GCONV_E_ALIGNMENT;
+  const BwdWs ws = carve_bwd(workspace, &gr->bwd, p->hidden, padded_rank(p->rank), rows, true);
+  if (workspace_bytes < ws.bytes) return GCONV_E_WORKSPACE;
+  return bwd_stages(gr, p, row_lo, row_hi, 1 << stage, x, grad_out, saved_h, saved_h1, saved_p, dp,
+                    dh1, grad_x, grad_w_down, grad_b_down, grad_w_up, grad_b_up, grad_scalar, ws,
+                    nullptr, static_cast<hipStream_t>(stream));
 }

@@ -23,6 +23,7 @@ struct SpmmArgs {
   const int32_t* seg_long;
   uint32_t* long_sync;
   int row_blocks;
+  int row_lo, row_hi;   // rows this launch produces; row_hi == 0 -> all (row slabs: SURVEY 8e)
   // operands
   const float* dis;     // nullptr -> unnormalised
   const float* H;       // [n, F] gathered rows
@@ -37,8 +38,10 @@ struct SpmmArgs {
   uint32_t flags;
 };
 
-// rows of `bias_partial` an EPI_BWD1 launch writes for this graph / width
+// rows of `bias_partial` an EPI_BWD1 launch writes for this graph / width (`rows` of them
+// produced by the launch: the whole graph, or one row slab of it)
 int spmm_bias_partial_rows(const gconv_csr_t* g, int width);
+int spmm_bias_partial_rows(const gconv_csr_t* g, int width, int rows);
 
 gconv_status_t launch_spmm(const gconv_csr_t* g, SpmmArgs a, int width, int epi,
                            hipStream_t stream);

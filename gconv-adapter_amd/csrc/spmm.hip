@@ -126,6 +126,11 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(SpmmArgs a) {
       const int lr = a.seg_long[s];
       const int row = a.long_rows[lr];
       const int base = a.long_seg_base[lr];
+      if (row < a.row_lo || row >= a.row_hi) {   // another device's row (wave-uniform)
+        if (EPI == EPI_BWD1 && s == base && grp == 0)   // its bias-gradient slot still gets summed
+          stg4(a.bias_partial + static_cast<size_t>(a.row_blocks + lr) * F + 4 * sub, zero4());
+        return;
+      }
       const int r0 = a.rowptr[row], r1 = a.rowptr[row + 1];
       const int e0 = r0 + (s - base) * GCONV_SEG_EDGES;
       const int e1 = min(e0 + GCONV_SEG_EDGES, r1);
@@ -177,10 +182,10 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(SpmmArgs a) {
 
   f32x4 bias_grad = zero4();
   const int rblock = blockIdx.x - seg_blocks;
-  const int row = (rblock * 4 + wave) * RPW + grp;
-  const int rowc = min(row, a.n - 1);
+  const int row = a.row_lo + (rblock * 4 + wave) * RPW + grp;
+  const int rowc = min(row, a.row_hi - 1);
   const int e0 = a.rowptr[rowc], e1 = a.rowptr[rowc + 1];
-  const bool mine = row < a.n && (e1 - e0) <= GCONV_LONG_ROW;  // long rows: segment path
+  const bool mine = row < a.row_hi && (e1 - e0) <= GCONV_LONG_ROW;  // long rows: segment path
   const int deg = mine ? e1 - e0 : 0;
 
   // The loop over 8-edge batches is WAVE-UNIFORM (trip count = longest row of the wave), so
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(SpmmArgs a) {
 template <int F, bool NORM, int EPI>
 static gconv_status_t launch_spmm_t(SpmmArgs& a, hipStream_t stream) {
   constexpr int RPW = RowShape<F>::RPW;
-  a.row_blocks = ceil_div(a.n, 4 * RPW);
+  a.row_blocks = ceil_div(a.row_hi - a.row_lo, 4 * RPW);
   const int seg_blocks = ceil_div(a.n_seg, 4);
   const int grid = a.row_blocks + seg_blocks;
   if (grid > 0) {
@@ -252,9 +257,12 @@ static gconv_status_t launch_spmm_n(SpmmArgs& a, int epi, hipStream_t stream) {
   return a.dis ? launch_spmm_e<F, true>(a, epi, stream) : launch_spmm_e<F, false>(a, epi, stream);
 }
 
-int spmm_bias_partial_rows(const gconv_csr_t* g, int width) {
+int spmm_bias_partial_rows(const gconv_csr_t* g, int width, int rows) {
   const int rpw = kWave / (width / 4);
-  return ceil_div(g->num_nodes, 4 * rpw) + g->n_long;
+  return ceil_div(rows, 4 * rpw) + g->n_long;
+}
+int spmm_bias_partial_rows(const gconv_csr_t* g, int width) {
+  return spmm_bias_partial_rows(g, width, g->num_nodes);
 }
 
 gconv_status_t launch_spmm(const gconv_csr_t* g, SpmmArgs a, int width, int epi,
@@ -269,6 +277,8 @@ gconv_status_t launch_spmm(const gconv_csr_t* g, SpmmArgs a, int width, int epi,
   a.seg_long = g->seg_long;
   a.long_sync = g->long_sync;
   if (a.n == 0) return GCONV_OK;
+  if (a.row_hi == 0) { a.row_lo = 0; a.row_hi = a.n; }
+  if (a.row_lo < 0 || a.row_hi > a.n || a.row_lo >= a.row_hi) return GCONV_E_INVALID_ARG;
   if (a.n_seg > 0 && !a.seg_partial) return GCONV_E_WORKSPACE;
   switch (width) {
     case 4:  return launch_spmm_n<4>(a, epi, stream);

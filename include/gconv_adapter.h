@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GCONV_ABI_VERSION 4
+#define GCONV_ABI_VERSION 5
 
 typedef int32_t gconv_status_t;
 typedef void*   gconv_stream_t; /* hipStream_t */
@@ -256,6 +256,52 @@ gconv_status_t gconv_adapter_bwd_partial_f32(const gconv_graph_t* graph,
 gconv_status_t gconv_adapter_bwd_finalize_f32(const gconv_pending_finalize_t* pending,
                                               int32_t count, gconv_stream_t stream);
 
+/* ---- one big graph over several devices: row slabs (single-graph case) ----------
+ * The reference has no multi-device path; this is the counterpart of running
+ * `GConvAdapter.forward` (`gconv_adapter.py:80-108`) on a graph that is not a batch of
+ * components (`scripts/finetune_transductive_learning.py:208-230`), 1-D row partitioned:
+ * every device holds the whole graph plan (`gconv_graph_build` on the full edge list — index
+ * data only) and the rows [row_lo, row_hi) of X / out / G / dX. The two propagations need the
+ * rank-width operand of ALL rows, so the rank-width arrays are full-height [num_nodes, Fp]
+ * buffers in GLOBAL row coordinates on every device; a stage writes this device's rows of one
+ * of them and the CALLER exchanges it (all-gather: RCCL `ncclAllGather` in place, every device
+ * contributing its rows) before the next stage. The library never calls a collective.
+ *
+ *   forward   stage 0: h0[rows]      = dis . (X Wd^T)                      -> all-gather h0
+ *             stage 1: saved_h[rows] = dis . act(S h0 + bd) (saved_h1: pre-activation, SiLU)
+ *                                                                          -> all-gather saved_h
+ *             stage 2: saved_p[rows] = S saved_h ; out = s (P Wu^T + bu + X)
+ *   backward  stage 0: dp[rows]      = dis . s (G Wu)                      -> all-gather dp
+ *             stage 1: dh1[rows]     = dis . (S^T dp) . act'               -> all-gather dh1
+ *             stage 2: T = S^T dh1 (into dp[rows]) ; grad_x ; this device's CONTRIBUTION to
+ *                      the parameter gradients                 -> all-reduce (sum) of those
+ *
+ * x / out / grad_out / grad_x are the device's own rows ([row_hi - row_lo, hidden], row 0 =
+ * global row row_lo). The three backward stages share one `workspace` (partials written by
+ * stages 0 and 1 are reduced by stage 2): it must not be touched in between. Uses the same
+ * kernels as the single-device path on a row range: results for a row are bitwise those of
+ * gconv_adapter_fwd_f32 / _bwd_f32 whatever the partition.                                  */
+size_t gconv_adapter_slab_fwd_workspace_bytes(const gconv_graph_t* graph, int32_t rank);
+size_t gconv_adapter_slab_bwd_workspace_bytes(const gconv_graph_t* graph, int32_t row_lo,
+                                              int32_t row_hi, int32_t hidden, int32_t rank);
+
+gconv_status_t gconv_adapter_slab_fwd_f32(const gconv_graph_t* graph,
+                                          const gconv_adapter_params_t* params, int32_t row_lo,
+                                          int32_t row_hi, int32_t stage, const float* x,
+                                          float* out, float* h0, float* saved_h, float* saved_h1,
+                                          float* saved_p, void* workspace,
+                                          size_t workspace_bytes, gconv_stream_t stream);
+
+gconv_status_t gconv_adapter_slab_bwd_f32(const gconv_graph_t* graph,
+                                          const gconv_adapter_params_t* params, int32_t row_lo,
+                                          int32_t row_hi, int32_t stage, const float* x,
+                                          const float* grad_out, const float* saved_h,
+                                          const float* saved_h1, const float* saved_p, float* dp,
+                                          float* dh1, float* grad_x, float* grad_w_down,
+                                          float* grad_b_down, float* grad_w_up, float* grad_b_up,
+                                          float* grad_scalar, void* workspace,
+                                          size_t workspace_bytes, gconv_stream_t stream);
+
 /* ---- next to the path: the optimizer step over the trainable set -------------
  * replaces: `optim.Adam(...)` + `optimizer.step()`
  *   (`scripts/finetune_inductive_learning.py:379,67`, `scripts/finetune_transductive_learning.py:205,230`)
@@ -264,6 +310,11 @@ gconv_status_t gconv_adapter_bwd_finalize_f32(const gconv_pending_finalize_t* pe
  * torch's update rule and operation order; `step` is the 1-based step count of this call
  * (bias corrections are computed from it in double on the host, as torch does). All four
  * arrays have `count` floats; param / exp_avg / exp_avg_sq are updated in place.            */
+gconv_status_t gconv_adam_step_f32(float* param, const float* grad, float* exp_avg,
+                                   float* exp_avg_sq, int64_t count, float lr, float beta1,
+                                   float beta2, float eps, float weight_decay, int64_t step,
+                                   gconv_stream_t stream);
+
 /* ---- next to the path: collation of a batch from a device-resident dataset -----
  * replaces: PyG `DataLoader` -> `Batch.from_data_list` -> `batch.to(device)`
  *   (`scripts/finetune_inductive_learning.py:291-293,45`) for datasets kept in HBM: the chosen
@@ -298,11 +349,6 @@ gconv_status_t gconv_graph_from_store(const gconv_graph_t* dataset, const int32_
                                       int32_t num_graphs, int32_t num_nodes, int64_t nnz,
                                       int32_t max_graph_nodes, void* arena, size_t arena_bytes,
                                       gconv_graph_t* graph_host_out, gconv_stream_t stream);
-
-gconv_status_t gconv_adam_step_f32(float* param, const float* grad, float* exp_avg,
-                                   float* exp_avg_sq, int64_t count, float lr, float beta1,
-                                   float beta2, float eps, float weight_decay, int64_t step,
-                                   gconv_stream_t stream);
 
 #ifdef __cplusplus
 }
