@@ -49,6 +49,7 @@ import torch.distributed as dist  # noqa: E402
 import gconv_adapter_amd as ga  # noqa: E402
 
 RESIDENT = 0
+PARTITION = "graphs"
 _FULL_AFFINITY = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
 _PINNED = []
 
@@ -71,10 +72,11 @@ HBM_MEASURED_GBS = 6290.0   # float4-copy achievable, same table
 
 
 # --------------------------------------------------------------------------- helpers
-def build_adapters(cfg: dict, normalize: bool, device) -> torch.nn.ModuleList:
+def build_adapters(cfg: dict, normalize: bool, device, cls=None) -> torch.nn.ModuleList:
+    cls = cls or ga.GConvAdapter
     mods = torch.nn.ModuleList([
-        ga.GConvAdapter(cfg["d"], cfg["r"], learnable_scalar=True, skip_connection=True,
-                        normalize=normalize) for _ in range(cfg["adapters"])]).to(device)
+        cls(cfg["d"], cfg["r"], learnable_scalar=True, skip_connection=True,
+            normalize=normalize) for _ in range(cfg["adapters"])]).to(device)
     g = torch.Generator().manual_seed(1)
     with torch.no_grad():  # trained-scale weights (init scale would be a near-identity)
         for p in mods.parameters():
@@ -168,11 +170,22 @@ def settle(fn, device, world: int = 1, chunk: int = 100, min_seconds: float = 1.
     ramp-up of the box: the step is host-bound, back-to-back kernel time does not change) —
     longer than any sensible --warmup. Runs chunks of `chunk` steps for at least `min_seconds`,
     until two consecutive chunks agree within 3 % (or `max_seconds`); returns the number of steps."""
-    if world > 1:   # the step contains a collective: every rank must run the same number of steps
-        for _ in range(40 * chunk):
-            fn()
-        torch.cuda.synchronize(device)
-        return 40 * chunk
+    if world > 1:   # the step contains a collective: every rank must run the same number of steps,
+        # so the counts come from max-reduced timings: ~2 s of steps, at most 40 chunks
+        ran, spent, n = 0, 0.0, 5
+        while True:
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize(device)
+            took = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+            dist.all_reduce(took, op=dist.ReduceOp.MAX)
+            took = max(float(took.item()), 1e-6)
+            ran, spent = ran + n, spent + took
+            if spent >= 2.0 or ran >= 40 * chunk:
+                return ran
+            n = int(min(40 * chunk - ran, max(5, (2.0 - spent) / (took / n))))
     ran, prev = 0, None
     t_begin = time.perf_counter()
     t_end = t_begin + max_seconds
@@ -426,7 +439,15 @@ def run_workload(name: str, normalize: bool, steps: int, warmup: int, rank: int,
     else:
         stream = BatchStream(name, rank, device, k=4, fresh=fresh)
     cfg = stream.cfg
-    mods = build_adapters(cfg, normalize, device)
+    by_rows = PARTITION == "rows" and not fresh and world > 1
+    mods = build_adapters(cfg, normalize, device, ga.RowSlabGConvAdapter if by_rows else None)
+    if by_rows:   # ONE graph over all ranks: this rank keeps its rows of x / grad_out
+        batch, x, ei, gout = stream.items[0]
+        slabs = None
+        for m in mods:
+            slabs = m.partition(x.shape[-2])
+        keep = (lambda t: slabs.take(t.reshape(-1, t.shape[-1])).reshape(*t.shape[:-2], slabs.rows, t.shape[-1]))
+        stream.items[0] = (batch, keep(x), ei, keep(gout))
     params = list(mods.parameters())
     bucket = ga.dist.FlatGradBucket(params) if world > 1 else None
     mods = list(mods)
@@ -447,7 +468,8 @@ def run_workload(name: str, normalize: bool, steps: int, warmup: int, rank: int,
         batch0 = stream.items[0][0]
         edges = round(sum(b.edge_index.shape[1] for b, *_ in stream.items) / len(stream.items))
     graphs_per_step = stream.avg("num_graphs")
-    res = {"value": graphs_per_step * world * steps / dt, "ms_per_step": dt / steps * 1e3, "cfg": cfg,
+    res = {"value": graphs_per_step * (1 if by_rows else world) * steps / dt, "ms_per_step": dt / steps * 1e3,
+           "cfg": cfg, "by_rows": by_rows,
            "nodes_per_rank": round(stream.avg("num_nodes")),
            "edges_per_rank": edges,
            "graphs_per_rank": round(graphs_per_step), "settle_steps": settled}
@@ -470,9 +492,14 @@ def main() -> None:
     ap.add_argument("--resident", type=int, default=0, metavar="G",
                     help="keep a G-molecule dataset in HBM and draw a fresh random batch every step "
                          "(device-side collation + plan assembly) instead of rotating 4 fixed batches")
+    ap.add_argument("--partition", default="graphs", choices=["graphs", "rows"],
+                    help="N > 1 on a single-graph workload (cora / pubmed / arxiv): 'graphs' runs one replica "
+                         "of the graph per GPU, 'rows' splits the ONE graph by rows over the GPUs "
+                         "(strong scaling; all-gathers of the rank-width operands between the stages)")
     args = ap.parse_args()
-    global RESIDENT
+    global RESIDENT, PARTITION
     RESIDENT = args.resident
+    PARTITION = args.partition
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -507,17 +534,21 @@ def main() -> None:
         "warmup": args.warmup,
         "ms_per_step": round(main_res["ms_per_step"], 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if main_res["by_rows"] else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"M-{args.workload}: {main_res['graphs_per_rank']} graphs/GPU "
+        "config": {"workload": f"{'M' if main_res['cfg']['kind'] == 'molecule' else 'T'}-{args.workload}: {main_res['graphs_per_rank']} graphs/GPU "
                                f"({main_res['nodes_per_rank']} nodes, {main_res['edges_per_rank']} edges), "
                                f"d={main_res['cfg']['d']}, r={main_res['cfg']['r']}, "
-                               f"{main_res['cfg']['adapters']} adapters fwd+bwd, fresh graph plan per step "
-                               f"(built on a side stream while the previous step runs)"
+                               f"{main_res['cfg']['adapters']} adapters fwd+bwd, "
+                               + ("fresh graph plan per step (built on a side stream while the previous step runs)"
+                                  if main_res["cfg"]["kind"] == "molecule" else "static graph (plan built once)")
                                + (" + flat RCCL grad all-reduce" if world > 1 else ""),
-                   "normalize": normalize, "sharding": f"by graph, {world} rank(s)",
+                   "normalize": normalize,
+                   "sharding": (f"ONE graph by rows over {world} rank(s): 4 all-gathers of [N, Fp] per adapter "
+                                f"and step + flat grad all-reduce" if main_res["by_rows"]
+                                else f"by graph, {world} rank(s)"),
                    "settle_steps": main_res["settle_steps"],
                    "host_threads": (f"pinned to cores {_PINNED[0]}-{_PINNED[-1]} (GPU's NUMA node)"
                                     if _PINNED else "not pinned"),

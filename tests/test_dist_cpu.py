@@ -97,3 +97,53 @@ def test_bucket_layout_single_process():
     assert ga.dist.shard_bounds(10, 1, 4) == (2, 5)
     with pytest.raises(ValueError):
         ga.dist.FlatGradBucket([])
+
+
+# ---------------------------------------------------------------------------
+# row partition of one big graph: slab arithmetic and the exchange, on CPU
+# ---------------------------------------------------------------------------
+def test_row_slabs_cover_every_row_once():
+    for n, world in ((10, 4), (170_000, 8), (3, 8), (0, 2), (64, 1), (7, 7)):
+        slabs = [ga.RowSlabs(n, world, r) for r in range(world)]
+        assert all(s.padded == world * s.slab and s.padded >= n for s in slabs)
+        covered = [i for s in slabs for i in range(*s.bounds())]
+        assert covered == list(range(n))                       # contiguous, disjoint, in rank order
+        assert all(s.lo == min(s.rank * s.slab, n) for s in slabs)   # global row == buffer row
+        assert all(s.rows <= s.slab for s in slabs)
+    with pytest.raises(ValueError):
+        ga.RowSlabs(5, 2, 2)
+    t = torch.arange(20.).view(10, 2)
+    assert torch.equal(ga.RowSlabs(10, 4, 3).take(t), t[9:10])
+    full = torch.zeros(12, 2)
+    ga.partition.exchange_rows(full, ga.RowSlabs(12, 1, 0))    # world 1: nothing to exchange
+    with pytest.raises(RuntimeError, match="process group"):
+        ga.partition.exchange_rows(full, ga.RowSlabs(12, 2, 0))
+
+
+def _exchange_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    assert ga.dist.init_process_group_from_env("gloo") == world
+    n, f = 11, 4                                       # last slab is short: 6 + 5 rows, padded to 12
+    slabs = ga.RowSlabs(n, world, rank)
+    want = torch.arange(float(n * f)).view(n, f)
+    full = torch.full((slabs.padded, f), -1.0)
+    lo, hi = slabs.bounds()
+    full[lo:hi] = want[lo:hi]                          # a stage has written this rank's rows
+    ga.partition.exchange_rows(full, slabs)
+    assert torch.equal(full[:n], want)
+    got = ga.partition.gather_rows(slabs.take(want), slabs)
+    assert torch.equal(got, want)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        ga.partition.exchange_rows(torch.zeros(n, f), slabs)   # not the padded height
+    if rank == 0:
+        torch.save(full, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_rows_two_ranks_gloo(tmp_path):
+    out = str(tmp_path / "full.pt")
+    mp.start_processes(_exchange_worker, args=(2, _free_port(), out), nprocs=2, join=True, start_method="spawn")
+    full = torch.load(out)
+    assert torch.equal(full[:11], torch.arange(44.).view(11, 4))
