@@ -1,0 +1,153 @@
+"""The frozen GIN layer that sits between two adapters.
+
+``MolecularGINConv`` keeps the reference's module surface
+(``/root/reference/src/layers/inductive/gin_conv.py:9-84``: constructor ``(emb_dim, aggr)``,
+``forward(x, edge_index, edge_attr)``, parameter names ``mlp.0/2.{weight,bias}``,
+``edge_embedding_type.weight``, ``edge_embedding_direction.weight``) so a pretrained backbone's
+``state_dict`` loads unchanged (``src/models/inductive/gnn.py:44-46``).
+
+What changes is how the part before the MLP runs. The reference appends N self-loop edges,
+gathers two embedding rows per edge, materialises ``x_j + e_ij`` as an ``[E + N, d]`` tensor and
+scatter-adds it — per layer. Here (``csrc/gin.hip``):
+
+  * the neighbour sum walks the UNNORMALISED CSR of the batch's graph plan — the plan the
+    adapters of the same batch already use (``normalize: false`` is the reference's YAML default);
+  * there are only 6 x 3 distinct bond embeddings, so the bond term of a node is
+    ``sum_c count[i, c] * T[c]``: the ``[N, 18]`` counts are an exact integer histogram built once
+    per BATCH (``edge_code_counts``) and shared by all five GIN layers;
+  * backward of a frozen layer only needs d agg -> d x: the same kernel on the transposed CSR.
+
+The MLP (two dense GEMMs) stays ``nn.Linear``: plain library GEMMs belong to rocBLAS / hipBLASLt.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .functional import _require_hip_f32, _stream
+from .graph import GraphPlan, get_plan
+
+NUM_BOND_TYPE = 6        # gin_conv.py:6
+NUM_BOND_DIRECTION = 3   # gin_conv.py:7
+_CODES = NUM_BOND_TYPE * NUM_BOND_DIRECTION
+SELF_LOOP_BOND_TYPE = 4  # gin_conv.py:54
+
+_COUNTS: "OrderedDict[tuple, tuple]" = OrderedDict()   # per-batch code counts, keyed like PLAN_CACHE
+_COUNTS_CAPACITY = 8
+
+
+def edge_code_counts(edge_index: torch.Tensor, edge_attr: torch.Tensor, num_nodes: int,
+                     validate: bool = False) -> torch.Tensor:
+    """``[num_nodes * 18 + 1]`` int32: per node, how many incoming edges carry each (bond type,
+    bond direction) code; the trailing element counts edges that were skipped because an
+    endpoint or attribute was out of range (``validate=True`` reads it back — one host
+    synchronisation — and raises, as ``nn.Embedding`` would in the reference). Cached on the
+    identity of ``edge_attr`` / ``edge_index`` (the entry keeps both alive; in-place edits miss)."""
+    key = (edge_attr.data_ptr(), edge_attr._version, edge_index.data_ptr(), edge_index._version,
+           edge_index.shape[1], num_nodes)
+    hit = _COUNTS.get(key)
+    if hit is not None:
+        _COUNTS.move_to_end(key)
+        return hit[0]
+    if not edge_index.is_cuda or edge_attr.device != edge_index.device:
+        raise RuntimeError("gconv_adapter_amd has no CPU path: edge_index and edge_attr must live on one HIP device")
+    if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
+        raise RuntimeError(f"edge_index must be int64 [2, E], got {edge_index.dtype} {tuple(edge_index.shape)}")
+    e = edge_index.shape[1]
+    if edge_attr.dtype != torch.int64 or edge_attr.numel() != 2 * e:
+        raise RuntimeError(f"edge_attr must be int64 [E, 2] (bond type, bond direction), got "
+                           f"{edge_attr.dtype} {tuple(edge_attr.shape)} for E = {e}")
+    lib = _lib.load()
+    ei, ea = edge_index.contiguous(), edge_attr.contiguous()
+    counts = torch.empty(num_nodes * _CODES + 1, dtype=torch.int32, device=edge_index.device)
+    with torch.cuda.device(edge_index.device):
+        st = lib.gconv_gin_code_count(ei.data_ptr(), ea.data_ptr(), e, num_nodes, counts.data_ptr(), _stream())
+    _lib.check(st, "gin_code_count")
+    if validate and int(counts[-1].item()) != 0:
+        raise RuntimeError(f"{int(counts[-1].item())} edges have an endpoint outside [0, {num_nodes}) or a bond "
+                           f"attribute outside [0, {NUM_BOND_TYPE}) x [0, {NUM_BOND_DIRECTION})")
+    _COUNTS[key] = (counts, edge_index, edge_attr)
+    while len(_COUNTS) > _COUNTS_CAPACITY:
+        _COUNTS.popitem(last=False)
+    return counts
+
+
+def _aggregate(csr, x: torch.Tensor, counts: Optional[torch.Tensor], emb_type, emb_dir) -> torch.Tensor:
+    lib = _lib.load()
+    out = torch.empty_like(x)
+    dev = x.device
+    if dev.index != torch.cuda.current_device():
+        torch.cuda.set_device(dev)
+    st = lib.gconv_gin_aggregate_f32(csr.ref(), x.data_ptr(), _lib.ptr(counts), _lib.ptr(emb_type),
+                                     _lib.ptr(emb_dir), out.data_ptr(), x.shape[1], _stream(dev.index))
+    if st != 0:
+        _lib.check(st, "gin_aggregate")
+    return out
+
+
+class GinAggregateFunction(torch.autograd.Function):
+    """agg = (A + I) x + bond term (``gin_conv.py:50-72``); d x = (A + I)^T d agg."""
+
+    @staticmethod
+    def forward(ctx, x, emb_type, emb_dir, plan: GraphPlan, counts):
+        _require_hip_f32(x, "x")
+        x = x.contiguous()
+        if x.dim() != 2 or x.shape[0] != plan.num_nodes:
+            raise RuntimeError(f"x must be [{plan.num_nodes}, d], got {tuple(x.shape)}")
+        ctx.plan = plan
+        ctx.save_for_backward(counts)
+        return _aggregate(plan.fwd, x, counts, emb_type.contiguous(), emb_dir.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        (counts,) = ctx.saved_tensors
+        g = g.contiguous()
+        gx = _aggregate(ctx.plan.bwd, g, None, None, None) if ctx.needs_input_grad[0] else None
+        gt = gd = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            # only when the backbone itself is fine-tuned (the adapter recipe freezes it,
+            # gnn.py:230-241): d T[c] = sum_i count[i, c] g[i], folded onto the two tables
+            n = g.shape[0]
+            per_code = counts[:-1].view(n, _CODES).to(g.dtype).t() @ g            # [18, d]
+            per_code = per_code.view(NUM_BOND_TYPE, NUM_BOND_DIRECTION, -1)
+            col = g.sum(0)
+            gt = per_code.sum(1)
+            gt[SELF_LOOP_BOND_TYPE] += col
+            gd = per_code.sum(0)
+            gd[0] += col
+        return gx, gt, gd, None, None
+
+
+class MolecularGINConv(nn.Module):
+    """Drop-in for the reference's ``MolecularGINConv`` (module docstring)."""
+
+    def __init__(self, emb_dim: int, aggr: str = "add"):
+        super().__init__()
+        if aggr != "add":
+            raise ValueError("gconv_adapter_amd.MolecularGINConv implements aggr='add' (the reference's "
+                             "default and the only one its configs use)")
+        if emb_dim % 4 != 0 or emb_dim > 1024:
+            raise ValueError(f"emb_dim={emb_dim} is unsupported (multiple of 4, <= 1024)")
+        self.aggr = aggr
+        self.mlp = nn.Sequential(nn.Linear(emb_dim, 2 * emb_dim), nn.ReLU(), nn.Linear(2 * emb_dim, emb_dim))
+        self.edge_embedding_type = nn.Embedding(NUM_BOND_TYPE, emb_dim)
+        self.edge_embedding_direction = nn.Embedding(NUM_BOND_DIRECTION, emb_dim)
+        nn.init.xavier_uniform_(self.edge_embedding_type.weight.data)
+        nn.init.xavier_uniform_(self.edge_embedding_direction.weight.data)
+        #: read the skipped-edge counter back after building a batch's code counts (one host
+        #: synchronisation per batch) and raise on out-of-range bond attributes
+        self.validate_edge_attr = False
+
+    def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_attr: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("gconv_adapter_amd.MolecularGINConv has no CPU path (x is on %s)" % x.device)
+        n = x.shape[0]
+        plan = get_plan(edge_index, n, False)
+        counts = edge_code_counts(edge_index, edge_attr, n, self.validate_edge_attr)
+        agg = GinAggregateFunction.apply(x, self.edge_embedding_type.weight, self.edge_embedding_direction.weight,
+                                         plan, counts)
+        return self.mlp(agg)

@@ -350,6 +350,28 @@ gconv_status_t gconv_graph_from_store(const gconv_graph_t* dataset, const int32_
                                       int32_t max_graph_nodes, void* arena, size_t arena_bytes,
                                       gconv_graph_t* graph_host_out, gconv_stream_t stream);
 
+/* ---- next to the path: aggregation of the frozen GIN layer between two adapters --
+ * replaces: `MolecularGINConv.forward` up to its MLP (`src/layers/inductive/gin_conv.py:38-73`):
+ * `add_self_loops`, the bond-type / bond-direction embedding look-ups (self-loops: type 4,
+ * direction 0), message `x_j + e_ij`, sum aggregation (`aggr="add"`):
+ *   agg[i] = x[i] + sum_{j->i} x[j] + emb_type[4] + emb_dir[0] + sum_{e: j->i} (emb_type[t_e] + emb_dir[d_e])
+ * `gconv_gin_code_count` builds, once per batch, the per-node counts of the 18 (type, direction)
+ * codes of the incoming edges ([num_nodes, 18] int32, + one trailing int = number of edges skipped
+ * because an endpoint or attribute was out of range; `edge_index` int64 [2, E], `edge_attr` int64
+ * [E, 2] as PyG collates them); `gconv_gin_aggregate_f32` walks a CSR of the batch's UNNORMALISED
+ * graph plan (`gconv_graph_build(..., normalize = 0, ...)`: `fwd` for the layer's forward; `bwd`
+ * with code_count == NULL gives the gradient w.r.t. x, d agg -> d x). emb_type [6, hidden],
+ * emb_dir [3, hidden]; hidden a multiple of 4, <= 1024. The MLP and BatchNorm that follow
+ * (`gin_conv.py:24-28`, `gnn.py:108-110`) are plain dense layers and stay with the BLAS.        */
+size_t gconv_gin_code_count_bytes(int32_t num_nodes);
+gconv_status_t gconv_gin_code_count(const int64_t* edge_index, const int64_t* edge_attr,
+                                    int64_t num_edges, int32_t num_nodes, int32_t* code_count,
+                                    gconv_stream_t stream);
+gconv_status_t gconv_gin_aggregate_f32(const gconv_csr_t* csr, const float* x,
+                                       const int32_t* code_count, const float* emb_type,
+                                       const float* emb_dir, float* out, int32_t hidden,
+                                       gconv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

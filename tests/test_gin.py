@@ -1,0 +1,193 @@
+"""The frozen GIN layer next to the adapter: oracle self-checks on CPU,
+parity of the HIP aggregation (through the module and the C ABI) against the oracle on GPU."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+import gconv_adapter_amd as ga
+from oracle import gin_restated as oracle
+
+from helpers import assert_close, grad_atol
+
+
+def _bond_attr(num_edges: int, seed: int) -> torch.Tensor:
+    g = torch.Generator().manual_seed(seed)
+    return torch.stack([torch.randint(0, 4, (num_edges,), generator=g),
+                        torch.randint(0, 3, (num_edges,), generator=g)], dim=1)
+
+
+# --------------------------------------------------------------------------- CPU
+def test_oracle_edge_list_form_equals_dense_form():
+    batch = ga.synth.molecule_batch("esol", 6, hidden=12, seed=3)
+    ea = _bond_attr(batch.edge_index.shape[1], 1)
+    p = oracle.init_params(12, seed=2)
+    x = batch.x.double()
+    a = oracle.gin_aggregate(x, batch.edge_index, ea, p)
+    b = oracle.gin_aggregate_dense(x, batch.edge_index, ea, p)
+    assert torch.allclose(a, b, rtol=1e-12, atol=1e-12)
+
+
+def test_oracle_self_loop_semantics():
+    """gin_conv.py:50-55: every node gets one extra (i, i) edge of bond type 4, direction 0 —
+    an isolated node's aggregate is x_i + T_type[4] + T_dir[0]; an existing loop is kept."""
+    p = oracle.init_params(4, seed=0)
+    x = torch.randn(3, 4, dtype=torch.float64)
+    ei = torch.tensor([[0, 1], [1, 1]])            # 0 -> 1 and an explicit loop on 1; node 2 isolated
+    ea = torch.tensor([[2, 1], [0, 2]])
+    t, d = p["edge_embedding_type.weight"], p["edge_embedding_direction.weight"]
+    agg = oracle.gin_aggregate(x, ei, ea, p)
+    assert torch.allclose(agg[2], x[2] + t[4] + d[0])
+    assert torch.allclose(agg[0], x[0] + t[4] + d[0])
+    assert torch.allclose(agg[1], x[0] + t[2] + d[1] + x[1] + t[0] + d[2] + x[1] + t[4] + d[0])
+
+
+def test_module_surface_matches_the_reference():
+    m = ga.MolecularGINConv(300)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {
+        "mlp.0.weight": (600, 300), "mlp.0.bias": (600,), "mlp.2.weight": (300, 600), "mlp.2.bias": (300,),
+        "edge_embedding_type.weight": (6, 300), "edge_embedding_direction.weight": (3, 300)}
+    with pytest.raises(ValueError):
+        ga.MolecularGINConv(300, aggr="mean")
+    with pytest.raises(ValueError):
+        ga.MolecularGINConv(302)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(torch.zeros(2, 300), torch.zeros(2, 0, dtype=torch.long), torch.zeros(0, 2, dtype=torch.long))
+
+
+# --------------------------------------------------------------------------- GPU
+def _module(d, params, dev):
+    m = ga.MolecularGINConv(d).to(dev)
+    m.load_state_dict({k: v.float() for k, v in params.items()})
+    return m
+
+
+def _check(dev, x, ei, ea, d, seed, frozen):
+    """(1) the aggregation — the HIP part — forward and backward (d x, and the two embedding
+    tables when they train) at the adapter's tolerance; (2) the whole layer's forward, and its
+    d x on every node that no ReLU kink can reach: a hidden unit whose fp64 pre-activation is
+    within 3e-5 of zero may switch sides in fp32 (the BLAS's, not this library's), which changes
+    d agg of that node and hence d x of the node and its in-neighbours by O(1) — with ~10^6 hidden
+    units per batch a handful of such units is expected, so those rows are left out."""
+    params = oracle.init_params(d, seed=seed)
+    gen = torch.Generator().manual_seed(seed + 1)
+    g = torch.randn(x.shape, generator=gen)
+    n = x.shape[0]
+    ei_d, ea_d = ei.to(dev), ea.to(dev)
+
+    # ---- (1) aggregation alone
+    xo = x.double().requires_grad_(True)
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    agg_o = oracle.gin_aggregate(xo, ei, ea, po)
+    agg_o.backward(g.double())
+    t = params["edge_embedding_type.weight"].float().to(dev).requires_grad_(not frozen)
+    dr = params["edge_embedding_direction.weight"].float().to(dev).requires_grad_(not frozen)
+    xd = x.to(dev).requires_grad_(True)
+    agg = ga.gin.GinAggregateFunction.apply(xd, t, dr, ga.get_plan(ei_d, n, False),
+                                            ga.gin.edge_code_counts(ei_d, ea_d, n))
+    agg.backward(g.to(dev))
+    # unnormalised sums over up to 80 neighbours with cancellation: absolute term relative to scale
+    assert_close(agg.detach().cpu().double(), agg_o.detach(), "aggregate", 1e-5, grad_atol(agg_o.detach()))
+    assert_close(xd.grad.cpu().double(), xo.grad, "d aggregate / d x", 1e-5, grad_atol(xo.grad))
+    if not frozen:
+        for got, k in ((t.grad, "edge_embedding_type.weight"), (dr.grad, "edge_embedding_direction.weight")):
+            assert_close(got.cpu().double(), po[k].grad, f"grad {k}", 1e-5, grad_atol(po[k].grad))
+    else:
+        assert t.grad is None and dr.grad is None
+
+    # ---- (2) the whole layer through the module
+    want_out, want = oracle.gin_forward_backward(x.double(), ei, ea, params, g.double())
+    m = _module(d, params, dev)
+    if frozen:                                        # the adapter recipe: backbone frozen (gnn.py:230-241)
+        for p in m.parameters():
+            p.requires_grad_(False)
+    xd = x.to(dev).requires_grad_(True)
+    out = m(xd, ei_d, ea_d)
+    out.backward(g.to(dev))
+    # the MLP runs in the BLAS's fp32: dot products of 300-600 terms of O(1) -> relative to scale
+    assert_close(out.detach().cpu().double(), want_out, "out", 1e-5, grad_atol(want_out, 2e-5))
+    pre = torch.nn.functional.linear(agg_o.detach(), params["mlp.0.weight"], params["mlp.0.bias"])
+    risky = (pre.abs() < 3e-5).any(1)
+    reach = risky.clone()
+    reach[ei[0][risky[ei[1]]]] = True                # d x[j] sees d agg[i] for every edge j -> i
+    safe = ~reach
+    assert safe.sum() >= 0.9 * n
+    assert_close(xd.grad.cpu().double()[safe], want["x"][safe], "grad x", 1e-5, grad_atol(want["x"], 2e-5))
+    if frozen:
+        assert all(p.grad is None for p in m.parameters())
+    else:
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frozen", [True, False])
+def test_gin_layer_esol_batch(dev, frozen):
+    batch, cfg = ga.synth.make_workload("esol")
+    _check(dev, batch.x, batch.edge_index, _bond_attr(batch.edge_index.shape[1], 5), cfg["d"], 0, frozen)
+
+
+@pytest.mark.gpu
+def test_gin_layer_hiv_shard(dev):
+    batch, cfg = ga.synth.make_workload("hiv", graphs=128)
+    _check(dev, batch.x, batch.edge_index, _bond_attr(batch.edge_index.shape[1], 6), cfg["d"], 1, True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,e,d", [(1, 0, 4), (9, 0, 8), (200, 1500, 64), (50, 4000, 128), (300, 900, 1024)])
+def test_gin_layer_directed_graphs_with_duplicates_and_loops(dev, n, e, d):
+    g = torch.Generator().manual_seed(n + e)
+    ei = torch.stack([torch.randint(n, (e,), generator=g), torch.randint(n, (e,), generator=g)])
+    x = torch.randn(n, d, generator=g)
+    _check(dev, x, ei, _bond_attr(e, 7), d, 2, frozen=False)
+
+
+@pytest.mark.gpu
+def test_gin_aggregate_alone_is_tight_and_deterministic(dev):
+    """Without the MLP the HIP kernel is compared at the adapter's tolerance (1e-5) and bit-for-bit
+    against itself; the code counts are exact integers."""
+    batch, cfg = ga.synth.make_workload("hiv", graphs=64)
+    d, n = cfg["d"], batch.num_nodes
+    ea = _bond_attr(batch.edge_index.shape[1], 8)
+    params = oracle.init_params(d, seed=3)
+    want = oracle.gin_aggregate(batch.x.double(), batch.edge_index, ea, params)
+    ei_d, ea_d = batch.edge_index.to(dev), ea.to(dev)
+    counts = ga.gin.edge_code_counts(ei_d, ea_d, n)
+    hist = np.zeros((n, 18), dtype=np.int64)
+    np.add.at(hist, (batch.edge_index[1].numpy(), (ea[:, 0] * 3 + ea[:, 1]).numpy()), 1)
+    np.testing.assert_array_equal(counts[:-1].view(n, 18).cpu().numpy(), hist)
+    assert int(counts[-1]) == 0
+    assert ga.gin.edge_code_counts(ei_d, ea_d, n) is counts          # one histogram per batch
+    plan = ga.get_plan(ei_d, n, False)
+    t = params["edge_embedding_type.weight"].float().to(dev)
+    dr = params["edge_embedding_direction.weight"].float().to(dev)
+    x = batch.x.to(dev)
+    a = ga.gin.GinAggregateFunction.apply(x, t, dr, plan, counts)
+    b = ga.gin.GinAggregateFunction.apply(x, t, dr, plan, counts)
+    assert torch.equal(a, b)
+    assert_close(a.cpu().double(), want, "aggregate")
+
+
+@pytest.mark.gpu
+def test_gin_shares_the_batch_plan_with_the_adapters_and_validates_attributes(dev):
+    batch, cfg = ga.synth.make_workload("esol")
+    d = cfg["d"]
+    ei = batch.edge_index.to(dev)
+    ea = _bond_attr(ei.shape[1], 9).to(dev)
+    x = batch.x.to(dev)
+    ga.PLAN_CACHE.clear()
+    misses, hits = ga.PLAN_CACHE.misses, ga.PLAN_CACHE.hits
+    adapter = ga.GConvAdapter(d, 4, normalize=False).to(dev)       # the reference's YAML default
+    layer = ga.MolecularGINConv(d).to(dev)
+    h = layer(adapter(x, ei, ea), ei, ea)
+    assert h.shape == x.shape and ga.PLAN_CACHE.misses == misses + 1 and ga.PLAN_CACHE.hits == hits + 1
+    bad = ea.clone()
+    bad[3, 0] = 6                                                   # nn.Embedding would raise here
+    out = layer(x, ei, bad)                                         # default: skipped, never a device fault
+    assert torch.isfinite(out).all()
+    layer.validate_edge_attr = True
+    bad2 = bad.clone()
+    with pytest.raises(RuntimeError, match="bond"):
+        layer(x, ei, bad2)
+    with pytest.raises(RuntimeError, match="edge_attr must be int64"):
+        layer(x, ei, ea.float())
