@@ -22,7 +22,7 @@ constexpr int kBondTypes = 6;   // NUM_BOND_TYPE, gin_conv.py:6
 constexpr int kBondDirs = 3;    // NUM_BOND_DIRECTION, gin_conv.py:7
 constexpr int kBondCodes = kBondTypes * kBondDirs;
 constexpr int kSelfLoopType = 4;   // gin_conv.py:54
-constexpr int kGinPasses = 4;      // float4 lanes per row / 64: hidden <= 1024
+constexpr int kGinPasses = 4;      // float4 lanes per row / 64 at most: hidden <= 1024
 
 __global__ __launch_bounds__(256) void gin_code_count_kernel(const int64_t* __restrict__ edge_index,
                                                              const int64_t* __restrict__ edge_attr,
@@ -39,7 +39,11 @@ __global__ __launch_bounds__(256) void gin_code_count_kernel(const int64_t* __re
   atomicAdd(count + static_cast<size_t>(tgt) * kBondCodes + static_cast<int>(ty) * kBondDirs + static_cast<int>(di), 1);
 }
 
-template <bool BOND>
+// NP = float4 lanes per row / 64 (d = 300: 2). Waves are persistent over rows so that the nine
+// bond-embedding rows live in registers (9 x NP float4 per lane): re-reading them per row cost
+// 3.6x the row's own L1 traffic (18 table loads against ~5 row loads) and made the bond term as
+// expensive as the neighbour sum.
+template <int NP, bool BOND>
 __global__ __launch_bounds__(256) void gin_aggregate_kernel(const int32_t* __restrict__ rowptr,
                                                             const int32_t* __restrict__ col,
                                                             const float* __restrict__ x,
@@ -48,58 +52,95 @@ __global__ __launch_bounds__(256) void gin_aggregate_kernel(const int32_t* __res
                                                             const float* __restrict__ emb_dir,
                                                             float* __restrict__ out, int n, int d) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + wave_id();
-  if (row >= n) return;   // wave-uniform
   const int nq = d >> 2;
-  const int e0 = uniform(rowptr[row]), e1 = uniform(rowptr[row + 1]);
-  f32x4 acc[kGinPasses];
+  f32x4 table[BOND ? (kBondTypes + kBondDirs) : 1][NP];
+  if (BOND) {
 #pragma unroll
-  for (int p = 0; p < kGinPasses; ++p) {
-    const int q = lane + 64 * p;
-    acc[p] = q < nq ? ldg4(x + static_cast<size_t>(row) * d + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  for (int e = e0; e < e1; e += 4) {   // 4 neighbour rows in flight per pass
-    int c[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) c[k] = uniform(col[min(e + k, e1 - 1)]);
-#pragma unroll
-    for (int p = 0; p < kGinPasses; ++p) {
+    for (int p = 0; p < NP; ++p) {
       const int q = lane + 64 * p;
-      if (q < nq) {
-        f32x4 h[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) h[k] = ldg4(x + static_cast<size_t>(c[k]) * d + 4 * q);
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (e + k < e1) acc[p] += h[k];   // uniform condition; CSR order
+      for (int t = 0; t < kBondTypes + kBondDirs; ++t) {
+        const float* src = t < kBondTypes ? emb_type + static_cast<size_t>(t) * d
+                                          : emb_dir + static_cast<size_t>(t - kBondTypes) * d;
+        table[t][p] = q < nq ? ldg4(src + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
   }
-  if (BOND) {
-    int cnt[kBondCodes];
+  for (int row = blockIdx.x * 4 + wave_id(); row < n; row += gridDim.x * 4) {   // wave-uniform
+    const int e0 = uniform(rowptr[row]), e1 = uniform(rowptr[row + 1]);
+    int mine = 0;   // the node's 18 code counts: ONE coalesced load, issued before the gathers
+    if (BOND) mine = lane < kBondCodes ? count[static_cast<size_t>(row) * kBondCodes + lane] : 0;
+    f32x4 acc[NP];
 #pragma unroll
-    for (int c = 0; c < kBondCodes; ++c) cnt[c] = uniform(count[static_cast<size_t>(row) * kBondCodes + c]);
-#pragma unroll
-    for (int p = 0; p < kGinPasses; ++p) {
+    for (int p = 0; p < NP; ++p) {
       const int q = lane + 64 * p;
-      if (q < nq) {
-        acc[p] += ldg4(emb_type + static_cast<size_t>(kSelfLoopType) * d + 4 * q) + ldg4(emb_dir + 4 * q);
+      acc[p] = q < nq ? ldg4(x + static_cast<size_t>(row) * d + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int e = e0; e < e1; e += 4) {   // 4 neighbour rows in flight per pass
+      int c[4];
 #pragma unroll
-        for (int c = 0; c < kBondCodes; ++c) {
-          if (cnt[c] != 0) {   // uniform: a node has at most `degree` distinct codes
-            const f32x4 t = ldg4(emb_type + static_cast<size_t>(c / kBondDirs) * d + 4 * q) +
-                            ldg4(emb_dir + static_cast<size_t>(c % kBondDirs) * d + 4 * q);
-            acc[p] += t * static_cast<float>(cnt[c]);
-          }
+      for (int k = 0; k < 4; ++k) c[k] = uniform(col[min(e + k, e1 - 1)]);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int q = lane + 64 * p;
+        if (q < nq) {
+          f32x4 h[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) h[k] = ldg4(x + static_cast<size_t>(c[k]) * d + 4 * q);
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (e + k < e1) acc[p] += h[k];   // uniform condition; CSR order
         }
       }
     }
-  }
+    if (BOND) {
+      // bond term = sum_t n_type[t] * emb_type[t] + sum_k n_dir[k] * emb_dir[k] (self-loop: type
+      // 4, direction 0), the 18 code counts folded into 6 + 3 wave-uniform multiplicities
+      float nt[kBondTypes], nd[kBondDirs];
 #pragma unroll
-  for (int p = 0; p < kGinPasses; ++p) {
-    const int q = lane + 64 * p;
-    if (q < nq) stg4(out + static_cast<size_t>(row) * d + 4 * q, acc[p]);
+      for (int k = 0; k < kBondDirs; ++k) nd[k] = 0.f;
+#pragma unroll
+      for (int t = 0; t < kBondTypes; ++t) {
+        nt[t] = 0.f;
+#pragma unroll
+        for (int k = 0; k < kBondDirs; ++k) {
+          const float c = static_cast<float>(__builtin_amdgcn_readlane(mine, t * kBondDirs + k));
+          nt[t] += c;
+          nd[k] += c;
+        }
+      }
+      nt[kSelfLoopType] += 1.f;
+      nd[0] += 1.f;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int t = 0; t < kBondTypes; ++t) acc[p] += table[t][p] * nt[t];
+#pragma unroll
+        for (int k = 0; k < kBondDirs; ++k) acc[p] += table[kBondTypes + k][p] * nd[k];
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int q = lane + 64 * p;
+      if (q < nq) stg4(out + static_cast<size_t>(row) * d + 4 * q, acc[p]);
+    }
   }
+}
+
+template <int NP>
+static void launch_gin_aggregate(const gconv_csr_t* csr, const float* x, const int32_t* count,
+                                 const float* emb_type, const float* emb_dir, float* out, int d,
+                                 hipStream_t stream) {
+  // persistent waves, as many as fit (the rows of a molecule batch are short: what hides their
+  // latency is the number of waves, not the work per wave): the bond variant holds 9 x NP table
+  // registers per lane (110 VGPRs at NP = 2: 4 workgroups of 4 waves per CU), the plain one 8
+  const int grid = min(ceil_div(csr->num_nodes, 4), kNumCU * (count ? 4 : 8));
+  if (count)
+    gin_aggregate_kernel<NP, true><<<grid, 256, 0, stream>>>(csr->rowptr, csr->col, x, count, emb_type, emb_dir,
+                                                             out, csr->num_nodes, d);
+  else
+    gin_aggregate_kernel<NP, false><<<grid, 256, 0, stream>>>(csr->rowptr, csr->col, x, nullptr, nullptr, nullptr,
+                                                              out, csr->num_nodes, d);
 }
 
 }  // namespace gconv
@@ -137,13 +178,12 @@ extern "C" gconv_status_t gconv_gin_aggregate_f32(const gconv_csr_t* csr, const 
   if (!aligned16(x) || !aligned16(out) || (code_count && (!aligned16(emb_type) || !aligned16(emb_dir))))
     return GCONV_E_ALIGNMENT;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const int grid = ceil_div(csr->num_nodes, 4);
-  if (code_count)
-    gin_aggregate_kernel<true><<<grid, 256, 0, stream>>>(csr->rowptr, csr->col, x, code_count, emb_type,
-                                                         emb_dir, out, csr->num_nodes, hidden);
-  else
-    gin_aggregate_kernel<false><<<grid, 256, 0, stream>>>(csr->rowptr, csr->col, x, nullptr, nullptr, nullptr,
-                                                          out, csr->num_nodes, hidden);
+  switch (ceil_div(hidden, 256)) {
+    case 1: launch_gin_aggregate<1>(csr, x, code_count, emb_type, emb_dir, out, hidden, stream); break;
+    case 2: launch_gin_aggregate<2>(csr, x, code_count, emb_type, emb_dir, out, hidden, stream); break;
+    case 3: launch_gin_aggregate<3>(csr, x, code_count, emb_type, emb_dir, out, hidden, stream); break;
+    default: launch_gin_aggregate<4>(csr, x, code_count, emb_type, emb_dir, out, hidden, stream); break;
+  }
   GCONV_LAUNCH_CHECK();
   return GCONV_OK;
 }
