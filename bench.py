@@ -342,6 +342,31 @@ def measure_tile_kernels(device, name: str = "hiv4096") -> dict:
             f"{name}_adapter_frac_of_hbm_peak": round((fb + bb) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)}
 
 
+def measure_gin(device, name: str = "hiv4096") -> dict:
+    """Next to the path: the frozen GIN layer's aggregation (`csrc/gin.hip`) on the
+    whole 4096-molecule batch — neighbour sum + bond term forward, d agg -> d x backward — at
+    algorithmic bytes (read x, write agg, CSR, [N, 18] code counts), HIP events."""
+    batch, cfg = ga.synth.make_workload(name)
+    n, d = batch.num_nodes, cfg["d"]
+    ei = batch.edge_index.to(device)
+    e = ei.shape[1]
+    g = torch.Generator().manual_seed(0)
+    ea = torch.stack([torch.randint(0, 4, (e,), generator=g), torch.randint(0, 3, (e,), generator=g)], 1).to(device)
+    x = batch.x.to(device)
+    layer = ga.MolecularGINConv(d).to(device)
+    plan = ga.get_plan(ei, n, False)
+    counts = ga.gin.edge_code_counts(ei, ea, n)
+    t, dr = layer.edge_embedding_type.weight.detach(), layer.edge_embedding_direction.weight.detach()
+    fwd_ms = event_time_ms(lambda: ga.gin._aggregate(plan.fwd, x, counts, t, dr), 50)
+    bwd_ms = event_time_ms(lambda: ga.gin._aggregate(plan.bwd, x, None, None, None), 50)
+    fb = 2 * n * d * 4 + 4 * (n + 1) + 4 * plan.fwd.nnz + 4 * 18 * n
+    bb = 2 * n * d * 4 + 4 * (n + 1) + 4 * plan.fwd.nnz
+    ga.PLAN_CACHE.clear()
+    return {f"{name}_gin_aggregate_fwd_us": round(fwd_ms * 1e3, 1), f"{name}_gin_aggregate_bwd_us": round(bwd_ms * 1e3, 1),
+            f"{name}_gin_aggregate_fwd_GBs": round(fb / (fwd_ms * 1e-3) / 1e9, 1),
+            f"{name}_gin_aggregate_bwd_GBs": round(bb / (bwd_ms * 1e-3) / 1e9, 1)}
+
+
 def measure_banded(device, r: int, flags: int, lib) -> dict:
     """Control (`--banded`): the SAME SpMM kernel on a graph of the same average degree whose
     neighbours are local (banded, 1 M nodes): how close it gets to HBM when gathers hit L2.
@@ -564,6 +589,7 @@ def main() -> None:
             line["roofline"] = ax["roofline"]
             extra.update(ax["extra"])
             extra.update(measure_tile_kernels(device))
+            extra.update(measure_gin(device))
             other = "esol" if args.workload != "esol" else "hiv"
             o = run_workload(other, normalize, max(20, args.steps // 2), args.warmup, rank, world,
                              device, with_cpu=not args.no_cpu_baseline)
