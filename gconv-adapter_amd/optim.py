@@ -6,10 +6,13 @@ fine-tuning loops (``/root/reference/scripts/finetune_inductive_learning.py:375-
 ``lr`` / ``weight_decay`` / ``betas`` / ``eps``), same update rule, ``state_dict()`` in the
 same per-parameter format — but the trainable parameters of a group live in ONE flat buffer
 (``p.data`` of every parameter becomes a view of it; ``Parameter`` objects, names and
-``state_dict`` keys of the model are untouched) and a step is ONE ``torch.cat`` of the
+``state_dict`` keys of the model are untouched) and a step is ONE multi-tensor copy of the
 gradients plus ONE ``gconv_adam_step_f32`` launch per group instead of ~10 multi-tensor
 launches. Frozen parameters (``requires_grad=False``) are ignored, as torch's Adam ignores
-parameters without a gradient. There is no CPU path.
+parameters without a gradient. Every parameter starts on a 16-byte boundary of the flat buffer
+(the adapter kernels read weights and biases with 16-byte loads and reject misaligned ones —
+a ``scalar`` of one float would otherwise shift everything behind it); the padding floats are
+zero, receive zero gradients and stay zero. There is no CPU path.
 """
 from __future__ import annotations
 
@@ -41,8 +44,8 @@ class FusedAdam(torch.optim.Optimizer):
         for p in ps:
             if not p.is_cuda or p.dtype != torch.float32 or p.device != dev:
                 raise RuntimeError("FusedAdam needs fp32 parameters on one HIP device (no CPU path)")
-        total = sum(p.numel() for p in ps)
-        flat = torch.empty(total, dtype=dt, device=dev)
+        total = sum(-(-p.numel() // 4) * 4 for p in ps)
+        flat = torch.zeros(total, dtype=dt, device=dev)
         m = torch.zeros_like(flat)
         v = torch.zeros_like(flat)
         off = 0
@@ -56,8 +59,10 @@ class FusedAdam(torch.optim.Optimizer):
                                  "exp_avg": m[off:off + n].view_as(p),
                                  "exp_avg_sq": v[off:off + n].view_as(p)}
                 offsets.append(off)
-                off += n
-        return dict(params=ps, offsets=offsets, total=total, flat=flat, grad=torch.empty_like(flat),
+                off += -(-n // 4) * 4
+        grad = torch.zeros_like(flat)
+        grad_views = [grad[o:o + p.numel()].view_as(p) for p, o in zip(ps, offsets)]
+        return dict(params=ps, offsets=offsets, total=total, flat=flat, grad=grad, grad_views=grad_views,
                     exp_avg=m, exp_avg_sq=v, step=0)
 
     # ------------------------------------------------------------------ step
@@ -77,8 +82,8 @@ class FusedAdam(torch.optim.Optimizer):
             fl["step"] += 1     # (the per-parameter "step" tensors are refreshed by state_dict())
             beta1, beta2 = group["betas"]
             dev = fl["flat"].device
-            if not any(g is None for g in grads):   # the normal case: one cat, one launch
-                torch.cat([g.reshape(-1) for g in grads], out=fl["grad"])
+            if not any(g is None for g in grads):   # the normal case: one multi-tensor copy, one launch
+                torch._foreach_copy_(fl["grad_views"], grads)
                 st = self._lib.gconv_adam_step_f32(
                     fl["flat"].data_ptr(), fl["grad"].data_ptr(), fl["exp_avg"].data_ptr(),
                     fl["exp_avg_sq"].data_ptr(), fl["total"], float(group["lr"]), float(beta1), float(beta2),
@@ -96,7 +101,7 @@ class FusedAdam(torch.optim.Optimizer):
                     j += 1
                 lo = fl["offsets"][i]
                 hi = fl["offsets"][j - 1] + ps[j - 1].numel()
-                torch.cat([g.reshape(-1) for g in grads[i:j]], out=fl["grad"][lo:hi])
+                torch._foreach_copy_(fl["grad_views"][i:j], grads[i:j])
                 st = self._lib.gconv_adam_step_f32(
                     fl["flat"].data_ptr() + 4 * lo, fl["grad"].data_ptr() + 4 * lo,
                     fl["exp_avg"].data_ptr() + 4 * lo, fl["exp_avg_sq"].data_ptr() + 4 * lo, hi - lo,
