@@ -124,6 +124,10 @@ SIGNATURES = {
     "gconv_gin_code_count_bytes": (_sz, [_i32]),
     "gconv_gin_code_count": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "gconv_gin_aggregate_f32": (_i32, [_csr_p, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "gconv_layer_norm_scale_bwd_workspace_bytes": (_sz, [_i32, _i32]),
+    "gconv_layer_norm_scale_fwd_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, C.c_float, _vp]),
+    "gconv_layer_norm_scale_bwd_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
+                                              _vp, _sz, _vp]),
     "gconv_adam_step_f32": (_i32, [_vp, _vp, _vp, _vp, C.c_int64, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_float, C.c_int64, _vp]),
 }

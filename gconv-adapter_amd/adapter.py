@@ -22,11 +22,13 @@ import torch
 import torch.nn as nn
 
 from . import _lib, _torch_ext
-from .functional import GConvAdapterFunction, _stream
+from .functional import GConvAdapterFunction, LayerNormScaleFunction, _stream
 from .graph import get_plan
 
 #: default of ``GConvAdapter.direct_param_grads`` (env GCONV_AUTOGRAD_PARAM_GRADS=1 turns it off)
 DIRECT_PARAM_GRADS = not os.environ.get("GCONV_AUTOGRAD_PARAM_GRADS")
+#: A/B knob: run the layer_norm tail with torch ops (LayerNorm + multiply) instead of csrc/norm.hip
+TORCH_LAYER_NORM = bool(os.environ.get("GCONV_TORCH_LAYER_NORM"))
 
 
 class GCNConvParams(nn.Module):
@@ -207,7 +209,15 @@ class GConvAdapter(nn.Module):
         if isinstance(self.normalization, nn.BatchNorm1d):
             if out.size(0) > 1:  # reference :99 (always skipped for [1, N, d])
                 out = self.normalization(out)
-        elif isinstance(self.normalization, nn.LayerNorm):
+        elif isinstance(self.normalization, nn.LayerNorm) and not TORCH_LAYER_NORM:
+            ln = self.normalization   # LayerNorm and the scalar in one HIP pass (csrc/norm.hip)
+            ext = _torch_ext.get()
+            if ext is not None:
+                if out.device.index != torch.cuda.current_device():
+                    torch.cuda.set_device(out.device)
+                return ext.layer_norm_scale(out, ln.weight, ln.bias, self.scalar, ln.eps, _stream(out.device.index))
+            return LayerNormScaleFunction.apply(out, ln.weight, ln.bias, self.scalar, ln.eps)
+        elif isinstance(self.normalization, nn.LayerNorm):   # A/B knob: torch's LayerNorm + multiply
             out = self.normalization(out)
         if not fuse_scalar and self.scalar is not None:
             out = out * self.scalar

@@ -1,0 +1,280 @@
+// Next to the path: the adapter's `layer_norm` tail on the device.
+//
+// With normalization='layer_norm' the reference finishes the adapter with
+//   out = LayerNorm(out) ; out = out * scalar        (gconv_adapter.py:101-102, 105-106)
+// i.e. two more element-wise passes over [N, d] forward and four to five backward (LayerNorm's
+// dx and its dgamma / dbeta reduction, the scalar multiply's two products and its reduction).
+// Here: ONE pass forward (row statistics in registers, normalise, affine, scale) and one pass +
+// a small fixed-order reduction backward. One wave per row, a row of d floats as float4 lanes
+// (d = 300: 75 lanes, two passes); the backward's waves are persistent over rows so the column
+// sums for dgamma / dbeta (and the scalar's gradient) accumulate in registers and leave the
+// workgroup once, as one partial row. No atomics: results are bitwise reproducible.
+#include "common.h"
+
+namespace gconv {
+
+constexpr int kLnPasses = 4;   // hidden <= 1024
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void ln_scale_fwd_kernel(const float* __restrict__ z,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const float* __restrict__ scalar,
+                                                           float* __restrict__ out,
+                                                           float* __restrict__ stats, int n, int d,
+                                                           float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave_id();
+  if (row >= n) return;   // wave-uniform
+  const int nq = d >> 2;
+  const float s = scalar ? scalar[0] : 1.f;
+  f32x4 v[NP];
+  float sum = 0.f;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int q = lane + 64 * p;
+    v[p] = q < nq ? ldg4(z + static_cast<size_t>(row) * d + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    sum += (v[p][0] + v[p][1]) + (v[p][2] + v[p][3]);
+  }
+  const float mean = wave_sum(sum) / static_cast<float>(d);
+  float sq = 0.f;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int q = lane + 64 * p;
+    if (q < nq) {
+      const f32x4 c = v[p] - mean;
+      sq += (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / static_cast<float>(d) + eps);   // biased variance, as torch
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int q = lane + 64 * p;
+    if (q < nq) {
+      f32x4 y = (v[p] - mean) * rstd;
+      if (gamma) y = y * ldg4(gamma + 4 * q);
+      if (beta) y = y + ldg4(beta + 4 * q);
+      stg4(out + static_cast<size_t>(row) * d + 4 * q, y * s);
+    }
+  }
+  if (lane == 0) {
+    stats[2 * row] = mean;
+    stats[2 * row + 1] = rstd;
+  }
+}
+
+// partial row layout: [dgamma (d) | dbeta (d) | dscalar (1)], one row per workgroup
+template <int NP>
+__global__ __launch_bounds__(256) void ln_scale_bwd_kernel(const float* __restrict__ g,
+                                                           const float* __restrict__ z,
+                                                           const float* __restrict__ stats,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const float* __restrict__ scalar,
+                                                           float* __restrict__ dz,
+                                                           float* __restrict__ part, int n, int d) {
+  __shared__ f32x4 red[3][64 * NP];   // waves 1..3 hand their column sums to wave 0
+  __shared__ float red_s[4];
+  const int lane = threadIdx.x & 63, wave = wave_id();
+  const int nq = d >> 2;
+  const float s = scalar ? scalar[0] : 1.f;
+  f32x4 gam[NP], bet[NP], dgam[NP], dbet[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int q = lane + 64 * p;
+    gam[p] = (gamma && q < nq) ? ldg4(gamma + 4 * q) : f32x4{1.f, 1.f, 1.f, 1.f};
+    bet[p] = (beta && q < nq) ? ldg4(beta + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    dgam[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dbet[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float ds = 0.f;
+  for (int row = blockIdx.x * 4 + wave; row < n; row += gridDim.x * 4) {   // wave-uniform
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    f32x4 xh[NP], dyg[NP];
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int q = lane + 64 * p;
+      if (q < nq) {
+        const f32x4 gv = ldg4(g + static_cast<size_t>(row) * d + 4 * q);
+        xh[p] = (ldg4(z + static_cast<size_t>(row) * d + 4 * q) - mean) * rstd;
+        const f32x4 y = xh[p] * gam[p] + bet[p];      // LayerNorm output (before the scalar)
+        const f32x4 dy = gv * s;
+        ds += (gv[0] * y[0] + gv[1] * y[1]) + (gv[2] * y[2] + gv[3] * y[3]);
+        dgam[p] += dy * xh[p];
+        dbet[p] += dy;
+        dyg[p] = dy * gam[p];
+        a += (dyg[p][0] + dyg[p][1]) + (dyg[p][2] + dyg[p][3]);
+        const f32x4 t = dyg[p] * xh[p];
+        b += (t[0] + t[1]) + (t[2] + t[3]);
+      } else {
+        xh[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dyg[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    a = wave_sum(a) / static_cast<float>(d);
+    b = wave_sum(b) / static_cast<float>(d);
+    if (dz) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int q = lane + 64 * p;
+        if (q < nq) stg4(dz + static_cast<size_t>(row) * d + 4 * q, (dyg[p] - a - xh[p] * b) * rstd);
+      }
+    }
+  }
+  // one partial row per workgroup, waves added in wave order
+  ds = wave_sum(ds);
+  if (wave > 0) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) red[wave - 1][lane + 64 * p] = dgam[p];
+  }
+  if (lane == 0) red_s[wave] = ds;
+  __syncthreads();
+  float* prow = part + static_cast<size_t>(blockIdx.x) * (2 * d + 1);
+  if (wave == 0) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int q = lane + 64 * p;
+      f32x4 t = dgam[p];
+      for (int w = 0; w < 3; ++w) t += red[w][lane + 64 * p];
+      if (q < nq) {
+        for (int k = 0; k < 4; ++k) prow[4 * q + k] = t[k];
+      }
+    }
+    if (lane == 0) prow[2 * d] = (red_s[0] + red_s[1]) + (red_s[2] + red_s[3]);
+  }
+  __syncthreads();
+  if (wave > 0) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) red[wave - 1][lane + 64 * p] = dbet[p];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int q = lane + 64 * p;
+      f32x4 t = dbet[p];
+      for (int w = 0; w < 3; ++w) t += red[w][lane + 64 * p];
+      if (q < nq) {
+        for (int k = 0; k < 4; ++k) prow[d + 4 * q + k] = t[k];
+      }
+    }
+  }
+}
+
+// column sums of the partial rows in a fixed order: a block owns 16 columns, its 16 row groups
+// walk the partial rows 16 apart (4 loads in flight each) and are added in group order
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ part, int nparts,
+                                                          int d, float* __restrict__ g_gamma,
+                                                          float* __restrict__ g_beta,
+                                                          float* __restrict__ g_scalar) {
+  __shared__ float red[16][17];
+  const int width = 2 * d + 1;
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < width) {
+    int r = rg;
+    for (; r + 48 < nparts; r += 64) {
+      a0 += part[static_cast<size_t>(r) * width + c];
+      a1 += part[static_cast<size_t>(r + 16) * width + c];
+      a2 += part[static_cast<size_t>(r + 32) * width + c];
+      a3 += part[static_cast<size_t>(r + 48) * width + c];
+    }
+    for (; r < nparts; r += 16) a0 += part[static_cast<size_t>(r) * width + c];
+  }
+  red[rg][cl] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (rg != 0 || c >= width) return;
+  float v = 0.f;
+  for (int k = 0; k < 16; ++k) v += red[k][cl];
+  if (c < d) {
+    if (g_gamma) g_gamma[c] = v;
+  } else if (c < 2 * d) {
+    if (g_beta) g_beta[c - d] = v;
+  } else if (g_scalar) {
+    g_scalar[0] = v;
+  }
+}
+
+static int ln_bwd_grid(int n) { return min(ceil_div(n > 0 ? n : 1, 4), kNumCU * 2); }
+
+}  // namespace gconv
+
+using namespace gconv;
+
+static gconv_status_t ln_check(int32_t n, int32_t d) {
+  if (n < 0) return GCONV_E_INVALID_ARG;
+  if (d <= 0 || d % 4 != 0 || d > 256 * kLnPasses) return GCONV_E_UNSUPPORTED;
+  return GCONV_OK;
+}
+
+extern "C" size_t gconv_layer_norm_scale_bwd_workspace_bytes(int32_t num_nodes, int32_t hidden) {
+  if (ln_check(num_nodes, hidden) != GCONV_OK) return 0;
+  return align_up(static_cast<size_t>(ln_bwd_grid(num_nodes)) * (2 * hidden + 1) * sizeof(float) + 16, 256);
+}
+
+extern "C" gconv_status_t gconv_layer_norm_scale_fwd_f32(const float* z, const float* gamma,
+                                                         const float* beta, const float* scalar,
+                                                         float* out, float* stats, int32_t num_nodes,
+                                                         int32_t hidden, float eps,
+                                                         gconv_stream_t stream_) {
+  const gconv_status_t st = ln_check(num_nodes, hidden);
+  if (st != GCONV_OK) return st;
+  if (num_nodes == 0) return GCONV_OK;
+  if (!z || !out || !stats) return GCONV_E_INVALID_ARG;
+  if (!aligned16(z) || !aligned16(out) || (gamma && !aligned16(gamma)) || (beta && !aligned16(beta)))
+    return GCONV_E_ALIGNMENT;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int grid = ceil_div(num_nodes, 4);
+  switch (ceil_div(hidden, 256)) {
+    case 1: ln_scale_fwd_kernel<1><<<grid, 256, 0, stream>>>(z, gamma, beta, scalar, out, stats, num_nodes, hidden, eps); break;
+    case 2: ln_scale_fwd_kernel<2><<<grid, 256, 0, stream>>>(z, gamma, beta, scalar, out, stats, num_nodes, hidden, eps); break;
+    case 3: ln_scale_fwd_kernel<3><<<grid, 256, 0, stream>>>(z, gamma, beta, scalar, out, stats, num_nodes, hidden, eps); break;
+    default: ln_scale_fwd_kernel<4><<<grid, 256, 0, stream>>>(z, gamma, beta, scalar, out, stats, num_nodes, hidden, eps); break;
+  }
+  GCONV_LAUNCH_CHECK();
+  return GCONV_OK;
+}
+
+extern "C" gconv_status_t gconv_layer_norm_scale_bwd_f32(const float* grad_out, const float* z,
+                                                         const float* stats, const float* gamma,
+                                                         const float* beta, const float* scalar,
+                                                         float* grad_z, float* grad_gamma,
+                                                         float* grad_beta, float* grad_scalar,
+                                                         int32_t num_nodes, int32_t hidden,
+                                                         void* workspace, size_t workspace_bytes,
+                                                         gconv_stream_t stream_) {
+  const gconv_status_t st = ln_check(num_nodes, hidden);
+  if (st != GCONV_OK) return st;
+  if (!workspace || workspace_bytes < gconv_layer_norm_scale_bwd_workspace_bytes(num_nodes, hidden))
+    return GCONV_E_WORKSPACE;
+  if (num_nodes > 0 && (!grad_out || !z || !stats)) return GCONV_E_INVALID_ARG;
+  if (!aligned16(grad_out) || !aligned16(z) || (grad_z && !aligned16(grad_z)) ||
+      (gamma && !aligned16(gamma)) || (beta && !aligned16(beta)) || !aligned16(workspace))
+    return GCONV_E_ALIGNMENT;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  float* part = static_cast<float*>(workspace);
+  const int grid = num_nodes > 0 ? ln_bwd_grid(num_nodes) : 0;
+  if (grid > 0) {
+    switch (ceil_div(hidden, 256)) {
+      case 1: ln_scale_bwd_kernel<1><<<grid, 256, 0, stream>>>(grad_out, z, stats, gamma, beta, scalar, grad_z, part, num_nodes, hidden); break;
+      case 2: ln_scale_bwd_kernel<2><<<grid, 256, 0, stream>>>(grad_out, z, stats, gamma, beta, scalar, grad_z, part, num_nodes, hidden); break;
+      case 3: ln_scale_bwd_kernel<3><<<grid, 256, 0, stream>>>(grad_out, z, stats, gamma, beta, scalar, grad_z, part, num_nodes, hidden); break;
+      default: ln_scale_bwd_kernel<4><<<grid, 256, 0, stream>>>(grad_out, z, stats, gamma, beta, scalar, grad_z, part, num_nodes, hidden); break;
+    }
+    GCONV_LAUNCH_CHECK();
+  }
+  if (grad_gamma || grad_beta || grad_scalar) {
+    ln_finalize_kernel<<<ceil_div(2 * hidden + 1, 16), 256, 0, stream>>>(part, grid, hidden, grad_gamma, grad_beta,
+                                                                         grad_scalar);
+    GCONV_LAUNCH_CHECK();
+  }
+  return GCONV_OK;
+}

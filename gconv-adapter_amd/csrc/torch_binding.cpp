@@ -44,6 +44,12 @@ using bwd_partial_fn_t = gconv_status_t (*)(const gconv_graph_t*, const gconv_ad
                                             const float*, float*, float*, float*, float*, float*, float*,
                                             void*, size_t, gconv_pending_finalize_t*, gconv_stream_t);
 using bwd_finalize_fn_t = gconv_status_t (*)(const gconv_pending_finalize_t*, int32_t, gconv_stream_t);
+using ln_fwd_fn_t = gconv_status_t (*)(const float*, const float*, const float*, const float*, float*, float*,
+                                       int32_t, int32_t, float, gconv_stream_t);
+using ln_bwd_fn_t = gconv_status_t (*)(const float*, const float*, const float*, const float*, const float*,
+                                       const float*, float*, float*, float*, float*, int32_t, int32_t, void*,
+                                       size_t, gconv_stream_t);
+using ln_bytes_fn_t = size_t (*)(int32_t, int32_t);
 
 struct Lib {
   void* handle = nullptr;
@@ -54,6 +60,9 @@ struct Lib {
   build_fn_t build = nullptr;
   bwd_partial_fn_t bwd_partial = nullptr;
   bwd_finalize_fn_t bwd_finalize = nullptr;
+  ln_fwd_fn_t ln_fwd = nullptr;
+  ln_bwd_fn_t ln_bwd = nullptr;
+  ln_bytes_fn_t ln_bytes = nullptr;
 };
 Lib g_lib;
 
@@ -68,8 +77,11 @@ void load_library(const std::string& path) {
   g_lib.build = reinterpret_cast<build_fn_t>(dlsym(h, "gconv_graph_build"));
   g_lib.bwd_partial = reinterpret_cast<bwd_partial_fn_t>(dlsym(h, "gconv_adapter_bwd_partial_f32"));
   g_lib.bwd_finalize = reinterpret_cast<bwd_finalize_fn_t>(dlsym(h, "gconv_adapter_bwd_finalize_f32"));
+  g_lib.ln_fwd = reinterpret_cast<ln_fwd_fn_t>(dlsym(h, "gconv_layer_norm_scale_fwd_f32"));
+  g_lib.ln_bwd = reinterpret_cast<ln_bwd_fn_t>(dlsym(h, "gconv_layer_norm_scale_bwd_f32"));
+  g_lib.ln_bytes = reinterpret_cast<ln_bytes_fn_t>(dlsym(h, "gconv_layer_norm_scale_bwd_workspace_bytes"));
   TORCH_CHECK(g_lib.fwd && g_lib.bwd && g_lib.str && g_lib.build_bytes && g_lib.build && g_lib.bwd_partial &&
-                  g_lib.bwd_finalize,
+                  g_lib.bwd_finalize && g_lib.ln_fwd && g_lib.ln_bwd && g_lib.ln_bytes,
               "gconv_adapter_amd: C ABI symbols missing in ", path);
   g_lib.handle = h;
 }
@@ -500,6 +512,59 @@ int64_t plan_submit(at::Tensor edge_index, int64_t num_nodes, bool normalize, in
 }
 std::tuple<at::Tensor, py::bytes, int64_t> plan_take(int64_t id) { return worker().take(id); }
 
+
+// out = scalar * LayerNorm(z): the adapter's layer_norm tail (gconv_adapter.py:101-102,105-106),
+// mirroring functional.LayerNormScaleFunction (csrc/norm.hip does the work)
+struct LayerNormScaleFn : public torch::autograd::Function<LayerNormScaleFn> {
+  static at::Tensor forward(torch::autograd::AutogradContext* ctx, at::Tensor z,
+                            c10::optional<at::Tensor> gamma_, c10::optional<at::Tensor> beta_,
+                            c10::optional<at::Tensor> scalar_, double eps, int64_t stream) {
+    at::Tensor gamma = gamma_.value_or(at::Tensor()), beta = beta_.value_or(at::Tensor()),
+               scalar = scalar_.value_or(at::Tensor());
+    TORCH_CHECK(g_lib.handle, "gconv_adapter_amd: library not loaded");
+    TORCH_CHECK(z.is_cuda() && z.scalar_type() == at::kFloat && z.dim() >= 1,
+                "gconv_adapter_amd computes in fp32 on a HIP device (no CPU path)");
+    if (!z.is_contiguous()) z = z.contiguous();
+    const int64_t d = z.size(-1), n = d > 0 ? z.numel() / d : 0;
+    at::Tensor out = at::empty_like(z);
+    at::Tensor stats = at::empty({n, 2}, z.options());
+    check(g_lib.ln_fwd(z.data_ptr<float>(), fptr(gamma), fptr(beta), fptr(scalar), out.data_ptr<float>(),
+                       stats.data_ptr<float>(), static_cast<int32_t>(n), static_cast<int32_t>(d),
+                       static_cast<float>(eps), reinterpret_cast<void*>(stream)),
+          "layer_norm_scale_fwd");
+    ctx->save_for_backward({z, stats, gamma, beta, scalar});
+    ctx->saved_data["stream"] = stream;
+    return out;
+  }
+
+  static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx,
+                                                 torch::autograd::variable_list grads) {
+    auto sv = ctx->get_saved_variables();
+    at::Tensor z = sv[0], stats = sv[1], gamma = sv[2], beta = sv[3], scalar = sv[4];
+    at::Tensor go = grads[0];
+    if (!go.is_contiguous()) go = go.contiguous();
+    const int64_t d = z.size(-1), n = d > 0 ? z.numel() / d : 0;
+    at::Tensor gz, gg, gb, gs;
+    if (ctx->needs_input_grad(0)) gz = at::empty_like(z);
+    if (gamma.defined()) gg = at::empty_like(gamma);
+    if (beta.defined()) gb = at::empty_like(beta);
+    if (scalar.defined()) gs = at::empty_like(scalar);
+    const size_t bytes = g_lib.ln_bytes(static_cast<int32_t>(n), static_cast<int32_t>(d));
+    at::Tensor ws = at::empty({static_cast<int64_t>(bytes > 16 ? bytes : 16)}, z.options().dtype(at::kByte));
+    check(g_lib.ln_bwd(go.data_ptr<float>(), z.data_ptr<float>(), stats.data_ptr<float>(), fptr(gamma),
+                       fptr(beta), fptr(scalar), fptr_mut(gz), fptr_mut(gg), fptr_mut(gb), fptr_mut(gs),
+                       static_cast<int32_t>(n), static_cast<int32_t>(d), ws.data_ptr(),
+                       static_cast<size_t>(ws.numel()), reinterpret_cast<void*>(ctx->saved_data["stream"].toInt())),
+          "layer_norm_scale_bwd");
+    return {gz, gg, gb, gs, at::Tensor(), at::Tensor()};
+  }
+};
+
+at::Tensor layer_norm_scale(at::Tensor z, c10::optional<at::Tensor> gamma, c10::optional<at::Tensor> beta,
+                            c10::optional<at::Tensor> scalar, double eps, int64_t stream) {
+  return LayerNormScaleFn::apply(std::move(z), std::move(gamma), std::move(beta), std::move(scalar), eps, stream);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -511,4 +576,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("pack_release", &pack_release);
   m.def("plan_submit", &plan_submit);
   m.def("plan_take", &plan_take);
+  m.def("layer_norm_scale", &layer_norm_scale);
 }

@@ -180,3 +180,51 @@ def gemm_up_fused(p: torch.Tensor, w_up: torch.Tensor, b_up: Optional[torch.Tens
                                          out.data_ptr(), n, d, r, _stream())
     _lib.check(st, "gemm_up_fused_f32")
     return out
+
+
+class LayerNormScaleFunction(torch.autograd.Function):
+    """out = scalar * LayerNorm(z) — the adapter's ``layer_norm`` tail
+    (``src/finetune/gconv_adapter.py:101-102,105-106``) in one HIP pass each way
+    (``csrc/norm.hip``) instead of torch's LayerNorm + multiply and their five backward kernels."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, scalar, eps: float):
+        lib = _lib.load()
+        _require_hip_f32(z, "z")
+        shape = z.shape
+        z2 = z.contiguous().view(-1, shape[-1])
+        n, d = z2.shape
+        dev = z.device
+        if dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        out = torch.empty_like(z2)
+        stats = torch.empty(n, 2, dtype=torch.float32, device=dev)
+        st = lib.gconv_layer_norm_scale_fwd_f32(z2.data_ptr(), _ptr(gamma), _ptr(beta), _ptr(scalar),
+                                                out.data_ptr(), stats.data_ptr(), n, d, float(eps), _stream(dev.index))
+        if st != 0:
+            _lib.check(st, "layer_norm_scale_fwd")
+        ctx.save_for_backward(z2, stats, gamma, beta, scalar)
+        ctx.shape = shape
+        return out.view(shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        z2, stats, gamma, beta, scalar = ctx.saved_tensors
+        n, d = z2.shape
+        g2 = g.contiguous().view(n, d)
+        dev = z2.device
+        if dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        gz = torch.empty_like(z2) if ctx.needs_input_grad[0] else None
+        ggam = torch.empty_like(gamma) if gamma is not None else None
+        gbet = torch.empty_like(beta) if beta is not None else None
+        gsc = torch.empty_like(scalar) if scalar is not None else None
+        nbytes = int(lib.gconv_layer_norm_scale_bwd_workspace_bytes(n, d))
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+        st = lib.gconv_layer_norm_scale_bwd_f32(g2.data_ptr(), z2.data_ptr(), stats.data_ptr(), _ptr(gamma),
+                                                _ptr(beta), _ptr(scalar), _ptr(gz), _ptr(ggam), _ptr(gbet),
+                                                _ptr(gsc), n, d, ws.data_ptr(), ws.numel(), _stream(dev.index))
+        if st != 0:
+            _lib.check(st, "layer_norm_scale_bwd")
+        return (gz.view(ctx.shape) if gz is not None else None), ggam, gbet, gsc, None

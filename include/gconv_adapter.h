@@ -372,6 +372,27 @@ gconv_status_t gconv_gin_aggregate_f32(const gconv_csr_t* csr, const float* x,
                                        const float* emb_dir, float* out, int32_t hidden,
                                        gconv_stream_t stream);
 
+/* ---- next to the path: the adapter's `layer_norm` tail ---------------------------
+ * replaces: `out = self.normalization(out)` for nn.LayerNorm and `out = out * self.scalar`
+ * (`gconv_adapter.py:101-102,105-106`) — and their autograd backward — with one pass each way:
+ *   out = scalar * (gamma . (z - mean) * rstd + beta),  per-row mean / biased variance, eps inside
+ * the square root (torch.nn.LayerNorm). gamma, beta, scalar (device, 1 float) nullable. `stats`
+ * [num_nodes, 2] receives (mean, rstd) for the backward. The backward overwrites grad_z (nullable),
+ * grad_gamma / grad_beta [hidden] and grad_scalar [1] (each nullable); hidden a multiple of 4,
+ * <= 1024. Deterministic (fixed-order reductions, no atomics).                                  */
+size_t gconv_layer_norm_scale_bwd_workspace_bytes(int32_t num_nodes, int32_t hidden);
+gconv_status_t gconv_layer_norm_scale_fwd_f32(const float* z, const float* gamma, const float* beta,
+                                              const float* scalar, float* out, float* stats,
+                                              int32_t num_nodes, int32_t hidden, float eps,
+                                              gconv_stream_t stream);
+gconv_status_t gconv_layer_norm_scale_bwd_f32(const float* grad_out, const float* z,
+                                              const float* stats, const float* gamma,
+                                              const float* beta, const float* scalar, float* grad_z,
+                                              float* grad_gamma, float* grad_beta,
+                                              float* grad_scalar, int32_t num_nodes, int32_t hidden,
+                                              void* workspace, size_t workspace_bytes,
+                                              gconv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

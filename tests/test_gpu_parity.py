@@ -810,3 +810,48 @@ def test_arxiv_scale_properties(dev):
     want = oracle.adapter_forward_reassociated(batch.x.double(), batch.edge_index,
                                                {k: v.double() for k, v in params.items()}, flags)
     assert_close(outs[0][0].cpu().double(), want, "arxiv-scale out")
+
+
+# ---------------------------------------------------------------------------
+# layer_norm tail: LayerNorm + scalar in one pass each way
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,affine,with_scalar", [
+    ((1, 8), True, True), ((5, 300), True, True), ((3000, 300), True, True), ((1, 700, 32), True, True),
+    ((257, 1024), True, False), ((64, 128), False, True), ((33, 516), False, False)])
+def test_layer_norm_scale_matches_torch_fp64(dev, shape, affine, with_scalar):
+    from gconv_adapter_amd.functional import LayerNormScaleFunction
+    d = shape[-1]
+    g = torch.Generator().manual_seed(d + shape[0])
+    z = (3.0 * torch.randn(shape, generator=g) + 1.5)
+    gamma = (1.0 + 0.3 * torch.randn(d, generator=g)) if affine else None
+    beta = (0.3 * torch.randn(d, generator=g)) if affine else None
+    s = torch.tensor([1.3]) if with_scalar else None
+    go = torch.randn(shape, generator=g)
+    leaves = [t.double().requires_grad_(True) if t is not None else None for t in (z, gamma, beta, s)]
+    want = torch.nn.functional.layer_norm(leaves[0], (d,), leaves[1], leaves[2], 1e-5)
+    if s is not None:
+        want = want * leaves[3]
+    want.backward(go.double())
+    dl = [t.to(dev).requires_grad_(True) if t is not None else None for t in (z, gamma, beta, s)]
+    got = LayerNormScaleFunction.apply(dl[0], dl[1], dl[2], dl[3], 1e-5)
+    got.backward(go.to(dev))
+    assert got.shape == z.shape
+    assert_close(got.detach().cpu().double(), want.detach(), "out")
+    assert_close(dl[0].grad.cpu().double(), leaves[0].grad, "grad z", 1e-5, 1e-5)
+    for name, a, b in (("gamma", dl[1], leaves[1]), ("beta", dl[2], leaves[2]), ("scalar", dl[3], leaves[3])):
+        if a is not None:
+            assert_close(a.grad.cpu().double(), b.grad, f"grad {name}", 1e-5, grad_atol(b.grad))
+    again = LayerNormScaleFunction.apply(dl[0], dl[1], dl[2], dl[3], 1e-5)
+    assert torch.equal(again, got)
+
+
+def test_adapter_layer_norm_uses_the_fused_tail(dev):
+    """The module path with normalization='layer_norm' (ablation 4) against the oracle, 2-D and
+    [1, N, d] inputs, with and without the learnable scalar."""
+    batch, cfg = ga.synth.make_workload("esol")
+    for scalar in (True, False):
+        flags = oracle.AdapterFlags(normalization="layer_norm", learnable_scalar=scalar, normalize=True)
+        _check_workload(dev, batch, cfg["d"], cfg["r"], flags)
+    cora, ccfg = ga.synth.make_workload("cora")
+    flags = oracle.AdapterFlags(normalization="layer_norm", learnable_scalar=True, normalize=True)
+    _check_workload(dev, cora, ccfg["d"], ccfg["r"], flags)
