@@ -367,6 +367,70 @@ def measure_gin(device, name: str = "hiv4096") -> dict:
             f"{name}_gin_aggregate_bwd_GBs": round(bb / (bwd_ms * 1e-3) / 1e9, 1)}
 
 
+class _FinetuneModel(torch.nn.Module):
+    """The reference's inductive model in the shape its fine-tune loop sees it (`MolecularGNN.forward`,
+    `src/models/inductive/gnn.py:85-130`, sequential pre-adapters; mean pool; `graph_pred_linear`):
+    frozen GIN layers, trainable adapters / BatchNorm / head (`gnn.py:230-241`)."""
+
+    def __init__(self, d: int, r: int, layers: int, tasks: int, normalize: bool):
+        super().__init__()
+        self.gnn_layers = torch.nn.ModuleList([ga.MolecularGINConv(d) for _ in range(layers)])
+        self.batch_norm_layers = torch.nn.ModuleList([torch.nn.BatchNorm1d(d) for _ in range(layers)])
+        self.pre_adapters = torch.nn.ModuleDict({str(i): ga.GConvAdapter(d, r, learnable_scalar=True,
+                                                                         normalize=normalize) for i in range(layers)})
+        self.graph_pred_linear = torch.nn.Linear(d, tasks)
+        for layer in self.gnn_layers:
+            for p in layer.parameters():
+                p.requires_grad_(False)
+
+    def forward(self, x, edge_index, edge_attr, batch, num_graphs, inv_count):
+        h = x
+        last = len(self.gnn_layers) - 1
+        for i, (gin, bn) in enumerate(zip(self.gnn_layers, self.batch_norm_layers)):
+            h = self.pre_adapters[str(i)](h, edge_index, edge_attr)
+            h = bn(gin(h, edge_index, edge_attr))
+            if i != last:
+                h = torch.relu(h)
+        pooled = torch.zeros(num_graphs, h.shape[1], device=h.device).index_add_(0, batch, h) * inv_count
+        return self.graph_pred_linear(pooled)
+
+
+def measure_finetune_step(device, normalize: bool, name: str = "hiv", steps: int = 60) -> dict:
+    """The whole fine-tune step of the reference's loop body (`scripts/finetune_inductive_learning.py:43-67`)
+    on one 512-molecule batch: model forward (5 x adapter -> frozen GIN -> BatchNorm -> ReLU, mean pool,
+    head), NaN-masked BCE in fp64, backward, FusedAdam — the adapters in their surroundings. The frozen
+    layers' MLP GEMMs (rocBLAS fp32, ~0.3 ms per layer) and the host-side dispatch of the ~150 torch ops
+    around them dominate; reported next to the headline, never as `value`."""
+    batch, cfg = ga.synth.make_workload(name)
+    d, r, n, e = cfg["d"], cfg["r"], batch.num_nodes, batch.edge_index.shape[1]
+    g = torch.Generator().manual_seed(0)
+    ea = torch.stack([torch.randint(0, 4, (e,), generator=g), torch.randint(0, 3, (e,), generator=g)], 1).to(device)
+    sizes = batch.graph_ptr[1:] - batch.graph_ptr[:-1]
+    node_graph = torch.repeat_interleave(torch.arange(batch.num_graphs), sizes).to(device)
+    inv_count = (1.0 / sizes.clamp(min=1).float()).unsqueeze(1).to(device)
+    y = torch.randint(0, 2, (batch.num_graphs, 1), generator=g).double()
+    y[torch.rand(y.shape, generator=g) < 0.1] = float("nan")
+    y = y.to(device)
+    valid = ~torch.isnan(y)
+    target, count = y[valid], valid.sum()
+    model = _FinetuneModel(d, r, cfg["adapters"], 1, normalize).to(device)
+    opt = ga.FusedAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+    x, ei = batch.x.to(device), batch.edge_index.to(device)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(x, ei, ea, node_graph, batch.num_graphs, inv_count)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(out[valid].double(), target,
+                                                                    reduction="none").sum() / count
+        loss.backward()
+        opt.step()
+
+    ms = event_time_ms(step, steps, warmup=20)
+    ga.PLAN_CACHE.clear()
+    return {f"{name}_finetune_step_ms": round(ms, 4),
+            f"{name}_finetune_step_graphs_per_s": round(batch.num_graphs / (ms * 1e-3), 1)}
+
+
 def measure_banded(device, r: int, flags: int, lib) -> dict:
     """Control (`--banded`): the SAME SpMM kernel on a graph of the same average degree whose
     neighbours are local (banded, 1 M nodes): how close it gets to HBM when gathers hit L2.
@@ -598,6 +662,8 @@ def main() -> None:
             if "cpu" in o:
                 extra[f"{other}_cpu_graphs_per_s"] = o["cpu"]["value"]
                 extra[f"{other}_speedup_vs_cpu"] = round(o["value"] / o["cpu"]["value"], 1)
+            pin_host_threads()
+            extra.update(measure_finetune_step(device, normalize))   # last: torch layers, allocator churn
         line["extra"] = extra
     if rank == 0:
         print(json.dumps(line))
