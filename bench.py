@@ -46,6 +46,10 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+# the frozen layers' nn.Linear (fine-tune step in the extras): this torch build's hipBLASLt
+# addmm path blocks the host at every call until the GPU has caught up (the step ran at GPU time +
+# host time, 3.3 ms); with rocBLAS the host runs ahead again (2.4 ms). Read at the first addmm.
+os.environ.setdefault("DISABLE_ADDMM_HIP_LT", "1")
 import gconv_adapter_amd as ga  # noqa: E402
 
 RESIDENT = 0
@@ -375,7 +379,10 @@ class _FinetuneModel(torch.nn.Module):
     def __init__(self, d: int, r: int, layers: int, tasks: int, normalize: bool):
         super().__init__()
         self.gnn_layers = torch.nn.ModuleList([ga.MolecularGINConv(d) for _ in range(layers)])
-        self.batch_norm_layers = torch.nn.ModuleList([torch.nn.BatchNorm1d(d) for _ in range(layers)])
+        bn = torch.nn.BatchNorm1d if os.environ.get("GCONV_TORCH_BATCH_NORM") else ga.BatchNorm1d   # A/B knob
+        self.batch_norm_layers = torch.nn.ModuleList([bn(d) for _ in range(layers)])
+        for i, m in enumerate(self.batch_norm_layers):   # the ReLU after the norm (gnn.py:127-128) folded in
+            m.fused_relu = isinstance(m, ga.BatchNorm1d) and i != layers - 1
         self.pre_adapters = torch.nn.ModuleDict({str(i): ga.GConvAdapter(d, r, learnable_scalar=True,
                                                                          normalize=normalize) for i in range(layers)})
         self.graph_pred_linear = torch.nn.Linear(d, tasks)
@@ -389,7 +396,7 @@ class _FinetuneModel(torch.nn.Module):
         for i, (gin, bn) in enumerate(zip(self.gnn_layers, self.batch_norm_layers)):
             h = self.pre_adapters[str(i)](h, edge_index, edge_attr)
             h = bn(gin(h, edge_index, edge_attr))
-            if i != last:
+            if i != last and not getattr(bn, "fused_relu", False):
                 h = torch.relu(h)
         pooled = torch.zeros(num_graphs, h.shape[1], device=h.device).index_add_(0, batch, h) * inv_count
         return self.graph_pred_linear(pooled)
@@ -412,6 +419,10 @@ def measure_finetune_step(device, normalize: bool, name: str = "hiv", steps: int
     y[torch.rand(y.shape, generator=g) < 0.1] = float("nan")
     y = y.to(device)
     valid = ~torch.isnan(y)
+    # the reference indexes with the boolean mask (`output[valid_mask]`, :56-58), which makes the host
+    # wait for the forward pass every step; the mask comes with the batch, so its indices are
+    # taken once, on the side, and the step stays asynchronous
+    valid_idx = valid.view(-1).nonzero().squeeze(1)
     target, count = y[valid], valid.sum()
     model = _FinetuneModel(d, r, cfg["adapters"], 1, normalize).to(device)
     opt = ga.FusedAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3)
@@ -420,7 +431,7 @@ def measure_finetune_step(device, normalize: bool, name: str = "hiv", steps: int
     def step():
         opt.zero_grad(set_to_none=True)
         out = model(x, ei, ea, node_graph, batch.num_graphs, inv_count)
-        loss = torch.nn.functional.binary_cross_entropy_with_logits(out[valid].double(), target,
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(out.view(-1)[valid_idx].double(), target,
                                                                     reduction="none").sum() / count
         loss.backward()
         opt.step()

@@ -128,6 +128,11 @@ SIGNATURES = {
     "gconv_layer_norm_scale_fwd_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, C.c_float, _vp]),
     "gconv_layer_norm_scale_bwd_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
                                               _vp, _sz, _vp]),
+    "gconv_batch_norm_workspace_bytes": (_sz, [_i32, _i32]),
+    "gconv_batch_norm_fwd_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _i32, _vp, _vp, _vp,
+                                        _i32, _i32, _vp, _sz, _vp]),
+    "gconv_batch_norm_apply_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp]),
+    "gconv_batch_norm_bwd_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _sz, _vp]),
     "gconv_adam_step_f32": (_i32, [_vp, _vp, _vp, _vp, C.c_int64, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_float, C.c_int64, _vp]),
 }

@@ -24,6 +24,7 @@ import torch.nn as nn
 from . import _lib, _torch_ext
 from .functional import GConvAdapterFunction, LayerNormScaleFunction, _stream
 from .graph import get_plan
+from .norm import BatchNorm1d
 
 #: default of ``GConvAdapter.direct_param_grads`` (env GCONV_AUTOGRAD_PARAM_GRADS=1 turns it off)
 DIRECT_PARAM_GRADS = not os.environ.get("GCONV_AUTOGRAD_PARAM_GRADS")
@@ -97,7 +98,7 @@ class GConvAdapter(nn.Module):
         self.non_linearity = non_linearity
 
         if normalization == 'batch_norm':
-            self.normalization = nn.BatchNorm1d(self.hidden_size)
+            self.normalization = BatchNorm1d(self.hidden_size)   # nn.BatchNorm1d subclass, HIP kernels (norm.py)
         elif normalization == 'layer_norm':
             self.normalization = nn.LayerNorm(self.hidden_size)
         elif normalization == 'none':

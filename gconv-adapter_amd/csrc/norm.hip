@@ -278,3 +278,323 @@ extern "C" gconv_status_t gconv_layer_norm_scale_bwd_f32(const float* grad_out, 
   }
   return GCONV_OK;
 }
+
+// =============================================================================================
+// BatchNorm1d over [N, d] node features with batch statistics (the backbone's
+// `batch_norm_layers[layer](h)` after every GIN layer, /root/reference/src/models/inductive/
+// gnn.py:108-110, trainable under the freeze rule gnn.py:236-239; also the adapter's own
+// `batch_norm` tail, gconv_adapter.py:98-100) — optionally with the ReLU that follows it
+// (gnn.py:127-128) folded in. torch's channels-last kernels take 72 + 10 us forward and
+// 88 + 15 us backward for a [13104, 300] batch (28 % of the whole fine-tune step); the data is
+// 15.7 MB. Here: one pass for the column sums (persistent waves, a lane owns 4 columns per pass and
+// accumulates over the rows its wave walks; sums are taken around row 0 so that a large mean does
+// not cancel), a small fixed-order reduction, one pass to apply; the same three steps backward.
+// =============================================================================================
+namespace gconv {
+
+enum { BN_SUMS_STATS = 0, BN_SUMS_GRAD = 1 };
+
+// part[block][0:d] = sum_rows A, part[block][d:2d] = sum_rows B with
+//   STATS: A = x - x[0], B = (x - x[0])^2        GRAD: A = g', B = g' * xhat   (g' = g where y > 0 if relu)
+template <int NP, int MODE>
+__global__ __launch_bounds__(256) void bn_colsums_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ g,
+                                                         const float* __restrict__ y,
+                                                         const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd,
+                                                         float* __restrict__ part, int n, int d) {
+  __shared__ f32x4 red[3][64 * NP];
+  const int lane = threadIdx.x & 63, wave = wave_id();
+  const int nq = d >> 2;
+  f32x4 c0[NP], c1[NP], a[NP], b[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int q = lane + 64 * p;
+    const bool ok = q < nq;
+    if (MODE == BN_SUMS_STATS) {
+      c0[p] = ok ? ldg4(x + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};   // shift: row 0
+      c1[p] = f32x4{1.f, 1.f, 1.f, 1.f};
+    } else {
+      c0[p] = ok ? ldg4(mean + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+      c1[p] = ok ? ldg4(rstd + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    a[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    b[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int row = blockIdx.x * 4 + wave; row < n; row += gridDim.x * 4) {   // wave-uniform
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int q = lane + 64 * p;
+      if (q < nq) {
+        const size_t off = static_cast<size_t>(row) * d + 4 * q;
+        const f32x4 xc = (ldg4(x + off) - c0[p]) * c1[p];
+        if (MODE == BN_SUMS_STATS) {
+          a[p] += xc;
+          b[p] += xc * xc;
+        } else {
+          f32x4 gv = ldg4(g + off);
+          if (y) {
+            const f32x4 yv = ldg4(y + off);
+            for (int k = 0; k < 4; ++k) gv[k] = yv[k] > 0.f ? gv[k] : 0.f;
+          }
+          a[p] += gv;
+          b[p] += gv * xc;
+        }
+      }
+    }
+  }
+  float* prow = part + static_cast<size_t>(blockIdx.x) * (2 * d);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {   // waves added in wave order, A then B
+    if (wave > 0) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) red[wave - 1][lane + 64 * p] = half ? b[p] : a[p];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int q = lane + 64 * p;
+        f32x4 t = half ? b[p] : a[p];
+        for (int w = 0; w < 3; ++w) t += red[w][lane + 64 * p];
+        if (q < nq) stg4(prow + half * d + 4 * q, t);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// reduces the partial rows (16 columns x 16 row groups per block, fixed order) and finishes:
+//   STATS: mean, rstd (biased variance), running statistics (unbiased variance, torch's rule)
+//   GRAD : dgamma = sum g' xhat, dbeta = sum g'
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nparts,
+                                                          const float* __restrict__ x_row0, int n, int d,
+                                                          float eps, float momentum,
+                                                          float* __restrict__ out0, float* __restrict__ out1,
+                                                          float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var) {
+  __shared__ float red[2][16][17];
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+  if (c < d) {
+    int r = rg;
+    for (; r + 16 < nparts; r += 32) {
+      a0 += part[static_cast<size_t>(r) * 2 * d + c];
+      b0 += part[static_cast<size_t>(r) * 2 * d + d + c];
+      a1 += part[static_cast<size_t>(r + 16) * 2 * d + c];
+      b1 += part[static_cast<size_t>(r + 16) * 2 * d + d + c];
+    }
+    for (; r < nparts; r += 16) {
+      a0 += part[static_cast<size_t>(r) * 2 * d + c];
+      b0 += part[static_cast<size_t>(r) * 2 * d + d + c];
+    }
+  }
+  red[0][rg][cl] = a0 + a1;
+  red[1][rg][cl] = b0 + b1;
+  __syncthreads();
+  if (rg != 0 || c >= d) return;
+  float sa = 0.f, sb = 0.f;
+  for (int k = 0; k < 16; ++k) {
+    sa += red[0][k][cl];
+    sb += red[1][k][cl];
+  }
+  if (MODE == BN_SUMS_STATS) {
+    const float inv_n = 1.f / static_cast<float>(n);
+    const float m1 = sa * inv_n;                        // mean - x[0]
+    const float var = fmaxf(sb * inv_n - m1 * m1, 0.f);  // biased
+    const float mu = x_row0[c] + m1;
+    out0[c] = mu;
+    out1[c] = rsqrtf(var + eps);
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    if (running_var) {
+      const float unbiased = n > 1 ? var * static_cast<float>(n) / static_cast<float>(n - 1) : var;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+  } else {
+    if (out0) out0[c] = sb;   // dgamma
+    if (out1) out1[c] = sa;   // dbeta
+  }
+}
+
+// y = [relu](gamma * (x - mean) * rstd + beta)
+template <int NP>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta,
+                                                       float* __restrict__ y, int n, int d, int relu) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave_id();
+  if (row >= n) return;
+  const int nq = d >> 2;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int q = lane + 64 * p;
+    if (q < nq) {
+      const size_t off = static_cast<size_t>(row) * d + 4 * q;
+      f32x4 v = (ldg4(x + off) - ldg4(mean + 4 * q)) * ldg4(rstd + 4 * q);
+      if (gamma) v = v * ldg4(gamma + 4 * q);
+      if (beta) v = v + ldg4(beta + 4 * q);
+      if (relu)
+        for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+      stg4(y + off, v);
+    }
+  }
+}
+
+// dx = gamma * rstd * (g' - dbeta / n - xhat * dgamma / n)
+template <int NP>
+__global__ __launch_bounds__(256) void bn_dx_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                    const float* __restrict__ y,
+                                                    const float* __restrict__ mean,
+                                                    const float* __restrict__ rstd,
+                                                    const float* __restrict__ gamma,
+                                                    const float* __restrict__ dgamma,
+                                                    const float* __restrict__ dbeta,
+                                                    float* __restrict__ dx, int n, int d) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave_id();
+  if (row >= n) return;
+  const int nq = d >> 2;
+  const float inv_n = 1.f / static_cast<float>(n);
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int q = lane + 64 * p;
+    if (q < nq) {
+      const size_t off = static_cast<size_t>(row) * d + 4 * q;
+      const f32x4 rs = ldg4(rstd + 4 * q);
+      const f32x4 xh = (ldg4(x + off) - ldg4(mean + 4 * q)) * rs;
+      f32x4 gv = ldg4(g + off);
+      if (y) {
+        const f32x4 yv = ldg4(y + off);
+        for (int k = 0; k < 4; ++k) gv[k] = yv[k] > 0.f ? gv[k] : 0.f;
+      }
+      f32x4 v = (gv - ldg4(dbeta + 4 * q) * inv_n - xh * (ldg4(dgamma + 4 * q) * inv_n)) * rs;
+      if (gamma) v = v * ldg4(gamma + 4 * q);
+      stg4(dx + off, v);
+    }
+  }
+}
+
+static int bn_grid(int n) { return min(ceil_div(n > 0 ? n : 1, 4), kNumCU * 2); }
+
+// workspace: [partials: grid x 2d] [dgamma d] [dbeta d]
+struct BnWs {
+  float *part, *dgamma, *dbeta;
+  size_t bytes;
+};
+static BnWs bn_carve(void* ws, int n, int d) {
+  BnWs w;
+  char* base = static_cast<char*>(ws);
+  size_t off = 0;
+  auto take = [&](size_t count) {
+    float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
+    off += align_up(count * sizeof(float) + 16, 256);
+    return p;
+  };
+  w.part = take(static_cast<size_t>(bn_grid(n)) * 2 * d);
+  w.dgamma = take(d);
+  w.dbeta = take(d);
+  w.bytes = off;
+  return w;
+}
+
+#define GCONV_BN_DISPATCH(KERNEL_CALL)                \
+  switch (ceil_div(hidden, 256)) {                    \
+    case 1: { constexpr int NP = 1; KERNEL_CALL; } break; \
+    case 2: { constexpr int NP = 2; KERNEL_CALL; } break; \
+    case 3: { constexpr int NP = 3; KERNEL_CALL; } break; \
+    default: { constexpr int NP = 4; KERNEL_CALL; } break; \
+  }
+
+}  // namespace gconv
+
+extern "C" size_t gconv_batch_norm_workspace_bytes(int32_t num_nodes, int32_t hidden) {
+  if (ln_check(num_nodes, hidden) != GCONV_OK) return 0;
+  return bn_carve(nullptr, num_nodes, hidden).bytes;
+}
+
+extern "C" gconv_status_t gconv_batch_norm_fwd_f32(const float* x, const float* gamma, const float* beta,
+                                                   float* running_mean, float* running_var,
+                                                   float momentum, float eps, int32_t relu, float* y,
+                                                   float* save_mean, float* save_rstd,
+                                                   int32_t num_nodes, int32_t hidden, void* workspace,
+                                                   size_t workspace_bytes, gconv_stream_t stream_) {
+  const gconv_status_t st = ln_check(num_nodes, hidden);
+  if (st != GCONV_OK) return st;
+  if (num_nodes < 2) return GCONV_E_INVALID_ARG;   // batch statistics need more than one row
+  if (!x || !y || !save_mean || !save_rstd || !workspace) return GCONV_E_INVALID_ARG;
+  const BnWs ws = bn_carve(workspace, num_nodes, hidden);
+  if (workspace_bytes < ws.bytes) return GCONV_E_WORKSPACE;
+  if (!aligned16(x) || !aligned16(y) || !aligned16(save_mean) || !aligned16(save_rstd) ||
+      (gamma && !aligned16(gamma)) || (beta && !aligned16(beta)) || !aligned16(workspace))
+    return GCONV_E_ALIGNMENT;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int grid = bn_grid(num_nodes);
+  GCONV_BN_DISPATCH((bn_colsums_kernel<NP, BN_SUMS_STATS><<<grid, 256, 0, stream>>>(
+      x, nullptr, nullptr, nullptr, nullptr, ws.part, num_nodes, hidden)))
+  GCONV_LAUNCH_CHECK();
+  bn_finalize_kernel<BN_SUMS_STATS><<<ceil_div(hidden, 16), 256, 0, stream>>>(
+      ws.part, grid, x, num_nodes, hidden, eps, momentum, save_mean, save_rstd, running_mean, running_var);
+  GCONV_LAUNCH_CHECK();
+  GCONV_BN_DISPATCH((bn_apply_kernel<NP><<<ceil_div(num_nodes, 4), 256, 0, stream>>>(
+      x, save_mean, save_rstd, gamma, beta, y, num_nodes, hidden, relu)))
+  GCONV_LAUNCH_CHECK();
+  return GCONV_OK;
+}
+
+extern "C" gconv_status_t gconv_batch_norm_apply_f32(const float* x, const float* mean, const float* rstd,
+                                                     const float* gamma, const float* beta, int32_t relu,
+                                                     float* y, int32_t num_nodes, int32_t hidden,
+                                                     gconv_stream_t stream_) {
+  const gconv_status_t st = ln_check(num_nodes, hidden);
+  if (st != GCONV_OK) return st;
+  if (num_nodes == 0) return GCONV_OK;
+  if (!x || !y || !mean || !rstd) return GCONV_E_INVALID_ARG;
+  if (!aligned16(x) || !aligned16(y) || !aligned16(mean) || !aligned16(rstd) ||
+      (gamma && !aligned16(gamma)) || (beta && !aligned16(beta)))
+    return GCONV_E_ALIGNMENT;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GCONV_BN_DISPATCH((bn_apply_kernel<NP><<<ceil_div(num_nodes, 4), 256, 0, stream>>>(
+      x, mean, rstd, gamma, beta, y, num_nodes, hidden, relu)))
+  GCONV_LAUNCH_CHECK();
+  return GCONV_OK;
+}
+
+extern "C" gconv_status_t gconv_batch_norm_bwd_f32(const float* grad_y, const float* x, const float* y,
+                                                   const float* save_mean, const float* save_rstd,
+                                                   const float* gamma, float* grad_x, float* grad_gamma,
+                                                   float* grad_beta, int32_t num_nodes, int32_t hidden,
+                                                   void* workspace, size_t workspace_bytes,
+                                                   gconv_stream_t stream_) {
+  const gconv_status_t st = ln_check(num_nodes, hidden);
+  if (st != GCONV_OK) return st;
+  if (num_nodes < 2) return GCONV_E_INVALID_ARG;
+  if (!grad_y || !x || !save_mean || !save_rstd || !workspace) return GCONV_E_INVALID_ARG;
+  const BnWs ws = bn_carve(workspace, num_nodes, hidden);
+  if (workspace_bytes < ws.bytes) return GCONV_E_WORKSPACE;
+  if (!aligned16(grad_y) || !aligned16(x) || (y && !aligned16(y)) || !aligned16(save_mean) ||
+      !aligned16(save_rstd) || (gamma && !aligned16(gamma)) || (grad_x && !aligned16(grad_x)) ||
+      (grad_gamma && !aligned16(grad_gamma)) || (grad_beta && !aligned16(grad_beta)) || !aligned16(workspace))
+    return GCONV_E_ALIGNMENT;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int grid = bn_grid(num_nodes);
+  GCONV_BN_DISPATCH((bn_colsums_kernel<NP, BN_SUMS_GRAD><<<grid, 256, 0, stream>>>(
+      x, grad_y, y, save_mean, save_rstd, ws.part, num_nodes, hidden)))
+  GCONV_LAUNCH_CHECK();
+  // the column sums are needed by dx whether or not the caller wants them back
+  float* dg = grad_gamma ? grad_gamma : ws.dgamma;
+  float* db = grad_beta ? grad_beta : ws.dbeta;
+  bn_finalize_kernel<BN_SUMS_GRAD><<<ceil_div(hidden, 16), 256, 0, stream>>>(
+      ws.part, grid, nullptr, num_nodes, hidden, 0.f, 0.f, dg, db, nullptr, nullptr);
+  GCONV_LAUNCH_CHECK();
+  if (grad_x) {
+    GCONV_BN_DISPATCH((bn_dx_kernel<NP><<<ceil_div(num_nodes, 4), 256, 0, stream>>>(
+        grad_y, x, y, save_mean, save_rstd, gamma, dg, db, grad_x, num_nodes, hidden)))
+    GCONV_LAUNCH_CHECK();
+  }
+  return GCONV_OK;
+}

@@ -1,0 +1,122 @@
+"""BatchNorm1d over node features on the device (``csrc/norm.hip``).
+
+``BatchNorm1d`` is an ``nn.BatchNorm1d`` — same constructor, parameters, buffers and ``state_dict``
+keys, so the reference's ``batch_norm_layers`` (``/root/reference/src/models/inductive/gnn.py:47-48,
+108-110``) and a pretrained checkpoint load unchanged — whose forward / backward on ``[N, d]`` fp32
+HIP tensors run the three-launch kernels of ``gconv_batch_norm_*`` instead of torch's channels-last
+BatchNorm kernels (72 + 10 us forward, 88 + 15 us backward on a 512-molecule batch — 28 % of the
+whole fine-tune step). ``fused_relu=True`` folds in the ReLU that follows the norm in every layer but
+the last (``gnn.py:127-128``): one pass less each way.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .functional import _ptr, _require_hip_f32, _stream
+
+
+class BatchNormFunction(torch.autograd.Function):
+    """y = [relu](gamma * (x - mean_batch) * rstd_batch + beta); running statistics updated in place."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum: float, eps: float, relu: bool):
+        lib = _lib.load()
+        _require_hip_f32(x, "x")
+        if x.dim() != 2:
+            raise RuntimeError(f"BatchNormFunction takes [N, d] node features, got {tuple(x.shape)}")
+        x = x.contiguous()
+        n, d = x.shape
+        if n < 2:
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
+        dev = x.device
+        if dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        y = torch.empty_like(x)
+        stats = torch.empty(2, d, dtype=torch.float32, device=dev)
+        nbytes = int(lib.gconv_batch_norm_workspace_bytes(n, d))
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+        st = lib.gconv_batch_norm_fwd_f32(x.data_ptr(), _ptr(gamma), _ptr(beta), _ptr(running_mean),
+                                          _ptr(running_var), float(momentum), float(eps), int(relu),
+                                          y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), n, d,
+                                          ws.data_ptr(), ws.numel(), _stream(dev.index))
+        if st != 0:
+            _lib.check(st, "batch_norm_fwd")
+        ctx.relu = relu
+        ctx.save_for_backward(x, y if relu else None, stats, gamma)
+        ctx.has_beta = beta is not None
+        return y   # (the running statistics are buffers: updated in place, outside autograd)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, y, stats, gamma = ctx.saved_tensors
+        g = g.contiguous()
+        n, d = x.shape
+        dev = x.device
+        if dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        ggam = torch.empty(d, dtype=torch.float32, device=dev) if gamma is not None else None
+        gbet = torch.empty(d, dtype=torch.float32, device=dev) if ctx.has_beta else None
+        nbytes = int(lib.gconv_batch_norm_workspace_bytes(n, d))
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+        st = lib.gconv_batch_norm_bwd_f32(g.data_ptr(), x.data_ptr(), _ptr(y), stats[0].data_ptr(),
+                                          stats[1].data_ptr(), _ptr(gamma), _ptr(gx), _ptr(ggam), _ptr(gbet),
+                                          n, d, ws.data_ptr(), ws.numel(), _stream(dev.index))
+        if st != 0:
+            _lib.check(st, "batch_norm_bwd")
+        return gx, ggam, gbet, None, None, None, None, None
+
+
+def batch_norm_eval(x, running_mean, running_var, gamma, beta, eps: float, relu: bool) -> torch.Tensor:
+    """Evaluation-mode forward (running statistics; autograd through the torch formula when needed)."""
+    if torch.is_grad_enabled() and (x.requires_grad or (gamma is not None and gamma.requires_grad)):
+        y = torch.nn.functional.batch_norm(x, running_mean, running_var, gamma, beta, False, 0.0, eps)
+        return torch.relu(y) if relu else y
+    lib = _lib.load()
+    _require_hip_f32(x, "x")
+    x = x.contiguous()
+    n, d = x.shape
+    rstd = torch.rsqrt(running_var + eps)
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        st = lib.gconv_batch_norm_apply_f32(x.data_ptr(), running_mean.data_ptr(), rstd.data_ptr(), _ptr(gamma),
+                                            _ptr(beta), int(relu), y.data_ptr(), n, d, _stream())
+    _lib.check(st, "batch_norm_apply")
+    return y
+
+
+class BatchNorm1d(nn.BatchNorm1d):
+    """``nn.BatchNorm1d`` with the HIP kernels for ``[N, d]`` fp32 inputs on a HIP device (module
+    docstring). Anything else (3-D input, other dtypes, ``d`` not a multiple of 4 or > 1024) takes
+    ``nn.BatchNorm1d``'s own path, so the class can replace it everywhere."""
+
+    def __init__(self, num_features: int, eps: float = 1e-5, momentum: Optional[float] = 0.1,
+                 affine: bool = True, track_running_stats: bool = True, device=None, dtype=None,
+                 fused_relu: bool = False):
+        super().__init__(num_features, eps, momentum, affine, track_running_stats, device=device, dtype=dtype)
+        self.fused_relu = fused_relu
+
+    def _native(self, x: torch.Tensor) -> bool:
+        return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] % 4 == 0
+                and x.shape[1] <= 1024 and x.shape[0] >= 1)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not self._native(x):
+            y = super().forward(x)
+            return torch.relu(y) if self.fused_relu else y
+        use_batch_stats = self.training or self.running_mean is None
+        if not use_batch_stats:
+            return batch_norm_eval(x, self.running_mean, self.running_var, self.weight, self.bias, self.eps,
+                                   self.fused_relu)
+        factor = 0.0
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+            factor = (1.0 / float(self.num_batches_tracked)) if self.momentum is None else self.momentum
+        rm = self.running_mean if self.training and self.track_running_stats else None
+        rv = self.running_var if self.training and self.track_running_stats else None
+        return BatchNormFunction.apply(x, self.weight, self.bias, rm, rv, factor, self.eps, self.fused_relu)

@@ -393,6 +393,37 @@ gconv_status_t gconv_layer_norm_scale_bwd_f32(const float* grad_out, const float
                                               void* workspace, size_t workspace_bytes,
                                               gconv_stream_t stream);
 
+/* ---- next to the path: BatchNorm1d over node features, batch statistics --------
+ * replaces: `h = self.batch_norm_layers[layer](h)` after every GIN layer
+ * (`src/models/inductive/gnn.py:108-110`; BatchNorm parameters train under the freeze rule,
+ * `gnn.py:236-239`) — optionally with the ReLU that follows it (`gnn.py:127-128`) folded in — and
+ * the adapter's own `batch_norm` tail (`gconv_adapter.py:98-100`); and their autograd backward.
+ *   forward (training): per-column mean / biased variance over the num_nodes rows (>= 2), y =
+ *     [relu](gamma (x - mean) rstd + beta); save_mean / save_rstd [hidden] kept for backward;
+ *     running_mean / running_var (nullable) updated in place with torch's rule (momentum, unbiased
+ *     variance). `gconv_batch_norm_apply_f32` is the evaluation-mode forward with given mean / rstd.
+ *   backward: grad_x (nullable), grad_gamma, grad_beta (nullable) overwritten; `y` = the forward's
+ *     output, needed only when the forward folded the ReLU in (else NULL).
+ * Three launches each way (column sums with persistent waves, fixed-order reduction, apply), no
+ * atomics; hidden a multiple of 4, <= 1024; one workspace size for both directions.             */
+size_t gconv_batch_norm_workspace_bytes(int32_t num_nodes, int32_t hidden);
+gconv_status_t gconv_batch_norm_fwd_f32(const float* x, const float* gamma, const float* beta,
+                                        float* running_mean, float* running_var, float momentum,
+                                        float eps, int32_t relu, float* y, float* save_mean,
+                                        float* save_rstd, int32_t num_nodes, int32_t hidden,
+                                        void* workspace, size_t workspace_bytes,
+                                        gconv_stream_t stream);
+gconv_status_t gconv_batch_norm_apply_f32(const float* x, const float* mean, const float* rstd,
+                                          const float* gamma, const float* beta, int32_t relu,
+                                          float* y, int32_t num_nodes, int32_t hidden,
+                                          gconv_stream_t stream);
+gconv_status_t gconv_batch_norm_bwd_f32(const float* grad_y, const float* x, const float* y,
+                                        const float* save_mean, const float* save_rstd,
+                                        const float* gamma, float* grad_x, float* grad_gamma,
+                                        float* grad_beta, int32_t num_nodes, int32_t hidden,
+                                        void* workspace, size_t workspace_bytes,
+                                        gconv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,7 +25,7 @@ class MiniMolecularGNN(nn.Module):
     def __init__(self):
         super().__init__()
         self.gnn_layers = nn.ModuleList([ga.MolecularGINConv(D) for _ in range(LAYERS)])
-        self.batch_norm_layers = nn.ModuleList([nn.BatchNorm1d(D) for _ in range(LAYERS)])
+        self.batch_norm_layers = nn.ModuleList([ga.BatchNorm1d(D, fused_relu=i != LAYERS - 1) for i in range(LAYERS)])
         self.pre_adapters = nn.ModuleDict()
         self.graph_pred_linear = nn.Linear(D, TASKS)
 
@@ -44,9 +44,7 @@ class MiniMolecularGNN(nn.Module):
         for layer in range(LAYERS):
             h = self.pre_adapters[str(layer)](h, edge_index, edge_attr)
             h = self.gnn_layers[layer](h, edge_index, edge_attr)
-            h = self.batch_norm_layers[layer](h)
-            if layer != LAYERS - 1:
-                h = F.relu(h)
+            h = self.batch_norm_layers[layer](h)      # ReLU of the inner layers folded in (gnn.py:127-128)
         pooled = torch.zeros(num_graphs, D, device=h.device, dtype=h.dtype).index_add_(0, batch, h)
         pooled = pooled / torch.bincount(batch, minlength=num_graphs).clamp(min=1).unsqueeze(1)
         return self.graph_pred_linear(pooled)

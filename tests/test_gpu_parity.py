@@ -855,3 +855,62 @@ def test_adapter_layer_norm_uses_the_fused_tail(dev):
     cora, ccfg = ga.synth.make_workload("cora")
     flags = oracle.AdapterFlags(normalization="layer_norm", learnable_scalar=True, normalize=True)
     _check_workload(dev, cora, ccfg["d"], ccfg["r"], flags)
+
+
+# ---------------------------------------------------------------------------
+# BatchNorm1d over node features (the backbone's norm after every GIN layer)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n,d,relu,shift", [(2, 8, False, 0.0), (431, 300, False, 0.0), (13104, 300, True, 0.0),
+                                            (1000, 1024, False, 0.0), (5000, 64, True, 50.0)])
+def test_batch_norm_matches_torch_fp64(dev, n, d, relu, shift):
+    g = torch.Generator().manual_seed(n + d)
+    x = 2.0 * torch.randn(n, d, generator=g) + shift + torch.randn(d, generator=g)
+    go = torch.randn(n, d, generator=g)
+    ref = torch.nn.BatchNorm1d(d).double()
+    mine = ga.BatchNorm1d(d, fused_relu=relu).to(dev)
+    with torch.no_grad():
+        ref.weight.copy_(1.0 + 0.3 * torch.randn(d, generator=g))
+        ref.bias.copy_(0.3 * torch.randn(d, generator=g))
+    mine.load_state_dict({k: (v.float() if v.dtype.is_floating_point else v) for k, v in ref.state_dict().items()})
+    for step in range(3):   # running statistics accumulate over steps
+        xr = (x + 0.1 * step).double().requires_grad_(True)
+        yr = ref(xr)
+        if relu:
+            yr = torch.relu(yr)
+        ref.zero_grad()
+        yr.backward(go.double())
+        xm = (x + 0.1 * step).to(dev).requires_grad_(True)
+        ym = mine(xm)
+        mine.zero_grad()
+        ym.backward(go.to(dev))
+    # a large common offset (shift) costs relative accuracy in x - mean itself: (|mean| / std) * 2^-24
+    tol = 1e-5 * max(1.0, shift)
+    assert_close(ym.detach().cpu().double(), yr.detach(), "y", 1e-5, tol)
+    assert_close(xm.grad.cpu().double(), xr.grad, "grad x", 1e-5, tol)
+    assert_close(mine.weight.grad.cpu().double(), ref.weight.grad, "grad gamma", 1e-5, grad_atol(ref.weight.grad) * max(1.0, shift))
+    assert_close(mine.bias.grad.cpu().double(), ref.bias.grad, "grad beta", 1e-5, grad_atol(ref.bias.grad))
+    assert_close(mine.running_mean.cpu().double(), ref.running_mean, "running_mean", 1e-5, 1e-5 * max(1.0, shift))
+    assert_close(mine.running_var.cpu().double(), ref.running_var, "running_var", 1e-5, tol)
+    assert int(mine.num_batches_tracked) == 3
+    assert set(mine.state_dict()) == set(ref.state_dict())
+    ref.eval(); mine.eval()
+    with torch.no_grad():
+        ye = ref(x.double())
+        ye = torch.relu(ye) if relu else ye
+        assert_close(mine(x.to(dev)).cpu().double(), ye, "eval y", 1e-5, tol)
+    xe = x.to(dev).requires_grad_(True)          # eval mode with autograd: torch's formula
+    mine(xe).sum().backward()
+    assert torch.isfinite(xe.grad).all()
+    again = ga.BatchNorm1d(d, fused_relu=relu).to(dev).train()
+    again.load_state_dict(mine.state_dict())
+    a, b = again(x.to(dev)), ga.norm.BatchNormFunction.apply(x.to(dev), again.weight, again.bias, None, None, 0.0,
+                                                             again.eps, relu)
+    assert torch.equal(a, b)                      # bitwise repeatable
+
+
+def test_batch_norm_other_inputs_take_torchs_path(dev):
+    m = ga.BatchNorm1d(6).to(dev)                 # d % 4 != 0 -> nn.BatchNorm1d's own kernels
+    x = torch.randn(10, 6, device=dev)
+    assert torch.allclose(m(x), torch.nn.functional.batch_norm(x, None, None, m.weight, m.bias, True), atol=1e-6)
+    with pytest.raises(ValueError, match="more than 1 value"):
+        ga.BatchNorm1d(8).to(dev)(torch.randn(1, 8, device=dev))
