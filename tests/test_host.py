@@ -236,3 +236,24 @@ def test_ctypes_structs_match_the_header():
     for i, ctype in enumerate((ga._lib.CsrStruct, ga._lib.GraphStruct, ga._lib.AdapterParams,
                                ga._lib.PendingFinalize)):
         assert lib.gconv_abi_struct_bytes(i) == ctypes.sizeof(ctype)
+
+
+def test_batch_norm_module_is_a_drop_in_on_any_input():
+    """`gconv_adapter_amd.BatchNorm1d` is an nn.BatchNorm1d: same state dict, same results wherever the
+    HIP kernels do not apply (CPU tensors here), and the freeze rule's isinstance test sees it."""
+    import torch
+    import gconv_adapter_amd as ga
+    torch.manual_seed(0)
+    ref, mine = torch.nn.BatchNorm1d(12), ga.BatchNorm1d(12)
+    relu = ga.BatchNorm1d(12, fused_relu=True)
+    assert isinstance(mine, torch.nn.BatchNorm1d) and list(mine.state_dict()) == list(ref.state_dict())
+    mine.load_state_dict(ref.state_dict()); relu.load_state_dict(ref.state_dict())
+    x = torch.randn(9, 12)
+    want = ref(x)
+    assert torch.equal(mine(x), want) and torch.equal(relu(x), torch.relu(want))
+    assert torch.equal(mine.running_mean, ref.running_mean) and int(mine.num_batches_tracked) == 1
+    adapter = ga.GConvAdapter(8, 2, normalization="batch_norm")
+    assert isinstance(adapter.normalization, torch.nn.BatchNorm1d)
+    assert set(k for k in adapter.state_dict() if k.startswith("normalization")) == {
+        "normalization.weight", "normalization.bias", "normalization.running_mean", "normalization.running_var",
+        "normalization.num_batches_tracked"}
