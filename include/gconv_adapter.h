@@ -102,8 +102,12 @@ typedef struct gconv_csr {
  * contiguous tiles that no edge crosses. A tile is handled end-to-end by ONE workgroup
  * (rank-width intermediates never leave LDS). Tiles start at the last edge-free boundary
  * at or below every multiple of GCONV_TILE_NODES. */
+#ifndef GCONV_TILE_NODES
 #define GCONV_TILE_NODES 32
-#define GCONV_TILE_BACK  480   /* how far a tile start may be pulled back to find a cut */
+#endif
+#ifndef GCONV_TILE_BACK
+#define GCONV_TILE_BACK  (512 - GCONV_TILE_NODES)   /* how far a tile start may be pulled back to find a cut */
+#endif
 
 /* Everything the kernels need to apply S and S^T for one edge list. All pointers
  * point into the caller's arena (see gconv_graph_build). */
