@@ -20,6 +20,12 @@ SPMM_OUT_PRESCALE = 2
 LONG_ROW = 64
 SEG_EDGES = 128
 TILE_NODES = 32
+TILE_WIDE_FROM = 65536
+
+
+def tile_nodes(num_nodes: int) -> int:
+    """Nominal nodes per component tile of a batch (``tile_nodes`` in ``csrc/common.h``)."""
+    return 2 * TILE_NODES if num_nodes >= TILE_WIDE_FROM else TILE_NODES
 
 _i32p = C.POINTER(C.c_int32)
 

@@ -101,14 +101,14 @@ __global__ __launch_bounds__(256) void plan_copy_kernel(
   if (p == nb - 1 && threadIdx.x == 0) rowptr_b[no + nn] = eo + ne;
 }
 
-// tile t starts at the last graph boundary at or below t * GCONV_TILE_NODES (graphs are the
+// tile t starts at the last graph boundary at or below t * tile_nodes(n) (graphs are the
 // components: no edge crosses a graph boundary); spans + size keys for the size sort
 __global__ void plan_tiles_kernel(const int32_t* __restrict__ noff, int nb, int n, int ntiles,
                                   int32_t* __restrict__ tile_ptr) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t > ntiles) return;
   if (t == ntiles) { tile_ptr[t] = n; return; }
-  const int q = t * GCONV_TILE_NODES;
+  const int q = t * tile_nodes(n);
   int lo = 0, hi = nb;                       // largest p with noff[p] <= q  (noff[0] = 0)
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -134,7 +134,7 @@ static StoreLayout store_layout(int32_t n, int64_t nnz, int32_t nb) {
   StoreLayout L{};
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes + 16, 256); return o; };
-  L.ntiles = ceil_div(n > 0 ? n : 1, GCONV_TILE_NODES);
+  L.ntiles = ceil_div(n > 0 ? n : 1, tile_nodes(n));
   L.rowptr = take((static_cast<size_t>(n) + 1) * 4);
   L.col = take(static_cast<size_t>(nnz > 0 ? nnz : 1) * 4);
   L.dis = take((static_cast<size_t>(n) + 1) * 4);
@@ -213,9 +213,9 @@ extern "C" gconv_status_t gconv_graph_from_store(const gconv_graph_t* dataset, c
   g->tile_order = reinterpret_cast<int32_t*>(arena + L.tile_order);
   g->n_tiles = L.ntiles;
   // upper bounds known without reading anything back: a tile starts at most
-  // GCONV_TILE_NODES - 1 nodes before its nominal start and ends inside the graph that covers
+  // tile_nodes(n) - 1 nodes before its nominal start and ends inside the graph that covers
   // its nominal end (they only size the LDS of the fused kernels)
-  const int bound = GCONV_TILE_NODES + max_graph_nodes;
+  const int bound = tile_nodes(num_nodes) + max_graph_nodes;
   g->tile_nodes_max = bound < num_nodes ? bound : num_nodes;
   const int64_t eb = static_cast<int64_t>(g->tile_nodes_max) * (dataset->max_degree > 0 ? dataset->max_degree : 1);
   g->tile_edges_max = static_cast<int32_t>(eb < nnz ? eb : nnz);

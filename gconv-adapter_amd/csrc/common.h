@@ -22,6 +22,16 @@ constexpr int kWave = 64;
 constexpr int kNumCU = 256;
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Nominal nodes per component tile of an n-node batch: GCONV_TILE_NODES (32), and twice that
+// once a persistent workgroup would otherwise walk more than ~8 tiles (measured with libraries
+// built at 32 / 48 / 64 / 96 / 128: the 512-molecule shard does not care up to 64, the
+// 4096-molecule batch runs 8 % faster at 64, everything loses beyond). A tile never exceeds
+// kTileSpan nodes (its start may be pulled back to the previous edge-free boundary).
+constexpr int kTileSpan = 512;
+__host__ __device__ inline int tile_nodes(int n) {
+  return n >= GCONV_TILE_WIDE_FROM ? 2 * GCONV_TILE_NODES : GCONV_TILE_NODES;
+}
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

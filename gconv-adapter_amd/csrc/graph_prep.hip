@@ -20,7 +20,7 @@
 
 namespace gconv {
 
-// a tile holds at most GCONV_TILE_NODES + GCONV_TILE_BACK = 512 nodes: 10-bit size keys
+// a tile holds at most kTileSpan = 512 nodes: 10-bit size keys
 constexpr int kTileSizeMax = 1023, kTileSizeBits = 10;
 
 enum {
@@ -65,7 +65,7 @@ __global__ void make_keys_kernel(const int64_t* __restrict__ ei, int64_t E, int3
                     : ko.make(static_cast<uint32_t>(d), static_cast<uint32_t>(s));
     if (span && s != d) {  // boundaries lo+1 .. hi are crossed by this edge
       const int lo = static_cast<int>(s < d ? s : d), hi = static_cast<int>(s < d ? d : s);
-      if (hi - lo > GCONV_TILE_NODES + GCONV_TILE_BACK) {
+      if (hi - lo > kTileSpan) {
         // wider than any tile: the graph is not tileable; skip the atomics (on power-law
         // graphs thousands of them would pile up on the hub's counter)
         if (info[INFO_NOTILE] == 0) atomicOr(&info[INFO_NOTILE], 1);
@@ -148,8 +148,8 @@ __global__ void sym_check_kernel(const int32_t* __restrict__ rowptr,
   if (q >= rowptr[j + 1] || col[q] != i) atomicOr(asym, 1);
 }
 
-// tile_ptr[t] = last boundary q <= t * B that no edge spans (span_ps[q] == 0), searched at most
-// GCONV_TILE_BACK positions back. One wave per tile: 64 candidate boundaries per step
+// tile_ptr[t] = last boundary q <= t * B (B = tile_nodes(n)) that no edge spans (span_ps[q] == 0),
+// searched at most kTileSpan - B positions back. One wave per tile: 64 candidate boundaries per step
 // (coalesced load + ballot) instead of a serial walk of up to 480 dependent loads per thread.
 __global__ __launch_bounds__(256) void tile_start_kernel(const int32_t* __restrict__ span_ps, int32_t n,
                                                          int ntiles, int32_t* __restrict__ tile_ptr,
@@ -161,11 +161,11 @@ __global__ __launch_bounds__(256) void tile_start_kernel(const int32_t* __restri
     if (lane == 0) tile_ptr[t] = n;
     return;
   }
-  const int q0 = t * GCONV_TILE_NODES;
+  const int q0 = t * tile_nodes(n), back = kTileSpan - tile_nodes(n);
   int found = -1;
-  for (int base = 0; base <= GCONV_TILE_BACK && found < 0; base += 64) {
+  for (int base = 0; base <= back && found < 0; base += 64) {
     const int q = q0 - base - lane;                       // lane 0 = the highest candidate
-    const bool cand = q >= 0 && base + lane <= GCONV_TILE_BACK;
+    const bool cand = q >= 0 && base + lane <= back;
     const bool ok = cand && (q == 0 || span_ps[q] == 0);
     const unsigned long long m = __ballot(ok);
     if (m) found = q0 - base - (__ffsll(static_cast<long long>(m)) - 1);
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void tile_start_kernel(const int32_t* __restri
   if (lane == 0) {
     if (found < 0) {   // no edge-free boundary within reach: the graph is not tileable
       atomicOr(&info[INFO_NOTILE], 1);
-      found = max(q0 - GCONV_TILE_BACK, 0);
+      found = max(q0 - back, 0);
     }
     tile_ptr[t] = found;
   }
@@ -256,7 +256,7 @@ static BuildLayout build_layout(int64_t E, int32_t n) {
   };
   csr(L.f);
   csr(L.b);
-  L.ntiles = ceil_div(n > 0 ? n : 1, GCONV_TILE_NODES);
+  L.ntiles = ceil_div(n > 0 ? n : 1, tile_nodes(n));
   L.dis = take((static_cast<size_t>(n) + 1) * 4);
   L.tile_ptr = take((static_cast<size_t>(L.ntiles) + 1) * 4);
   L.tile_order = take(static_cast<size_t>(L.ntiles) * 8);

@@ -101,12 +101,15 @@ typedef struct gconv_csr {
 /* Component tiles: molecule batches are block-diagonal, so the node range splits into
  * contiguous tiles that no edge crosses. A tile is handled end-to-end by ONE workgroup
  * (rank-width intermediates never leave LDS). Tiles start at the last edge-free boundary
- * at or below every multiple of GCONV_TILE_NODES. */
+ * at or below every multiple of the batch's nominal tile size (GCONV_TILE_NODES, doubled for
+ * batches of GCONV_TILE_WIDE_FROM nodes or more); a tile spans at most 512 nodes. */
 #ifndef GCONV_TILE_NODES
 #define GCONV_TILE_NODES 32
 #endif
-#ifndef GCONV_TILE_BACK
-#define GCONV_TILE_BACK  (512 - GCONV_TILE_NODES)   /* how far a tile start may be pulled back to find a cut */
+/* batches of at least this many nodes are cut at multiples of 2 * GCONV_TILE_NODES instead
+ * (fewer, longer tiles once a persistent workgroup walks many of them) */
+#ifndef GCONV_TILE_WIDE_FROM
+#define GCONV_TILE_WIDE_FROM 65536
 #endif
 
 /* Everything the kernels need to apply S and S^T for one edge list. All pointers

@@ -914,3 +914,33 @@ def test_batch_norm_other_inputs_take_torchs_path(dev):
     assert torch.allclose(m(x), torch.nn.functional.batch_norm(x, None, None, m.weight, m.bias, True), atol=1e-6)
     with pytest.raises(ValueError, match="more than 1 value"):
         ga.BatchNorm1d(8).to(dev)(torch.randn(1, 8, device=dev))
+
+
+# ---------------------------------------------------------------------------
+# whole batches (>= 65536 nodes): tiles are cut at multiples of 64 nodes
+# ---------------------------------------------------------------------------
+def test_wide_tiles_for_whole_batches(dev):
+    """2700 HIV-sized molecules (~69 k nodes): nominal tile size 64 (`_lib.tile_nodes`), same boundary
+    rule, same results — direct build, plan assembled from a resident dataset, adapter vs the oracle."""
+    batch = ga.synth.molecule_batch("hiv", 2700, hidden=64, seed=12)
+    n = batch.num_nodes
+    assert n >= ga._lib.TILE_WIDE_FROM and ga._lib.tile_nodes(n) == 64 and ga._lib.tile_nodes(n - 30000) == 32
+    ei = batch.edge_index.to(dev)
+    plan = ga.GraphPlan(ei, n, True)
+    assert plan.symmetric and plan.n_tiles == -(-n // 64)
+    tp = plan.tile_ptr.cpu().numpy()
+    gptr = batch.graph_ptr.numpy()
+    for t in list(range(0, plan.n_tiles, 37)) + [plan.n_tiles - 1]:
+        assert gptr[gptr <= t * 64].max() == tp[t]
+    assert tp[-1] == n and plan.tile_nodes_max == np.diff(tp).max() <= 64 + int(np.diff(gptr).max())
+    order = plan.tile_order.cpu().numpy()
+    want = np.argsort(-np.diff(tp), kind="stable")
+    assert (order[:, 0] == tp[:-1][want]).all() and (order[:, 1] == np.diff(tp)[want]).all()
+    store = ga.MoleculeStore.from_batch(batch, dev)           # the same batch, assembled from the dataset plan
+    got = store.collate(np.arange(batch.num_graphs), normalize=True)
+    plan2 = ga.get_plan(got.edge_index, n, True)
+    assert plan2.n_tiles == plan.n_tiles and torch.equal(plan2.tile_ptr, plan.tile_ptr)
+    assert torch.equal(plan2.tile_order, plan.tile_order)
+    ga.PLAN_CACHE.clear()
+    flags = oracle.AdapterFlags(learnable_scalar=True, normalize=True)
+    _check_workload(dev, batch, 64, 8, flags)
