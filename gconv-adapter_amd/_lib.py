@@ -20,7 +20,7 @@ SPMM_OUT_PRESCALE = 2
 LONG_ROW = 64
 SEG_EDGES = 128
 TILE_NODES = 32
-TILE_WIDE_FROM = 65536
+TILE_WIDE_FROM = 16384
 
 
 def tile_nodes(num_nodes: int) -> int:

@@ -23,11 +23,14 @@ constexpr int kNumCU = 256;
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-// Nominal nodes per component tile of an n-node batch: GCONV_TILE_NODES (32), and twice that
-// once a persistent workgroup would otherwise walk more than ~8 tiles (measured with libraries
-// built at 32 / 48 / 64 / 96 / 128: the 512-molecule shard does not care up to 64, the
-// 4096-molecule batch runs 8 % faster at 64, everything loses beyond). A tile never exceeds
-// kTileSpan nodes (its start may be pulled back to the previous edge-free boundary).
+// Nominal nodes per component tile of an n-node batch: GCONV_TILE_NODES (32), and twice that as
+// soon as there are enough 64-node tiles to give each of the 256 persistent workgroups one
+// (n >= 16384). Measured with libraries built at 32 / 48 / 64 / 96 / 128 and at batch sizes from
+// 512 to 4096 molecules: below that size 64 only halves the number of busy workgroups (ESOL
+// 24 -> 29 us, the 512-molecule shard 46.7 -> 47.6), above it a workgroup walks half as many
+// latency chains (768 molecules 68.5 -> 50.3 us forward + backward, 1024: 70.3 -> 57.1, 4096:
+// 181 -> 162); 96 and 128 lose everywhere. A tile never exceeds kTileSpan nodes (its start may be
+// pulled back to the previous edge-free boundary).
 constexpr int kTileSpan = 512;
 __host__ __device__ inline int tile_nodes(int n) {
   return n >= GCONV_TILE_WIDE_FROM ? 2 * GCONV_TILE_NODES : GCONV_TILE_NODES;

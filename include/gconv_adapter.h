@@ -106,10 +106,10 @@ typedef struct gconv_csr {
 #ifndef GCONV_TILE_NODES
 #define GCONV_TILE_NODES 32
 #endif
-/* batches of at least this many nodes are cut at multiples of 2 * GCONV_TILE_NODES instead
- * (fewer, longer tiles once a persistent workgroup walks many of them) */
+/* batches of at least this many nodes (256 workgroups x 64 nodes: enough 64-node tiles to give
+ * every persistent workgroup one) are cut at multiples of 2 * GCONV_TILE_NODES instead */
 #ifndef GCONV_TILE_WIDE_FROM
-#define GCONV_TILE_WIDE_FROM 65536
+#define GCONV_TILE_WIDE_FROM 16384
 #endif
 
 /* Everything the kernels need to apply S and S^T for one edge list. All pointers

@@ -332,10 +332,10 @@ def test_adapter_tile_path_large_components(dev):
 
 
 def test_adapter_many_tiles_per_workgroup(dev):
-    """1500 molecules = ~1200 component tiles on 256 persistent workgroups: every workgroup walks
-    4-5 tiles (boustrophedon passes over the size-sorted tile list, spans requested a pass
+    """3200 molecules = ~1280 64-node component tiles on 256 persistent workgroups: every workgroup
+    walks 4-5 tiles (boustrophedon passes over the size-sorted tile list, spans requested a pass
     ahead, accumulators carried across tiles) — vs the fp64 oracle."""
-    batch = ga.synth.molecule_batch("hiv", 1500, hidden=300, seed=21)
+    batch = ga.synth.molecule_batch("hiv", 3200, hidden=300, seed=21)
     plan = ga.GraphPlan(batch.edge_index.to(dev), batch.num_nodes, True)
     assert plan.n_tiles > 4 * 256
     flags = oracle.AdapterFlags(learnable_scalar=True, normalize=True)
@@ -917,14 +917,14 @@ def test_batch_norm_other_inputs_take_torchs_path(dev):
 
 
 # ---------------------------------------------------------------------------
-# whole batches (>= 65536 nodes): tiles are cut at multiples of 64 nodes
+# larger batches (>= 16384 nodes): tiles are cut at multiples of 64 nodes
 # ---------------------------------------------------------------------------
 def test_wide_tiles_for_whole_batches(dev):
     """2700 HIV-sized molecules (~69 k nodes): nominal tile size 64 (`_lib.tile_nodes`), same boundary
     rule, same results — direct build, plan assembled from a resident dataset, adapter vs the oracle."""
     batch = ga.synth.molecule_batch("hiv", 2700, hidden=64, seed=12)
     n = batch.num_nodes
-    assert n >= ga._lib.TILE_WIDE_FROM and ga._lib.tile_nodes(n) == 64 and ga._lib.tile_nodes(n - 30000) == 32
+    assert n >= ga._lib.TILE_WIDE_FROM and ga._lib.tile_nodes(n) == 64 and ga._lib.tile_nodes(16383) == 32
     ei = batch.edge_index.to(dev)
     plan = ga.GraphPlan(ei, n, True)
     assert plan.symmetric and plan.n_tiles == -(-n // 64)

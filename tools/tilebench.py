@@ -28,7 +28,8 @@ def ev(fn, iters=200, warm=10, reps=3):
 
 
 def run(name):
-    batch, cfg = ga.synth.make_workload(name)
+    name, _, graphs = name.partition(":")          # "hiv:2048" = 2048 molecules of the hiv generator
+    batch, cfg = ga.synth.make_workload(name, graphs=int(graphs) if graphs else None)
     d, r = cfg["d"], cfg["r"]
     x = batch.x.reshape(-1, d).to(dev); ei = batch.edge_index.to(dev); g = torch.randn_like(x)
     n = x.shape[0]
