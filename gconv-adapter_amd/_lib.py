@@ -69,7 +69,7 @@ class PendingFinalize(C.Structure):
     _fields_ = [("opaque", C.c_uint64 * 24)]
 
 
-FINALIZE_BATCH = 8
+FINALIZE_BATCH = 5
 ABI_VERSION = 5   # GCONV_ABI_VERSION of include/gconv_adapter.h this binding was written against
 
 

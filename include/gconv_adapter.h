@@ -245,7 +245,11 @@ gconv_status_t gconv_adapter_bwd_f32(const gconv_graph_t* graph,
  * `gconv_adapter_bwd_finalize_f32` then runs any number of pending reductions,
  * GCONV_FINALIZE_BATCH per launch, on `stream` (the stream of the partial calls).
  * bwd == bwd_partial + bwd_finalize(…, 1), bit for bit.                                      */
-#define GCONV_FINALIZE_BATCH 8
+/* (5 descriptors = an 0.8 KB by-value kernel argument; with 8 — 1.26 KB — the launch faulted
+ * under rocprofv3's kernel tracing, never outside it: kept below 1 KB) */
+#ifndef GCONV_FINALIZE_BATCH
+#define GCONV_FINALIZE_BATCH 5
+#endif
 typedef struct gconv_pending_finalize {
   uint64_t opaque[24];
 } gconv_pending_finalize_t;
