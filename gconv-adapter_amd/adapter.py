@@ -171,6 +171,19 @@ class GConvAdapter(nn.Module):
         self.__dict__["_pack"] = (key, pack)
         return pack
 
+    #: per-instance caches that must not travel with a copy: ``_pack`` is a handle into the C++
+    #: ParamPack table keyed on the ORIGINAL's Parameter objects, ``_flat_params`` holds those
+    #: objects, ``_anchor`` is a device tensor of the original's device
+    _TRANSIENT = ("_pack", "_flat_params", "_anchor")
+
+    def __getstate__(self):
+        """copy.deepcopy / pickle / torch.save(model): drop the caches — the copy builds its own
+        on its first forward (and never releases or reuses the original's ParamPack)."""
+        state = self.__dict__.copy()
+        for k in self._TRANSIENT:
+            state.pop(k, None)
+        return state
+
     def __del__(self):
         hit = self.__dict__.get("_pack")
         if hit is not None:

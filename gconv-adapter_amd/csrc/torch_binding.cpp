@@ -218,16 +218,24 @@ std::shared_ptr<ParamPack> pack_get(int64_t id) {
 // adapters of that pass in one launch (gconv_adapter_bwd_finalize_f32): nobody reads a
 // parameter gradient before backward() returns, and a model with five adapters otherwise pays
 // five small launches and five kernel boundaries on the critical path of its backward.
-struct PendingAdd {   // p.grad existed already: add the fresh gradient once it has been reduced
+//
+// Lifetime: the deferred state belongs to ONE autograd graph task. It is owned by the final
+// callback queued on that task (Engine::queue_callback), the process-wide table below only holds
+// weak references keyed by the task id. A backward pass that raises never runs its final callbacks:
+// the engine then destroys them with the graph task, the state dies with its callback, the pending
+// reductions are dropped and no parameter's .grad has been touched — gradients are stored in
+// p.grad only inside flush(), after the reduction that fills them has been launched. The next
+// backward pass has a new task id, finds no live state and queues its own callback.
+struct PendingGrad {
   at::Tensor param, grad;
 };
-struct Deferred {
+struct TaskState {
+  std::mutex mu;
   std::vector<gconv_pending_finalize_t> pending;
-  std::vector<at::Tensor> keep;      // workspaces and gradient buffers of the pending entries
-  std::vector<PendingAdd> adds;
+  std::vector<at::Tensor> keep;      // workspaces of the pending entries
+  std::vector<PendingGrad> grads;    // reduced by `pending`, stored in p.grad by flush()
   int64_t stream = 0;
   int device = 0;                    // the stream's device (the callback may run elsewhere)
-  bool callback_queued = false;
 };
 
 // Runs `fn` with `device` current (kernel launches need the stream's device), restores after.
@@ -240,32 +248,80 @@ void on_device(int device, F&& fn) {
   if (cur != device) (void)hipSetDevice(cur);
 }
 std::mutex g_def_mu;
-Deferred g_def;
+std::unordered_map<int, std::weak_ptr<TaskState>> g_tasks;   // autograd graph task id -> its state
 
-void flush_deferred() {
-  Deferred d;
-  {
-    std::lock_guard<std::mutex> lk(g_def_mu);
-    std::swap(d, g_def);
-  }
-  if (d.pending.empty()) return;
-  on_device(d.device, [&] {
-    check(g_lib.bwd_finalize(d.pending.data(), static_cast<int32_t>(d.pending.size()),
-                             reinterpret_cast<void*>(d.stream)),
+// launches the reductions queued so far and stores their results the way AccumulateGrad would:
+// p.grad = g when undefined, p.grad += g otherwise. Caller holds st.mu.
+void flush_locked(TaskState& st) {
+  if (st.pending.empty()) return;
+  std::vector<gconv_pending_finalize_t> pending;
+  std::vector<PendingGrad> grads;
+  std::vector<at::Tensor> keep;
+  pending.swap(st.pending);
+  grads.swap(st.grads);
+  keep.swap(st.keep);
+  on_device(st.device, [&] {
+    check(g_lib.bwd_finalize(pending.data(), static_cast<int32_t>(pending.size()),
+                             reinterpret_cast<void*>(st.stream)),
           "adapter_bwd_finalize");
   });
   at::NoGradGuard no_grad;
-  for (auto& a : d.adds) a.param.mutable_grad().add_(a.grad);
+  for (auto& a : grads) {
+    at::Tensor& cur = a.param.mutable_grad();
+    if (!cur.defined()) cur = std::move(a.grad);
+    else cur.add_(a.grad);
+  }
 }
 
-// assigns (p.grad undefined: the tensor is filled by the deferred reduction) or schedules the add
-void deposit_grad(const at::Tensor& p, at::Tensor g, Deferred& d) {
+void queue_grad(const at::Tensor& p, at::Tensor g, TaskState& st) {
   if (!g.defined()) return;
-  d.keep.push_back(g);
-  if (!p.defined() || !p.requires_grad()) return;
-  at::Tensor& cur = p.mutable_grad();
-  if (!cur.defined()) cur = std::move(g);
-  else d.adds.push_back({p, std::move(g)});
+  if (!p.defined() || !p.requires_grad()) {
+    st.keep.push_back(std::move(g));   // still written by the reduction
+    return;
+  }
+  st.grads.push_back({p, std::move(g)});
+}
+
+// state of the graph task that is executing the calling node (created, with its final callback, on
+// first use)
+std::shared_ptr<TaskState> current_task_state() {
+  const int tid = torch::autograd::get_current_graph_task_id();
+  std::shared_ptr<TaskState> st;
+  {
+    std::lock_guard<std::mutex> lk(g_def_mu);
+    auto it = g_tasks.find(tid);
+    if (it != g_tasks.end()) st = it->second.lock();
+    if (st) return st;
+    for (auto j = g_tasks.begin(); j != g_tasks.end();)   // tasks that ended (or failed) since
+      j = j->second.expired() ? g_tasks.erase(j) : std::next(j);
+    st = std::make_shared<TaskState>();
+    g_tasks[tid] = st;
+  }
+  torch::autograd::Engine::get_default_engine().queue_callback([st, tid] {
+    {
+      std::lock_guard<std::mutex> lk(st->mu);
+      flush_locked(*st);
+    }
+    std::lock_guard<std::mutex> lk(g_def_mu);
+    auto it = g_tasks.find(tid);
+    if (it != g_tasks.end() && it->second.lock() == st) g_tasks.erase(it);
+  });
+  return st;
+}
+
+// True when standard autograd accumulation has observers that a direct store into p.grad would
+// bypass: tensor hooks, post-accumulate-grad hooks, or hooks on a live grad accumulator (what
+// DistributedDataParallel's reducer installs). Checked on every call: hooks can be added any time.
+bool has_grad_observers(const at::Tensor& p) {
+  if (!p.defined()) return false;
+  auto* meta = torch::autograd::impl::get_autograd_meta(p);
+  if (!meta) return false;
+  if (!meta->hooks_.empty() || meta->post_acc_grad_hooks_) return true;
+  if (auto acc = meta->grad_accumulator_.lock())
+    if (!acc->post_hooks().empty() || !acc->pre_hooks().empty() || !acc->tensor_pre_hooks().empty() ||
+        acc->tensor_post_acc_grad_hooks())
+      return true;
+  return false;
 }
 
 struct AdapterFnDirect : public torch::autograd::Function<AdapterFnDirect> {
@@ -337,33 +393,27 @@ struct AdapterFnDirect : public torch::autograd::Function<AdapterFnDirect> {
                             fptr_mut(gbu), fptr_mut(gsc), ws.data_ptr(), static_cast<size_t>(ws_bwd),
                             &pend, reinterpret_cast<void*>(stream)),
           "adapter_bwd");
-    bool queue = false;
+    // torch.autograd.grad(out, x) / backward(inputs=[x]): the task names its inputs and the
+    // parameters (not graph inputs of this node) are not among them — AccumulateGrad would not
+    // run for them either, so nothing is stored and the partials are dropped.
+    const auto* exec_info = torch::autograd::get_current_graph_task_exec_info();
+    if (exec_info && !exec_info->empty()) return {gx, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
+                                                   at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
+                                                   at::Tensor(), at::Tensor()};
+    const std::shared_ptr<TaskState> st = current_task_state();
     {
-      std::lock_guard<std::mutex> lk(g_def_mu);
-      if (!g_def.pending.empty() && g_def.stream != stream) {   // another stream: do not mix
-        Deferred other;
-        std::swap(other, g_def);
-        g_def.callback_queued = other.callback_queued;
-        on_device(other.device, [&] {
-          check(g_lib.bwd_finalize(other.pending.data(), static_cast<int32_t>(other.pending.size()),
-                                   reinterpret_cast<void*>(other.stream)),
-                "adapter_bwd_finalize");
-        });
-        for (auto& a : other.adds) a.param.mutable_grad().add_(a.grad);
-      }
-      g_def.stream = stream;
-      g_def.device = x.get_device();
-      g_def.pending.push_back(pend);
-      g_def.keep.push_back(ws);
-      deposit_grad(pk->w_down, std::move(gwd), g_def);
-      deposit_grad(pk->b_down, std::move(gbd), g_def);
-      deposit_grad(pk->w_up, std::move(gwu), g_def);
-      deposit_grad(pk->b_up, std::move(gbu), g_def);
-      deposit_grad(pk->scalar, std::move(gsc), g_def);
-      queue = !g_def.callback_queued;
-      g_def.callback_queued = true;
+      std::lock_guard<std::mutex> lk(st->mu);
+      if (!st->pending.empty() && st->stream != stream) flush_locked(*st);   // another stream: do not mix
+      st->stream = stream;
+      st->device = x.get_device();
+      st->pending.push_back(pend);
+      st->keep.push_back(ws);
+      queue_grad(pk->w_down, std::move(gwd), *st);
+      queue_grad(pk->b_down, std::move(gbd), *st);
+      queue_grad(pk->w_up, std::move(gwu), *st);
+      queue_grad(pk->b_up, std::move(gbu), *st);
+      queue_grad(pk->scalar, std::move(gsc), *st);
     }
-    if (queue) torch::autograd::Engine::get_default_engine().queue_callback([] { flush_deferred(); });
     at::Tensor none;
     return {gx, none, none, none, none, none, none, none, none, none, none};
   }
@@ -372,6 +422,15 @@ struct AdapterFnDirect : public torch::autograd::Function<AdapterFnDirect> {
 at::Tensor adapter_apply_direct(at::Tensor x, c10::optional<at::Tensor> anchor, int64_t pack_id,
                                 at::Tensor arena, int64_t graph_addr, int64_t fp, int64_t ws_fwd,
                                 int64_t ws_bwd, int64_t act, bool skip, int64_t stream) {
+  {
+    const std::shared_ptr<ParamPack> pk = pack_get(pack_id);
+    if (has_grad_observers(pk->w_down) || has_grad_observers(pk->b_down) || has_grad_observers(pk->w_up) ||
+        has_grad_observers(pk->b_up) || has_grad_observers(pk->scalar)) {
+      auto opt = [](const at::Tensor& t) { return t.defined() ? c10::optional<at::Tensor>(t) : c10::nullopt; };
+      return AdapterFn::apply(x, pk->w_down, opt(pk->b_down), pk->w_up, opt(pk->b_up), opt(pk->scalar), arena,
+                              graph_addr, fp, ws_fwd, ws_bwd, act, skip, stream);
+    }
+  }
   return AdapterFnDirect::apply(x, anchor, pack_id, arena, graph_addr, fp, ws_fwd, ws_bwd, act, skip, stream);
 }
 
@@ -393,14 +452,15 @@ at::Tensor adapter_apply(at::Tensor x, at::Tensor w_down, c10::optional<at::Tens
 //
 // Memory: the arena is allocated by the submitting thread on ITS current stream; the side
 // stream first waits for an event recorded there at submit time (edge_index is complete and
-// every earlier use of the recycled block has drained), and gconv_graph_build returns only
-// after the side stream has finished, so the consumer needs no further synchronisation.
+// every earlier use of the recycled block has drained). gconv_graph_build returns with its last
+// launch (the size sort of the component tiles) still queued on the side stream, so the worker
+// records a second event behind the build and plan_take() makes the CONSUMER's stream wait for it.
 // ---------------------------------------------------------------------------------------
 struct PlanJob {
   at::Tensor edge_index, arena;
   int64_t num_edges = 0;
   int32_t num_nodes = 0, normalize = 0, device = 0;
-  hipEvent_t ready = nullptr;
+  hipEvent_t ready = nullptr, built = nullptr;
   void* side_stream = nullptr;
   gconv_graph_t graph{};
   gconv_status_t status = 0;
@@ -434,6 +494,7 @@ class PlanWorker {
     const size_t bytes = g_lib.build_bytes(job->num_edges, job->num_nodes);
     job->arena = at::empty({static_cast<int64_t>(bytes)}, edge_index.options().dtype(at::kByte));
     TORCH_CHECK(hipEventCreateWithFlags(&job->ready, hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&job->built, hipEventDisableTiming) == hipSuccess &&
                     hipEventRecord(job->ready, reinterpret_cast<hipStream_t>(main_stream)) == hipSuccess,
                 "gconv_adapter_amd: cannot record the prefetch event");
     std::lock_guard<std::mutex> lk(mu_);
@@ -445,8 +506,9 @@ class PlanWorker {
     return id;
   }
 
-  // (arena, gconv_graph_t bytes, status); blocks until the build has finished
-  std::tuple<at::Tensor, py::bytes, int64_t> take(int64_t id) {
+  // (arena, gconv_graph_t bytes, status); blocks until the build call has returned and orders
+  // `consumer_stream` behind everything the build queued on the side stream
+  std::tuple<at::Tensor, py::bytes, int64_t> take(int64_t id, int64_t consumer_stream) {
     std::shared_ptr<PlanJob> job;
     {
       py::gil_scoped_release nogil;
@@ -457,7 +519,13 @@ class PlanWorker {
       done_cv_.wait(lk, [&] { return job->done; });
       jobs_.erase(it);
     }
+    gconv_status_t st = job->status;
+    if (st == 0)   // status > 0 is a hipError_t
+      st = static_cast<gconv_status_t>(
+          hipStreamWaitEvent(reinterpret_cast<hipStream_t>(consumer_stream), job->built, 0));
     (void)hipEventDestroy(job->ready);
+    (void)hipEventDestroy(job->built);
+    job->status = st;
     return {job->arena, py::bytes(reinterpret_cast<const char*>(&job->graph), sizeof(gconv_graph_t)),
             static_cast<int64_t>(job->status)};
   }
@@ -483,6 +551,7 @@ class PlanWorker {
       if (st == 0)
         st = g_lib.build(job->edge_index.data_ptr<int64_t>(), job->num_edges, job->num_nodes, job->normalize,
                          job->arena.data_ptr(), static_cast<size_t>(job->arena.numel()), &job->graph, side);
+      if (st == 0) st = static_cast<gconv_status_t>(hipEventRecord(job->built, side));
       {
         std::lock_guard<std::mutex> lk(mu_);
         job->status = st;
@@ -510,7 +579,9 @@ int64_t plan_submit(at::Tensor edge_index, int64_t num_nodes, bool normalize, in
                     int64_t side_stream) {
   return worker().submit(std::move(edge_index), num_nodes, normalize, main_stream, side_stream);
 }
-std::tuple<at::Tensor, py::bytes, int64_t> plan_take(int64_t id) { return worker().take(id); }
+std::tuple<at::Tensor, py::bytes, int64_t> plan_take(int64_t id, int64_t consumer_stream) {
+  return worker().take(id, consumer_stream);
+}
 
 
 // out = scalar * LayerNorm(z): the adapter's layer_norm tail (gconv_adapter.py:101-102,105-106),

@@ -188,12 +188,18 @@ class PlanCache:
         fut = self._pending.pop(key, None)
         if isinstance(fut, tuple):                # (job id, edge_index) of the native worker
             from . import _torch_ext
-            plan = GraphPlan(fut[1], num_nodes, normalize, _built=_torch_ext.get().plan_take(fut[0]))
+            # plan_take orders this stream behind the side stream's last launch (the tile size sort
+            # is queued after the build's final host synchronisation)
+            plan = GraphPlan(fut[1], num_nodes, normalize, _built=_torch_ext.get().plan_take(
+                fut[0], torch._C._cuda_getCurrentRawStream(fut[1].device.index)))
             self.hits += 1
         elif fut is not None:                     # built (or being built) by the Python prefetcher
             plan = fut.result()
-            # the arena was allocated on the side stream but is consumed on this one
-            plan.arena.record_stream(torch.cuda.current_stream(plan.device))
+            # the arena was allocated on the side stream but is consumed on this one, and the
+            # build's last launch (tile size sort) may still be queued there
+            cur = torch.cuda.current_stream(plan.device)
+            cur.wait_stream(self._side_streams[plan.device])
+            plan.arena.record_stream(cur)
             self.hits += 1
         else:
             self.misses += 1
@@ -245,7 +251,7 @@ class PlanCache:
         for fut in list(self._pending.values()):
             if isinstance(fut, tuple):
                 from . import _torch_ext
-                _torch_ext.get().plan_take(fut[0])
+                _torch_ext.get().plan_take(fut[0], torch._C._cuda_getCurrentRawStream(fut[1].device.index))
             else:
                 fut.result()
         self._pending.clear()

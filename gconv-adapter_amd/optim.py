@@ -63,7 +63,7 @@ class FusedAdam(torch.optim.Optimizer):
         grad = torch.zeros_like(flat)
         grad_views = [grad[o:o + p.numel()].view_as(p) for p, o in zip(ps, offsets)]
         return dict(params=ps, offsets=offsets, total=total, flat=flat, grad=grad, grad_views=grad_views,
-                    exp_avg=m, exp_avg_sq=v, step=0)
+                    exp_avg=m, exp_avg_sq=v, steps=[0] * len(ps))
 
     # ------------------------------------------------------------------ step
     @torch.no_grad()
@@ -77,27 +77,34 @@ class FusedAdam(torch.optim.Optimizer):
             if not ps:
                 continue
             grads = [p.grad for p in ps]
-            if all(g is None for g in grads):
+            has = [g is not None for g in grads]
+            if not any(has):
                 continue
-            fl["step"] += 1     # (the per-parameter "step" tensors are refreshed by state_dict())
+            # torch.optim.Adam counts the step PER PARAMETER (a parameter without a gradient is
+            # skipped and its bias correction does not advance): keep one counter each
+            steps = fl["steps"]
+            for i, h in enumerate(has):
+                if h:
+                    steps[i] += 1
             beta1, beta2 = group["betas"]
             dev = fl["flat"].device
-            if not any(g is None for g in grads):   # the normal case: one multi-tensor copy, one launch
+            if all(has) and min(steps) == max(steps):   # the normal case: one multi-tensor copy, one launch
                 torch._foreach_copy_(fl["grad_views"], grads)
                 st = self._lib.gconv_adam_step_f32(
                     fl["flat"].data_ptr(), fl["grad"].data_ptr(), fl["exp_avg"].data_ptr(),
                     fl["exp_avg_sq"].data_ptr(), fl["total"], float(group["lr"]), float(beta1), float(beta2),
-                    float(group["eps"]), float(group["weight_decay"]), fl["step"], _stream(dev.index))
+                    float(group["eps"]), float(group["weight_decay"]), steps[0], _stream(dev.index))
                 _lib.check(st, "adam_step")
                 continue
-            # contiguous runs of parameters that have a gradient
+            # contiguous runs of parameters that have a gradient AND the same step count: one
+            # launch per run, each with its own bias correction
             i = 0
             while i < len(ps):
-                if grads[i] is None:
+                if not has[i]:
                     i += 1
                     continue
                 j = i
-                while j < len(ps) and grads[j] is not None:
+                while j < len(ps) and has[j] and steps[j] == steps[i]:
                     j += 1
                 lo = fl["offsets"][i]
                 hi = fl["offsets"][j - 1] + ps[j - 1].numel()
@@ -106,7 +113,7 @@ class FusedAdam(torch.optim.Optimizer):
                     fl["flat"].data_ptr() + 4 * lo, fl["grad"].data_ptr() + 4 * lo,
                     fl["exp_avg"].data_ptr() + 4 * lo, fl["exp_avg_sq"].data_ptr() + 4 * lo, hi - lo,
                     float(group["lr"]), float(beta1), float(beta2), float(group["eps"]),
-                    float(group["weight_decay"]), fl["step"], _stream(dev.index))
+                    float(group["weight_decay"]), steps[i], _stream(dev.index))
                 _lib.check(st, "adam_step")
                 i = j
         return loss
@@ -117,8 +124,8 @@ class FusedAdam(torch.optim.Optimizer):
         (the moments are views of the flat buffers: deep-copy before loading it elsewhere, as with
         any optimizer state dict that is not going through ``torch.save``)."""
         for fl in self._flat:
-            for p in fl.get("params", []):
-                self.state[p]["step"] = torch.tensor(float(fl["step"]))
+            for p, k in zip(fl.get("params", []), fl.get("steps", [])):
+                self.state[p]["step"] = torch.tensor(float(k))
         return super().state_dict()
 
     def load_state_dict(self, state_dict) -> None:
@@ -134,6 +141,5 @@ class FusedAdam(torch.optim.Optimizer):
                     mine["exp_avg_sq"].copy_(loaded["exp_avg_sq"])
                     mine["step"] = torch.as_tensor(float(loaded["step"]))
                     self.state[p] = mine
-            steps = [int(self.state[p]["step"]) for p in fl.get("params", [])]
-            if steps:
-                fl["step"] = max(steps)
+            if fl.get("params"):
+                fl["steps"] = [int(self.state[p]["step"]) for p in fl["params"]]

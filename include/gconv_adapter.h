@@ -141,7 +141,11 @@ size_t gconv_graph_build_bytes(int64_t num_edges, int32_t num_nodes);
  *   test on device -> S^T only if the edge list is not symmetric -> component tiles.
  * `arena` (device, >= gconv_graph_build_bytes, 256-B aligned) receives every output
  * array; it must stay alive as long as `graph_host_out` is used.
- * Synchronises `stream` once (twice for asymmetric edge lists) to return the counters.
+ * Synchronises `stream` once (twice for asymmetric edge lists) to return the counters;
+ * the LAST launch (the size sort that fills `tile_order`) is queued on `stream` AFTER that
+ * synchronisation and may still be pending when the call returns: consumers on `stream` are
+ * ordered behind it by the stream itself, a consumer on ANOTHER stream must first wait for an
+ * event recorded on `stream` after this call.
  * Returns GCONV_E_BAD_INDEX if an endpoint is out of range — never a device fault. */
 gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t num_edges,
                                  int32_t num_nodes, int32_t normalize,

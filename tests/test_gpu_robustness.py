@@ -1,0 +1,220 @@
+"""Behaviour of the host side of the HIP path when things go wrong or get copied — `-m gpu`.
+
+What the reference's loops do around the adapter (`/root/reference/scripts/
+finetune_inductive_learning.py:43-67`): `zero_grad`, forward, `loss.backward()`, `step`, with
+`RuntimeError`s logged and the batch skipped; models are deep-copied / saved between epochs
+(`:423-441`). None of that may leave the adapter in a state that changes later results.
+"""
+from __future__ import annotations
+
+import copy
+import io
+
+import pytest
+import torch
+
+import gconv_adapter_amd as ga
+from oracle import pyg_restated as oracle
+
+from helpers import assert_close, grad_atol
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(dev, seed=0, **kw):
+    batch, cfg = ga.synth.make_workload("esol")
+    d, r = cfg["d"], cfg["r"]
+    flags = oracle.AdapterFlags(non_linearity="relu", learnable_scalar=True, skip_connection=True,
+                                normalize=True)
+    params = oracle.init_params(d, r, flags, seed=seed)
+    mod = ga.GConvAdapter(d, r, learnable_scalar=True, normalize=True, **kw).to(dev)
+    with torch.no_grad():
+        for k, v in params.items():
+            mod.get_parameter(k).copy_(v.float())
+    g = torch.randn(batch.num_nodes, d, generator=torch.Generator().manual_seed(seed + 7))
+    return batch, flags, params, mod, g
+
+
+def _check_against_oracle(mod, batch, flags, params, g, xg, out):
+    want_out, want = oracle.adapter_forward_backward(batch.x.double(), batch.edge_index, params, flags, g.double())
+    assert_close(out.detach().cpu().double(), want_out, "out")
+    assert_close(xg.grad.cpu().double(), want["x"], "grad x")
+    for k in params:
+        got = mod.get_parameter(k).grad
+        assert got is not None, f"grad {k} missing"
+        assert_close(got.cpu().double(), want[k], f"grad {k}", atol=grad_atol(want[k]))
+
+
+class _RaiseInBackward(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        raise RuntimeError("injected failure in a node that runs after the adapter's")
+
+
+def test_failed_backward_does_not_poison_later_steps(dev):
+    """A node that runs AFTER the adapter's backward node raises: the autograd engine then never
+    runs the final callback that launches the deferred reduction. The parameters' .grad must not
+    have been touched (never uninitialised memory), and the next steps must be exact again —
+    with the deferred reduction running, i.e. a fresh callback per backward pass."""
+    if ga._torch_ext.get() is None:
+        pytest.skip("pure-Python binding selected")
+    batch, flags, params, mod, g = _setup(dev)
+    ei = batch.edge_index.to(dev)
+    for _ in range(3):      # several failures in a row, state must not pile up
+        mod.zero_grad(set_to_none=True)
+        x0 = batch.x.to(dev).requires_grad_(True)
+        out = mod(_RaiseInBackward.apply(x0), ei)
+        with pytest.raises(RuntimeError, match="injected failure"):
+            out.backward(g.to(dev))
+        torch.cuda.synchronize()
+        for k, p in mod.named_parameters():
+            assert p.grad is None, f"{k}.grad was assigned by a backward pass that failed"
+    for _ in range(2):      # and two good steps afterwards
+        mod.zero_grad(set_to_none=True)
+        xg = batch.x.to(dev).requires_grad_(True)
+        out = mod(xg, ei)
+        out.backward(g.to(dev))
+        torch.cuda.synchronize()
+        _check_against_oracle(mod, batch, flags, params, g, xg, out)
+
+
+def test_failed_backward_keeps_accumulated_gradients(dev):
+    """Same failure with gradients already present (accumulation over micro-batches): the
+    existing .grad keeps its values, a later good backward adds exactly one contribution."""
+    if ga._torch_ext.get() is None:
+        pytest.skip("pure-Python binding selected")
+    batch, flags, params, mod, g = _setup(dev, seed=3)
+    ei = batch.edge_index.to(dev)
+    x = batch.x.to(dev)
+    mod(x, ei).backward(g.to(dev))
+    first = {k: p.grad.clone() for k, p in mod.named_parameters()}
+    out = mod(_RaiseInBackward.apply(x.clone().requires_grad_(True)), ei)
+    with pytest.raises(RuntimeError, match="injected failure"):
+        out.backward(g.to(dev))
+    for k, p in mod.named_parameters():
+        assert torch.equal(p.grad, first[k])
+    mod(x, ei).backward(g.to(dev))
+    for k, p in mod.named_parameters():
+        assert torch.equal(p.grad, first[k] + first[k])
+
+
+def test_grad_wrt_inputs_only_leaves_parameter_grads_alone(dev):
+    """torch.autograd.grad(out, x) and backward(inputs=[x]) must not write p.grad (AccumulateGrad
+    would not run for the parameters either); dX is still the oracle's."""
+    batch, flags, params, mod, g = _setup(dev, seed=5)
+    ei = batch.edge_index.to(dev)
+    xg = batch.x.to(dev).requires_grad_(True)
+    out = mod(xg, ei)
+    (dx,) = torch.autograd.grad(out, xg, g.to(dev), retain_graph=True)
+    assert all(p.grad is None for p in mod.parameters())
+    out.backward(g.to(dev), inputs=[xg], retain_graph=True)
+    assert all(p.grad is None for p in mod.parameters())
+    assert torch.equal(dx, xg.grad)
+    xg.grad = None
+    out.backward(g.to(dev))
+    _check_against_oracle(mod, batch, flags, params, g, xg, out)
+
+
+def test_hook_registered_after_first_forward_is_honoured(dev):
+    """The choice between direct deposit and standard accumulation is made per call: a tensor hook
+    or post-accumulate-grad hook added AFTER the first forward still runs."""
+    batch, flags, params, mod, g = _setup(dev, seed=6)
+    ei = batch.edge_index.to(dev)
+    x = batch.x.to(dev)
+    mod(x, ei).backward(g.to(dev))
+    want = {k: p.grad.clone() for k, p in mod.named_parameters()}
+    mod.zero_grad(set_to_none=True)
+    seen = []
+    mod.conv_down.bias.register_hook(lambda gr: seen.append("pre"))
+    mod.conv_up.lin.weight.register_post_accumulate_grad_hook(lambda p: seen.append("post"))
+    mod(x, ei).backward(g.to(dev))
+    assert sorted(seen) == ["post", "pre"]
+    for k, p in mod.named_parameters():
+        assert torch.equal(p.grad, want[k])
+
+
+def test_deepcopy_and_pickle_give_independent_modules(dev):
+    """copy.deepcopy / torch.save(model) after a forward: the copy owns its own parameter pack;
+    original and copy keep working (and training) independently, deleting one leaves the other."""
+    batch, flags, params, mod, g = _setup(dev, seed=8)
+    ei = batch.edge_index.to(dev)
+    x = batch.x.to(dev)
+    mod(x, ei).backward(g.to(dev))
+    want = {k: p.grad.clone() for k, p in mod.named_parameters()}
+    twin = copy.deepcopy(mod)
+    buf = io.BytesIO()
+    torch.save(mod, buf)
+    buf.seek(0)
+    loaded = torch.load(buf, weights_only=False)
+    for m in (twin, loaded):
+        assert not any(k in m.__dict__ for k in ga.GConvAdapter._TRANSIENT)
+    for m in (twin, loaded, mod, twin, mod):
+        m.zero_grad(set_to_none=True)
+        m(x, ei).backward(g.to(dev))
+        for k, p in m.named_parameters():
+            assert torch.equal(p.grad, want[k]), k
+    # the copy's parameters are its own: changing them changes only its output
+    with torch.no_grad():
+        twin.conv_up.bias.add_(1.0)
+    assert not torch.equal(twin(x, ei), mod(x, ei))
+    del twin, loaded
+    import gc
+    gc.collect()
+    mod.zero_grad(set_to_none=True)
+    mod(x, ei).backward(g.to(dev))
+    for k, p in mod.named_parameters():
+        assert torch.equal(p.grad, want[k])
+
+
+def test_prefetched_plan_is_ordered_behind_its_build(dev):
+    """A plan built by the prefetch worker on a side stream is consumed on the main stream while
+    the main stream is idle: tile_order (written by the build's LAST launch, queued after its host
+    synchronisation) must be complete — results equal those of a plan built in-stream."""
+    batch, cfg = ga.synth.make_workload("hiv")
+    d, r = cfg["d"], cfg["r"]
+    mod = ga.GConvAdapter(d, r, learnable_scalar=True).to(dev)
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.normal_(0, 0.1)
+    x = batch.x.to(dev)
+    ei0 = batch.edge_index.to(dev)
+    with torch.no_grad():
+        want = mod(x, ei0)
+    for _ in range(20):
+        ei = ei0.clone()
+        torch.cuda.synchronize()          # main stream idle: nothing orders it behind the side stream
+        ga.prefetch_plan(ei, batch.num_nodes, True)
+        with torch.no_grad():
+            got = mod(x, ei)
+        assert torch.equal(got, want)
+        ga.graph.PLAN_CACHE.discard(ei, batch.num_nodes, True)
+
+
+def test_fused_adam_counts_steps_per_parameter(dev):
+    """A parameter that had no gradient on earlier steps is bias-corrected with ITS step count, as
+    torch.optim.Adam does (state['step'] is per parameter)."""
+    torch.manual_seed(1)
+    shapes = [(8, 16), (8,), (16, 8), (1,)]
+    base = [torch.randn(s) * 0.1 for s in shapes]
+    grads = [[torch.randn(s) for s in shapes] for _ in range(5)]
+    skip = {0: {1}, 1: {1, 3}, 2: set(), 3: {0}, 4: set()}     # step -> parameters with grad None
+
+    def run(make_opt, device, dtype):
+        ps = [torch.nn.Parameter(b.to(device=device, dtype=dtype).clone()) for b in base]
+        opt = make_opt(ps)
+        for step in range(5):
+            for i, (p, g) in enumerate(zip(ps, grads[step])):
+                p.grad = None if i in skip[step] else g.to(device=device, dtype=dtype)
+            opt.step()
+        return ps, opt
+
+    ps_ref, opt_ref = run(lambda ps: torch.optim.Adam(ps, lr=1e-2), "cpu", torch.float64)
+    ps_f, opt_f = run(lambda ps: ga.FusedAdam(ps, lr=1e-2), dev, torch.float32)
+    for pr, pf in zip(ps_ref, ps_f):
+        assert torch.allclose(pf.detach().cpu().double(), pr.detach(), rtol=1e-5, atol=1e-7)
+    sd_ref, sd_f = opt_ref.state_dict()["state"], opt_f.state_dict()["state"]
+    assert [int(sd_f[i]["step"]) for i in range(4)] == [int(sd_ref[i]["step"]) for i in range(4)] == [4, 3, 5, 4]

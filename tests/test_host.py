@@ -257,3 +257,20 @@ def test_batch_norm_module_is_a_drop_in_on_any_input():
     assert set(k for k in adapter.state_dict() if k.startswith("normalization")) == {
         "normalization.weight", "normalization.bias", "normalization.running_mean", "normalization.running_var",
         "normalization.num_batches_tracked"}
+
+
+def test_copies_drop_the_per_instance_caches():
+    """deepcopy / pickle of a module that has run: the ParamPack handle, the cached Parameter
+    tuple and the anchor tensor belong to the ORIGINAL and must not travel with the copy
+    (the copy would release the original's pack on its first forward)."""
+    import copy
+    import pickle
+    mod = ga.GConvAdapter(32, 4, learnable_scalar=True)
+    mod.__dict__["_flat_params"] = ("stale",)
+    mod.__dict__["_anchor"] = torch.zeros(1)
+    for twin in (copy.deepcopy(mod), pickle.loads(pickle.dumps(mod))):
+        assert not any(k in twin.__dict__ for k in ga.GConvAdapter._TRANSIENT)
+        assert set(twin.state_dict()) == set(mod.state_dict())
+        assert twin.conv_down.lin.weight is not mod.conv_down.lin.weight
+    assert "_flat_params" in mod.__dict__
+    del mod.__dict__["_flat_params"], mod.__dict__["_anchor"]
