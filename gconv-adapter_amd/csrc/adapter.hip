@@ -17,6 +17,7 @@
 // implicit self-loop term disappears.)
 #include <cstring>
 
+#include "fused_gather.h"
 #include "fused_tile.h"
 #include "gemm.h"
 #include "spmm.h"
@@ -209,6 +210,19 @@ static gconv_status_t fwd_stages(const gconv_graph_t* gr, const gconv_adapter_pa
     SpmmArgs k2b{};
     k2b.dis = dis; k2b.H = saved_h; k2b.Y = saved_p; k2b.rank = r; k2b.seg_partial = seg;
     k2b.row_lo = lo; k2b.row_hi = hi;
+    if (lo == 0 && hi == graph->num_nodes && fused_gather_enabled(graph->num_nodes)) {
+      // K2' + K3 in one launch (fused_gather.hip); only the long rows' segments run in front
+      if (graph->n_seg > 0) {
+        k2b.seg_only = 1;
+        st = launch_spmm(graph, k2b, fp, EPI_STORE, stream);
+        if (st != GCONV_OK) return st;
+      }
+      UpGatherArgs f{};
+      f.rowptr = graph->rowptr; f.col = graph->col; f.dis = dis; f.H = saved_h; f.P = saved_p;
+      f.up.W_up = p->w_up; f.up.b_up = p->b_up; f.up.scalar = p->scalar; f.up.X = x; f.up.out = out;
+      f.up.n = rows; f.up.d = d; f.up.r = r; f.up.fp = fp; f.up.skip = p->skip;
+      return launch_up_gather(f, stream);
+    }
     st = launch_spmm(graph, k2b, fp, EPI_STORE, stream);
     if (st != GCONV_OK) return st;
 

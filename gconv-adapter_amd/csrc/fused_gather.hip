@@ -1,0 +1,188 @@
+// K2' + K3 and B3 + B4 of the general path as ONE launch each (gfx950).
+//
+// Replaces, together with spmm.hip / gemm.hip: the second `propagate` of the adapter
+// (conv_up of /root/reference/src/finetune/gconv_adapter.py:92, reassociated to rank r), the
+// residual / bias / scalar tail (:94-95,105-106) and, in the backward, the transposed
+// propagation that feeds dX / dW_down.
+//
+// Why fuse: P = S H2' is needed row by row by the up-projection (a per-row dependency, unlike
+// K2 -> K2', which needs ALL rows of H2'). As separate launches the gather kernel is bound by
+// the fabric's random-row rate (25 us at S-arxiv) while HBM idles, then the projection streams
+// X / out (37 us) while the gather path idles. Fused, a workgroup requests its X tile, gathers
+// the P rows of the same nodes meanwhile, parks them in LDS (and in HBM for the backward) and
+// multiplies. Rows longer than GCONV_LONG_ROW edges keep their segment path (a small launch of
+// the SpMM's segment blocks in front); every other row is summed by row_gather_sum — the same
+// code, hence the same bits, as the stand-alone SpMM.
+#include <cstdlib>
+
+#include "fused_gather.h"
+#include "spmm.h"
+
+namespace gconv {
+
+// Read per call: tests and tools flip the knobs inside one process. Above the node limit the
+// separate launches win (S-arxiv forward 124 us against 130 fused: a workgroup waits at its
+// barrier for the wave with the longest rows, a stand-alone SpMM wave only delays itself);
+// below it the launch that disappears is what counts (Cora forward 21 -> 15 us).
+bool fused_gather_enabled(int num_nodes) {
+  const char* v = std::getenv("GCONV_NO_FUSED_GATHER");
+  if (!(v == nullptr || v[0] == '\0' || v[0] == '0')) return false;
+  const char* m = std::getenv("GCONV_FUSED_GATHER_MAX_NODES");
+  return num_nodes <= (m ? std::atoi(m) : 65536);
+}
+
+static int env_int(const char* name, int dflt) {
+  const char* v = std::getenv(name);
+  return v ? std::atoi(v) : dflt;
+}
+
+// Gathers the rank-width rows of one node super-block (SB = 16 * nslots rows starting at sb0)
+// into the LDS tile `tile` ([SB][FP + 4]); short rows are also stored to `store` when STORE.
+//   W = waves of the workgroup; every wave takes RPW rows per pass.
+template <int FP, bool NORM, bool STORE>
+__device__ __forceinline__ void gather_block_rows(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                  const float* __restrict__ dis, const float* __restrict__ H,
+                                                  float* __restrict__ store, float* tile, int sb0, int SB, int n,
+                                                  int w, int W, int lane) {
+  constexpr int LPR = FP / 4, RPW = kWave / LPR, PST = FP + 4;
+  const int sub = lane % LPR, grp = lane / LPR;
+  for (int pass = 0; pass * W * RPW < SB; ++pass) {   // uniform
+    const int ridx = (pass * W + w) * RPW + grp;
+    const int row = sb0 + ridx;
+    const bool inb = ridx < SB && row < n;
+    const int rowc = min(row, n - 1);
+    const int e0 = rowptr[rowc], e1 = rowptr[rowc + 1];
+    const bool is_long = (e1 - e0) > GCONV_LONG_ROW;
+    const int deg = (inb && !is_long) ? e1 - e0 : 0;
+    const f32x4 sum = row_gather_sum<FP>(H, col, e0, e1, deg, rowc, sub, grp, false, nullptr);
+    const size_t off = static_cast<size_t>(rowc) * FP + 4 * sub;
+    f32x4 v = sum;
+    if (NORM) v = (sum + ldg4(H + off)) * dis[rowc];   // == spmm_epilogue<F, true, EPI_STORE>
+    if (__any(inb && is_long)) {                       // rare: completed by the segment launch
+      const f32x4 pl = ldg4(store + off);
+      v = is_long ? pl : v;
+    }
+    if (inb) {
+      if (STORE && !is_long) stg4(store + off, v);
+      *reinterpret_cast<f32x4*>(tile + ridx * PST + 4 * sub) = v;
+    }
+  }
+}
+
+// A fragments of the LDS tile for node row `r` of the super-block: frag[s] = tile[r][rank_k(s, t)]
+template <int FP>
+__device__ __forceinline__ void tile_rank_frag(const float* tile, int r, int t, float (&frag)[FP / 4]) {
+  constexpr int PST = FP + 4;
+  const float* p = tile + r * PST;
+  if constexpr (FP >= 16) {
+#pragma unroll
+    for (int q = 0; q < FP / 16; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p + 16 * q + 4 * t);
+      frag[4 * q + 0] = v[0]; frag[4 * q + 1] = v[1];
+      frag[4 * q + 2] = v[2]; frag[4 * q + 3] = v[3];
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < FP / 4; ++s) frag[s] = p[4 * s + t];
+  }
+}
+
+// ===========================================================================
+// K2' + K3
+// ===========================================================================
+template <int FP, bool NORM, int TB>
+__global__ __launch_bounds__(TB) void up_gather_kernel(UpGatherArgs a, int nchunks, int nslots) {
+  extern __shared__ float ptile[];   // [16 nslots][FP + 4]
+  constexpr int KS = FP / 4;
+  const UpArgs& u = a.up;
+  const int lane = threadIdx.x & 63, w = wave_id();
+  const int J = w % nchunks, slot = w / nchunks;
+  const int jj = lane & 15, t = lane >> 4;
+  const int colbase = 64 * J + 4 * jj;
+  const bool colvalid = colbase < u.d;
+  const float sval = u.scalar ? u.scalar[0] : 1.f;
+  const int W = nchunks * nslots, SB = 16 * nslots;
+
+  // B fragments: wb[s][c] = W_up[colbase + c][rank_k(s, t)]
+  float wb[KS][4];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int k = rank_k<FP>(s, t);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      wb[s][c] = (colvalid && k < u.r) ? u.W_up[static_cast<size_t>(colbase + c) * u.r + k] : 0.f;
+  }
+  f32x4 bu = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (colvalid && u.b_up) bu = ldg4(u.b_up + colbase);
+
+  const int nsb = ceil_div(u.n, SB);
+  for (int sb = blockIdx.x; sb < nsb; sb += gridDim.x) {
+    const int i0 = sb * SB + slot * 16;
+    // the [16, 64] X tile of this wave first: it streams from HBM while the P rows are gathered
+    f32x4 xv[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) xv[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (u.skip) load_tile_L(u.X, i0, t, u.n, u.d, colbase, colvalid, xv);   // uniform branch
+    gather_block_rows<FP, NORM, true>(a.rowptr, a.col, a.dis, a.H, a.P, ptile, sb * SB, SB, u.n, w, W, lane);
+    __syncthreads();
+    float pa[KS];
+    tile_rank_frag<FP>(ptile, slot * 16 + jj, t, pa);
+    f32x4 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = mfma16(pa[s], wb[s][c], acc[c]);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int row = i0 + 4 * t + m;
+      if (colvalid && row < u.n) {
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = sval * (acc[c][m] + bu[c] + xv[m][c]);
+        stg4(u.out + static_cast<size_t>(row) * u.d + colbase, o);
+      }
+    }
+    __syncthreads();   // the tile is rewritten by the next super-block
+  }
+}
+
+template <int FP, bool NORM>
+static gconv_status_t launch_up_gather_t(const UpGatherArgs& a, int grid, int threads, size_t lds, int nchunks,
+                                         int nslots, hipStream_t stream) {
+  if (threads <= 256) up_gather_kernel<FP, NORM, 256><<<grid, threads, lds, stream>>>(a, nchunks, nslots);
+  else if (threads <= 512) up_gather_kernel<FP, NORM, 512><<<grid, threads, lds, stream>>>(a, nchunks, nslots);
+  else up_gather_kernel<FP, NORM, 1024><<<grid, threads, lds, stream>>>(a, nchunks, nslots);
+  GCONV_LAUNCH_CHECK();
+  return GCONV_OK;
+}
+
+gconv_status_t launch_up_gather(const UpGatherArgs& a, hipStream_t stream) {
+  const UpArgs& u = a.up;
+  if (u.n == 0) return GCONV_OK;
+  const int nchunks = ceil_div(u.d, 64);
+  if (nchunks > 16) return GCONV_E_UNSUPPORTED;
+  const int nslots = chunk_slots(nchunks, 4);
+  const int SB = 16 * nslots, nsb = ceil_div(u.n, SB);
+  // persistent: a few workgroups per CU so that one workgroup's gather latency hides behind
+  // the others' streams (GCONV_UPG_WGPC: measured at S-arxiv)
+  const int wgpc = env_int("GCONV_UPG_WGPC", 3);
+  int grid = nsb < wgpc * kNumCU ? nsb : wgpc * kNumCU;
+  const int threads = 64 * nchunks * nslots;
+  const size_t lds = static_cast<size_t>(SB) * (u.fp + 4) * sizeof(float);
+#define GCONV_UPG_CASE(FP_)                                                                         \
+  case FP_:                                                                                         \
+    return a.dis ? launch_up_gather_t<FP_, true>(a, grid, threads, lds, nchunks, nslots, stream)    \
+                 : launch_up_gather_t<FP_, false>(a, grid, threads, lds, nchunks, nslots, stream);
+  switch (u.fp) {
+    GCONV_UPG_CASE(4) GCONV_UPG_CASE(8) GCONV_UPG_CASE(16) GCONV_UPG_CASE(32) GCONV_UPG_CASE(64)
+  }
+#undef GCONV_UPG_CASE
+  return GCONV_E_UNSUPPORTED;
+}
+
+gconv_status_t launch_bwd_gather(const BwdGatherArgs&, hipStream_t) { return GCONV_E_UNSUPPORTED; }
+
+}  // namespace gconv

@@ -83,4 +83,54 @@ constexpr int kReduceBlocks = 32;
 gconv_status_t launch_reduce_rows(const float* in, int rows, int width, float* out,
                                   hipStream_t stream);
 
+// ===========================================================================
+// Shared helpers for the L-layout kernels
+// ===========================================================================
+// MFMA k index that lane-quarter t feeds in k-step s of a rank-width operand:
+//   FP >= 16: float4 fragments, k = 16 (s / 4) + 4 t + (s % 4);  FP < 16: k = 4 s + t
+template <int FP>
+__device__ __forceinline__ int rank_k(int s, int t) {
+  return FP >= 16 ? 16 * (s >> 2) + 4 * t + (s & 3) : 4 * s + t;
+}
+
+// A fragments of a rank-width matrix Z[N, FP] for node row `row`:
+// frag[s] = Z[row][rank_k(s, t)], s = 0 .. FP/4 - 1.
+template <int FP>
+__device__ __forceinline__ void load_rank_frag(const float* __restrict__ Z, int row, int t,
+                                               float (&frag)[FP / 4]) {
+  const float* p = Z + static_cast<size_t>(row) * FP;
+  if constexpr (FP >= 16) {
+#pragma unroll
+    for (int q = 0; q < FP / 16; ++q) {
+      const f32x4 v = ldg4(p + 16 * q + 4 * t);
+      frag[4 * q + 0] = v[0]; frag[4 * q + 1] = v[1];
+      frag[4 * q + 2] = v[2]; frag[4 * q + 3] = v[3];
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < FP / 4; ++s) frag[s] = p[4 * s + t];
+  }
+}
+
+// waves of one workgroup = nchunks (64-column chunks of d) x nslots (node-block slots)
+inline int chunk_slots(int nchunks, int target_waves) {
+  const int s = target_waves / nchunks;
+  return s < 1 ? 1 : s;
+}
+
+// Loads the four L-layout rows (i0 + 4 t + m, m = 0..3) of a [n, d] matrix.
+__device__ __forceinline__ void load_tile_L(const float* __restrict__ M, int i0, int t, int n,
+                                            int d, int colbase, bool colvalid, f32x4 (&v)[4]) {
+  // clamped address + select instead of a per-lane branch around the load (a branch makes
+  // hipcc wait vmcnt(0) after every load); n == 0 means "operand not used": all zeros.
+  const int col = min(colbase, d - 4);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int row = i0 + 4 * t + m;
+    const f32x4 x = ldg4(M + static_cast<size_t>(min(row, max(n, 1) - 1)) * d + col);
+    v[m] = (colvalid && row < n) ? x : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+
 }  // namespace gconv

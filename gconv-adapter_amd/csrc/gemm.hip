@@ -34,7 +34,7 @@ namespace gconv {
 // the current block has fed its MFMAs, the same register is re-loaded with k-step q of the
 // wave's NEXT block, so NQ loads stay in flight per wave under straight-line code (no
 // branch between a load and its use: hipcc can then emit counted vmcnt waits).
-template <int NCB, int NQ>
+template <int NCB, int NQ, int DEPTH>
 __global__ __launch_bounds__(256) void gemm_rowsA_kernel(RowsAArgs a) {
   extern __shared__ f32x4 wl[];  // [NQ][NCB][64] weight fragments
   const int lane = threadIdx.x & 63, wave = wave_id();
@@ -78,69 +78,88 @@ __global__ __launch_bounds__(256) void gemm_rowsA_kernel(RowsAArgs a) {
   const float* __restrict__ rsp = has_rs ? a.row_scale : a.X;
   const float* __restrict__ pp = has_p ? a.P : a.X;
 
+  // DEPTH rings of NQ registers: ring dd holds the wave's block blk + dd * stride; once a k-step
+  // has fed its MFMAs the slot is refilled for the block DEPTH strides ahead, so a load has
+  // DEPTH block periods to arrive (one period is shorter than the memory latency under load).
   int blk = blockIdx.x * 4 + wave;
-  f32x4 x[NQ];
-  {
-    const float* xb = a.X + static_cast<size_t>(min(min(blk, nblk - 1) * 16 + node, a.n - 1)) * a.d;
+  f32x4 x[DEPTH][NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) x[q] = ldg4(xb + koff[q]);
+  for (int dd = 0; dd < DEPTH; ++dd) {
+    const float* xb = a.X + static_cast<size_t>(min(min(blk + dd * stride, nblk - 1) * 16 + node, a.n - 1)) * a.d;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) x[dd][q] = ldg4(xb + koff[q]);
   }
   while (blk < nblk) {
-    const int i0 = blk * 16;
-    // next block of this wave (clamped: the last prefetch of a wave is redundant, never invalid)
-    const int nb = min(blk + stride, nblk - 1);
-    const float* __restrict__ xn = a.X + static_cast<size_t>(min(nb * 16 + node, a.n - 1)) * a.d;
-    // Epilogue operands of THIS block first: vmcnt retires in order, so a small load issued
-    // after the ring refills could only be waited for by draining the whole prefetch.
-    float rs[4], pv[NCB][4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int rowc = min(i0 + 4 * kq + m, a.n - 1);
-      const float v = rsp[has_rs ? rowc : 0];
-      rs[m] = has_rs ? v : 1.f;
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) {
-        const int cc = min(16 * cb + node, a.fp - 1);
-        const float pvv = pp[has_p ? static_cast<size_t>(rowc) * a.fp + cc : 0];
-        pv[cb][m] = has_p ? pvv : 0.f;
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);  // keep those loads ahead of the ring refills
-    f32x4 acc[NCB][2];
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) acc[cb][0] = acc[cb][1] = zero;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const f32x4 xv = kok[q] ? x[q] : zero;
-      x[q] = ldg4(xn + koff[q]);  // ring: refill this slot for the next block ...
-      __builtin_amdgcn_sched_barrier(0);  // ... BEFORE this k-step's MFMAs, not after the burst
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) {
-        const f32x4 w = wl[(q * NCB + cb) * 64 + lane];
-        acc[cb][0] = mfma16(xv[0], w[0], acc[cb][0]);
-        acc[cb][1] = mfma16(xv[1], w[1], acc[cb][1]);
-        acc[cb][0] = mfma16(xv[2], w[2], acc[cb][0]);
-        acc[cb][1] = mfma16(xv[3], w[3], acc[cb][1]);
-      }
-    }
-
-    // D register m <-> (row i0 + 4 kq + m, column 16 cb + node)
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) {
-      const f32x4 res = acc[cb][0] + acc[cb][1];
-      const int c = 16 * cb + node;
+    for (int dd = 0; dd < DEPTH; ++dd) {
+      const int cur = blk + dd * stride;
+      const bool live = cur < nblk;                // uniform; a dead block recomputes the last one, stores nothing
+      const int i0 = min(cur, nblk - 1) * 16;
+      // the block this ring holds next (clamped: redundant at the tail, never invalid)
+      const int nb = min(cur + DEPTH * stride, nblk - 1);
+      const float* __restrict__ xn = a.X + static_cast<size_t>(min(nb * 16 + node, a.n - 1)) * a.d;
+      // Epilogue operands of THIS block first: vmcnt retires in order, so a small load issued
+      // after the ring refills could only be waited for by draining the whole prefetch.
+      float rs[4], pv[NCB][4];
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        const int row = i0 + 4 * kq + m;
-        if (row < a.n && c < a.fp) {
-          float v = res[m];
-          ds_acc += v * pv[cb][m];
-          if (a.mode == ROWSA_DP) v *= sval;
-          a.out[static_cast<size_t>(row) * a.fp + c] = v * rs[m];
+        const int rowc = min(i0 + 4 * kq + m, a.n - 1);
+        const float v = rsp[has_rs ? rowc : 0];
+        rs[m] = has_rs ? v : 1.f;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+          const int cc = min(16 * cb + node, a.fp - 1);
+          const float pvv = pp[has_p ? static_cast<size_t>(rowc) * a.fp + cc : 0];
+          pv[cb][m] = has_p ? pvv : 0.f;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep those loads ahead of the ring refills
+      f32x4 acc[NCB][2];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) acc[cb][0] = acc[cb][1] = zero;
+      // weight fragments are double-buffered in registers: the LDS reads of k-step q + 1 are
+      // issued BEFORE the MFMAs of k-step q (with one buffer the read can only follow the last
+      // MFMA that uses the old values, and its whole LDS latency is exposed once per k-step)
+      f32x4 wq[2][NCB];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) wq[0][cb] = wl[cb * 64 + lane];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const f32x4 xv = kok[q] ? x[dd][q] : zero;
+        x[dd][q] = ldg4(xn + koff[q]);  // ring: refill this slot ...
+        if (q + 1 < NQ) {
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) wq[(q + 1) & 1][cb] = wl[((q + 1) * NCB + cb) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // ... BEFORE this k-step's MFMAs, not after the burst
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+          const f32x4 w = wq[q & 1][cb];
+          acc[cb][0] = mfma16(xv[0], w[0], acc[cb][0]);
+          acc[cb][1] = mfma16(xv[1], w[1], acc[cb][1]);
+          acc[cb][0] = mfma16(xv[2], w[2], acc[cb][0]);
+          acc[cb][1] = mfma16(xv[3], w[3], acc[cb][1]);
+        }
+      }
+
+      // D register m <-> (row i0 + 4 kq + m, column 16 cb + node)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const f32x4 res = acc[cb][0] + acc[cb][1];
+        const int c = 16 * cb + node;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int row = i0 + 4 * kq + m;
+          if (live && row < a.n && c < a.fp) {
+            float v = res[m];
+            ds_acc += v * pv[cb][m];
+            if (a.mode == ROWSA_DP) v *= sval;
+            a.out[static_cast<size_t>(row) * a.fp + c] = v * rs[m];
+          }
         }
       }
     }
-    blk += stride;
+    blk += DEPTH * stride;
   }
 
   if (a.ds_partial) {  // block-wide sum in a fixed order
@@ -169,15 +188,23 @@ size_t rowsA_lds_bytes(int d, int fp) {
 int rowsA_grid(int n) {
   const int nblk = ceil_div(n, 16);
   int g = ceil_div(nblk, 4);  // persistent: <= 2 workgroups per CU walk the node blocks
-  return g < 1 ? 1 : (g > 2 * kNumCU ? 2 * kNumCU : g);   // measured best at S-arxiv: 2 (27 us) vs 3-6 (28-29 us)
+  static const int wgpc = std::getenv("GCONV_ROWSA_WGPC") ? std::atoi(std::getenv("GCONV_ROWSA_WGPC")) : 2;
+  return g < 1 ? 1 : (g > wgpc * kNumCU ? wgpc * kNumCU : g);   // measured best at S-arxiv: 2 (27 us) vs 3-6 (28-29 us)
 }
 
+// Ring depth: 1. A second ring (two block periods for a load to arrive, 123 VGPRs) was measured
+// in round 2 at S-arxiv: 27.2 -> 32.3 us, at 2 and at 3 workgroups per CU — the kernel is not
+// short of bytes in flight. GCONV_ROWSA_DEPTH=2 selects it for d <= 192 (A/B knob).
 template <int NCB>
 static gconv_status_t launch_rowsA_ncb(const RowsAArgs& a, int nq, int grid, size_t lds,
                                        hipStream_t stream) {
+  static const int depth_env = std::getenv("GCONV_ROWSA_DEPTH") ? std::atoi(std::getenv("GCONV_ROWSA_DEPTH")) : 1;
   switch (nq) {
-#define GCONV_ROWSA_CASE(NQ_) \
-    case NQ_: gemm_rowsA_kernel<NCB, NQ_><<<grid, 256, lds, stream>>>(a); break;
+#define GCONV_ROWSA_CASE(NQ_)                                                                      \
+    case NQ_:                                                                                      \
+      if (depth_env >= 2 && NQ_ <= 12) gemm_rowsA_kernel<NCB, NQ_, 2><<<grid, 256, lds, stream>>>(a); \
+      else gemm_rowsA_kernel<NCB, NQ_, 1><<<grid, 256, lds, stream>>>(a);                          \
+      break;
     GCONV_ROWSA_CASE(2) GCONV_ROWSA_CASE(4) GCONV_ROWSA_CASE(8) GCONV_ROWSA_CASE(12)
     GCONV_ROWSA_CASE(16) GCONV_ROWSA_CASE(19) GCONV_ROWSA_CASE(24) GCONV_ROWSA_CASE(32)
     GCONV_ROWSA_CASE(48) GCONV_ROWSA_CASE(64)
@@ -200,55 +227,6 @@ gconv_status_t launch_rowsA(const RowsAArgs& a, hipStream_t stream) {
     case 4: return launch_rowsA_ncb<4>(a, nq, grid, lds, stream);
   }
   return GCONV_E_UNSUPPORTED;
-}
-
-// ===========================================================================
-// Shared helpers for the L-layout kernels
-// ===========================================================================
-// MFMA k index that lane-quarter t feeds in k-step s of a rank-width operand:
-//   FP >= 16: float4 fragments, k = 16 (s / 4) + 4 t + (s % 4);  FP < 16: k = 4 s + t
-template <int FP>
-__device__ __forceinline__ int rank_k(int s, int t) {
-  return FP >= 16 ? 16 * (s >> 2) + 4 * t + (s & 3) : 4 * s + t;
-}
-
-// A fragments of a rank-width matrix Z[N, FP] for node row `row`:
-// frag[s] = Z[row][rank_k(s, t)], s = 0 .. FP/4 - 1.
-template <int FP>
-__device__ __forceinline__ void load_rank_frag(const float* __restrict__ Z, int row, int t,
-                                               float (&frag)[FP / 4]) {
-  const float* p = Z + static_cast<size_t>(row) * FP;
-  if constexpr (FP >= 16) {
-#pragma unroll
-    for (int q = 0; q < FP / 16; ++q) {
-      const f32x4 v = ldg4(p + 16 * q + 4 * t);
-      frag[4 * q + 0] = v[0]; frag[4 * q + 1] = v[1];
-      frag[4 * q + 2] = v[2]; frag[4 * q + 3] = v[3];
-    }
-  } else {
-#pragma unroll
-    for (int s = 0; s < FP / 4; ++s) frag[s] = p[4 * s + t];
-  }
-}
-
-// waves of one workgroup = nchunks (64-column chunks of d) x nslots (node-block slots)
-static int chunk_slots(int nchunks, int target_waves) {
-  const int s = target_waves / nchunks;
-  return s < 1 ? 1 : s;
-}
-
-// Loads the four L-layout rows (i0 + 4 t + m, m = 0..3) of a [n, d] matrix.
-__device__ __forceinline__ void load_tile_L(const float* __restrict__ M, int i0, int t, int n,
-                                            int d, int colbase, bool colvalid, f32x4 (&v)[4]) {
-  // clamped address + select instead of a per-lane branch around the load (a branch makes
-  // hipcc wait vmcnt(0) after every load); n == 0 means "operand not used": all zeros.
-  const int col = min(colbase, d - 4);
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const int row = i0 + 4 * t + m;
-    const f32x4 x = ldg4(M + static_cast<size_t>(min(row, max(n, 1) - 1)) * d + col);
-    v[m] = (colvalid && row < n) ? x : f32x4{0.f, 0.f, 0.f, 0.f};
-  }
 }
 
 // ===========================================================================
@@ -449,6 +427,10 @@ __global__ __launch_bounds__(TB) void bwd_main_kernel(BwdMainArgs a, int nchunks
       load_tile_L(a.G, nc * 16, t, a.n, a.d, colbase, colvalid, gn);
       load_tile_L(a.X, nc * 16, t, a.n, a.d, colbase, colvalid, xn);
     }
+    // (hipcc sinks these eight loads below most of the block's ~90 MFMAs. Pinning them ahead of
+    // the burst with a second sched_barrier was measured in round 2: 72.7 -> 87.4 us at S-arxiv —
+    // the loads then share the issue window with the fragment loads above and the dX stores of
+    // the previous block queue behind them; left to the compiler.)
 
     // contraction over the 16 nodes: k-step m covers nodes i0 + 4 t + m
 #pragma unroll

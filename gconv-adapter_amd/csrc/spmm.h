@@ -36,7 +36,67 @@ struct SpmmArgs {
   int act;
   int rank;             // valid columns (bias length)
   uint32_t flags;
+  int seg_only;         // launch the long-row segment blocks only (the fused K2'+K3 / B3+B4 kernels
+                        // gather the short rows themselves and read the long rows' results)
 };
+
+template <int F>
+struct RowShape {
+  static constexpr int LPR = F / 4;        // lanes per row
+  static constexpr int RPW = kWave / LPR;  // rows per wave
+};
+
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+// Plain sum over a row's stored edges of the gathered rows of H — the one summation order of
+// every short row (<= GCONV_LONG_ROW edges) in the library: spmm_rows_kernel and the fused
+// gather kernels (fused_gather.hip) call this, so a row's result has the same bits whichever
+// kernel produced it.
+//   lane group `grp` (LPR = F/4 lanes, `sub` = lane inside the group) owns the row; `deg` = edges
+//   this group sums (0: none), e0 / e1 = the row's CSR range, rowc = a valid row index (padding
+//   gathers read that row's own line and are masked out of the sum).
+// The loop over 8-edge batches is WAVE-UNIFORM (trip count = longest row of the wave), so it
+// can be software-pipelined without hipcc fencing every load: the 8 column indices of a batch
+// are fetched by the row's own lanes (8 / LPR coalesced loads, the next batch's are in flight
+// during the gathers) and broadcast by lane shuffle.
+template <int F>
+__device__ __forceinline__ f32x4 row_gather_sum(const float* __restrict__ H, const int32_t* __restrict__ col,
+                                                int e0, int e1, int deg, int rowc, int sub, int grp,
+                                                bool gather_scale, const float* __restrict__ dis) {
+  constexpr int LPR = RowShape<F>::LPR;
+  constexpr int CPL = (8 + LPR - 1) / LPR;  // column loads per lane per batch
+  int nbat = (deg + 7) >> 3;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) nbat = max(nbat, __shfl_xor(nbat, off));
+  nbat = __builtin_amdgcn_readfirstlane(nbat);
+  const int elast = max(e1 - 1, 0);
+  int cn[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) cn[j] = col[min(e0 + sub + j * LPR, elast)];
+  f32x4 acc0 = zero4(), acc1 = zero4();
+  for (int it = 0; it < nbat; ++it) {
+    int cc[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) cc[j] = cn[j];
+    const int eb = e0 + 8 * it;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) cn[j] = col[min(eb + 8 + sub + j * LPR, elast)];
+    f32x4 h[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int c = __shfl(cc[u / LPR], grp * LPR + (u % LPR));
+      c = (eb + u < e0 + deg) ? c : rowc;
+      h[u] = ldg4(H + static_cast<size_t>(c) * F + 4 * sub);
+      if (gather_scale) h[u] *= dis[c];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) h[u] = (eb + u < e0 + deg) ? h[u] : zero4();
+    // fixed association order: ((h0+h1)+(h2+h3)) + ((h4+h5)+(h6+h7))
+    acc0 += (h[0] + h[1]) + (h[2] + h[3]);
+    acc1 += (h[4] + h[5]) + (h[6] + h[7]);
+  }
+  return acc0 + acc1;
+}
 
 // rows of `bias_partial` an EPI_BWD1 launch writes for this graph / width (`rows` of them
 // produced by the launch: the whole graph, or one row slab of it)

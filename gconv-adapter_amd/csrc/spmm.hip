@@ -21,14 +21,6 @@
 
 namespace gconv {
 
-template <int F>
-struct RowShape {
-  static constexpr int LPR = F / 4;        // lanes per row
-  static constexpr int RPW = kWave / LPR;  // rows per wave
-};
-
-__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
-
 // ---------------------------------------------------------------------------
 // Epilogue shared by the row path and the long-row completion of the row kernel.
 //   `sum` = plain sum over the row's stored edges of the gathered rows.
@@ -188,43 +180,8 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(SpmmArgs a) {
   const bool mine = row < a.row_hi && (e1 - e0) <= GCONV_LONG_ROW;  // long rows: segment path
   const int deg = mine ? e1 - e0 : 0;
 
-  // The loop over 8-edge batches is WAVE-UNIFORM (trip count = longest row of the wave), so
-  // it can be software-pipelined without hipcc fencing every load: the 8 column indices of a
-  // batch are fetched by the row's own lanes (8 / LPR coalesced loads, the next batch's are
-  // in flight during the gathers) and broadcast by lane shuffle; edges past the end of a
-  // row gather the row's own line instead (an L1 hit) and are masked out of the sum.
-  constexpr int CPL = (8 + LPR - 1) / LPR;  // column loads per lane per batch
-  int nbat = (deg + 7) >> 3;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) nbat = max(nbat, __shfl_xor(nbat, off));
-  nbat = __builtin_amdgcn_readfirstlane(nbat);
-  const int elast = max(e1 - 1, 0);
-  int cn[CPL];
-#pragma unroll
-  for (int j = 0; j < CPL; ++j) cn[j] = col[min(e0 + sub + j * LPR, elast)];
-  f32x4 acc0 = zero4(), acc1 = zero4();
-  for (int it = 0; it < nbat; ++it) {
-    int cc[CPL];
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) cc[j] = cn[j];
-    const int eb = e0 + 8 * it;
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) cn[j] = col[min(eb + 8 + sub + j * LPR, elast)];
-    f32x4 h[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      int c = __shfl(cc[u / LPR], grp * LPR + (u % LPR));
-      c = (eb + u < e0 + deg) ? c : rowc;
-      h[u] = ldg4(H + static_cast<size_t>(c) * F + 4 * sub);
-      if (gather_scale) h[u] *= a.dis[c];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) h[u] = (eb + u < e0 + deg) ? h[u] : zero4();
-    // fixed association order: ((h0+h1)+(h2+h3)) + ((h4+h5)+(h6+h7))
-    acc0 += (h[0] + h[1]) + (h[2] + h[3]);
-    acc1 += (h[4] + h[5]) + (h[6] + h[7]);
-  }
-  if (mine) spmm_epilogue<F, NORM, EPI>(a, row, sub, acc0 + acc1, bias_grad);
+  const f32x4 sum = row_gather_sum<F>(H, col, e0, e1, deg, rowc, sub, grp, gather_scale, a.dis);
+  if (mine) spmm_epilogue<F, NORM, EPI>(a, row, sub, sum, bias_grad);
   if (EPI == EPI_BWD1) block_bias_partial<F>(bias_grad, a.bias_partial + static_cast<size_t>(rblock) * F);
 }
 
@@ -233,7 +190,7 @@ static gconv_status_t launch_spmm_t(SpmmArgs& a, hipStream_t stream) {
   constexpr int RPW = RowShape<F>::RPW;
   a.row_blocks = ceil_div(a.row_hi - a.row_lo, 4 * RPW);
   const int seg_blocks = ceil_div(a.n_seg, 4);
-  const int grid = a.row_blocks + seg_blocks;
+  const int grid = (a.seg_only ? 0 : a.row_blocks) + seg_blocks;
   if (grid > 0) {
     spmm_rows_kernel<F, NORM, EPI><<<grid, 256, 0, stream>>>(a);
     GCONV_LAUNCH_CHECK();

@@ -944,3 +944,46 @@ def test_wide_tiles_for_whole_batches(dev):
     ga.PLAN_CACHE.clear()
     flags = oracle.AdapterFlags(learnable_scalar=True, normalize=True)
     _check_workload(dev, batch, 64, 8, flags)
+
+
+@pytest.mark.parametrize("kind,d,r,normalize", [("cora", 32, 16, True), ("cora", 32, 16, False),
+                                                ("hub", 128, 32, True), ("hub", 300, 8, True),
+                                                ("hub", 64, 4, False), ("directed", 128, 32, True)])
+def test_fused_gather_launches_equal_separate_launches(dev, kind, d, r, normalize, monkeypatch):
+    """General path, forward: K2' + K3 as ONE launch (fused_gather.hip; rows gathered inside the
+    up-projection, long rows by the SpMM's segment blocks in front) must give the bits of the
+    separate launches — out, every gradient (the saved P feeds the backward) — for hub graphs with
+    long rows, directed graphs, both normalisation modes, ragged last node blocks."""
+    if kind == "cora":
+        batch, _ = ga.synth.make_workload("cora")
+        ei, n = batch.edge_index, batch.num_nodes
+    elif kind == "hub":
+        n = 3001
+        g = torch.Generator().manual_seed(5)
+        u = torch.randint(n, (9000,), generator=g)
+        v = (n * torch.rand(9000, generator=g) ** 3).long().clamp_(max=n - 1)
+        hub = torch.stack([torch.randint(n, (700,), generator=g), torch.zeros(700, dtype=torch.long)])
+        pairs = torch.cat([torch.stack([u, v]), hub], dim=1)
+        ei = torch.cat([pairs, pairs.flip(0)], dim=1)
+    else:
+        n = 2500
+        ei = _random_graph(n, 12000, 9, symmetric=False)
+    x = torch.randn(n, d, generator=torch.Generator().manual_seed(1)).to(dev)
+    gr = torch.randn(n, d, generator=torch.Generator().manual_seed(2)).to(dev)
+    eid = ei.to(dev)
+    mod = ga.GConvAdapter(d, r, learnable_scalar=True, normalize=normalize, non_linearity="silu").to(dev)
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.normal_(0, 0.1)
+    res = []
+    for fused in ("0", "1"):
+        monkeypatch.setenv("GCONV_NO_FUSED_GATHER", "0" if fused == "1" else "1")
+        mod.zero_grad(set_to_none=True)
+        xg = x.clone().requires_grad_(True)
+        out = mod(xg, eid)
+        out.backward(gr)
+        res.append([out.detach(), xg.grad] + [p.grad for p in mod.parameters()])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    if kind == "hub":
+        assert ga.get_plan(eid, n, normalize).fwd.n_long > 0
