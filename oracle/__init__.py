@@ -14,7 +14,10 @@ is not installed in the build container and cannot be installed (no network).
 The reference repository holds no tests, golden vectors or fixtures for this
 path. This oracle therefore restates the published ``GCNConv`` / ``gcn_norm`` /
 ``MessagePassing.propagate`` semantics and anchors on the reference's own call
-sites (``src/finetune/gconv_adapter.py:40-41,73-78,92-106``). Two independent
-derivations (edge-list form in PyG's op order, and a dense fp64 matrix form)
-are cross-checked against each other and against autograd.
+sites (``src/finetune/gconv_adapter.py:40-41,73-78,92-106``). Three independent
+derivations are cross-checked against each other and against the committed golden vectors:
+``pyg_restated.py`` (edge lists, PyG's op order, torch autograd), ``dense_ref.py`` (dense fp64
+matrix form, hand-written backward) and ``gconv_oracle.c`` (plain C, scalar loops over the edge
+list, hand-written backward; compiled by ``__graft_entry__.build()``, loaded through
+``c_oracle.py``).
 """

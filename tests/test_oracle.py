@@ -184,3 +184,72 @@ def test_g1_fixture_has_the_documented_edge_cases():
     assert pairs.count((1, 2)) == 2                          # duplicate edge
     assert (3, 0) in pairs and (0, 3) not in pairs           # directed-only edge
     assert 4 not in ei.flatten().tolist()                    # isolated node
+
+
+# ---- third derivation: plain C, hand-written backward in PyG's op order ------------------
+def _c_oracle():
+    from oracle import c_oracle
+    c_oracle.load()
+    return c_oracle
+
+
+@pytest.mark.parametrize("name", ["g1_path5_norm.npz", "g1_path5_raw.npz", "g2_molecules.npz"])
+def test_c_oracle_matches_golden_fixtures(name):
+    """oracle/gconv_oracle.c (scalar loops over the edge list, conv_up propagated at width d as
+    PyG does, backward written by hand) reproduces the committed golden vectors."""
+    c = _c_oracle()
+    case = golden_case(load_golden(name))
+    params = {k: v.double() for k, v in case["params"].items()}
+    out, grads = c.adapter_forward_backward(case["x"].double(), case["edge_index"], params, case["flags"],
+                                            case["grad_out"].double())
+    assert torch.allclose(out, case["expected"]["out"], rtol=1e-11, atol=1e-11)
+    for k, v in case["expected"].items():
+        if k != "out":
+            assert torch.allclose(grads[k], v, rtol=1e-10, atol=1e-10), k
+
+
+def test_c_oracle_matches_golden_flag_grid():
+    c = _c_oracle()
+    rec = load_golden("g4_flags.npz")
+    seen = 0
+    for i in range(36):
+        case = golden_case(rec, i)
+        if case["flags"].normalization != "none":
+            continue
+        seen += 1
+        params = {k: v.double() for k, v in case["params"].items()}
+        out, grads = c.adapter_forward_backward(case["x"].double(), case["edge_index"], params, case["flags"],
+                                                case["grad_out"].double())
+        assert torch.allclose(out, case["expected"]["out"], rtol=1e-11, atol=1e-11)
+        for k, v in case["expected"].items():
+            if k != "out":
+                assert torch.allclose(grads[k], v, rtol=1e-10, atol=1e-10), (i, k)
+    assert seen == 12
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_c_oracle_matches_torch_oracle_on_random_graphs(seed):
+    """directed lists with duplicates and self-loops, isolated nodes, both normalisation modes"""
+    c = _c_oracle()
+    g = torch.Generator().manual_seed(100 + seed)
+    n, d, r = 30 + 7 * seed, 8 + 4 * seed, 1 + seed
+    ei = _rand_graph(n - 3, 4 * n, seed=200 + seed)          # the last 3 nodes stay isolated
+    flags = oracle.AdapterFlags(non_linearity=["relu", "silu", "none"][seed % 3], learnable_scalar=seed % 2 == 0,
+                                skip_connection=seed % 3 != 1, normalize=seed % 2 == 1)
+    params = oracle.init_params(d, r, flags, seed=300 + seed)
+    x = torch.randn(n, d, generator=g, dtype=torch.float64)
+    gout = torch.randn(n, d, generator=g, dtype=torch.float64)
+    out, grads = oracle.adapter_forward_backward(x, ei, params, flags, gout)
+    out2, grads2 = c.adapter_forward_backward(x, ei, params, flags, gout)
+    assert torch.allclose(out, out2, rtol=1e-11, atol=1e-11)
+    for k, v in grads2.items():
+        assert torch.allclose(grads[k], v, rtol=1e-10, atol=1e-10), k
+
+
+def test_c_oracle_rejects_bad_edges():
+    c = _c_oracle()
+    flags = oracle.AdapterFlags()
+    params = oracle.init_params(4, 2, flags)
+    x = torch.zeros(3, 4, dtype=torch.float64)
+    with pytest.raises(RuntimeError):
+        c.adapter_forward_backward(x, torch.tensor([[0, 5], [1, 1]]), params, flags, x)

@@ -55,6 +55,71 @@ for remap in (0, 1):
     assert f() == 0
     t = ev(f)
     print(f"v1 remap={remap}        {t:6.2f} us  {algo/t/1e3:6.0f} GB/s  {check(y, 'v1')}", flush=True)
+
+# ---- row schedules: which XCD handles which rows (blocks are dealt round-robin over the 8 XCDs)
+import numpy as np
+ei = batch.edge_index.numpy(); src, dst = ei[0], ei[1]
+keep = src != dst; src, dst = src[keep], dst[keep]
+degn = np.bincount(dst, minlength=n)
+
+
+def distinct(xcd_of_row):
+    key = np.unique(xcd_of_row[dst].astype(np.int64) * n + src)
+    selfk = xcd_of_row.astype(np.int64) * n + np.arange(n)
+    return len(np.union1d(key, selfk))
+
+
+def sched_from_assign(assign):
+    """slot order such that block b (32 slots) holds rows of XCD b % 8; rows of an XCD keep index order"""
+    lists = [np.flatnonzero(assign == x) for x in range(8)]
+    nb = (n + 31) // 32
+    out = np.full(nb * 32, -1, dtype=np.int64)
+    ptr = [0] * 8
+    spill = []
+    for b in range(nb):
+        x = b % 8
+        take = lists[x][ptr[x]:ptr[x] + 32]
+        ptr[x] += len(take)
+        out[b * 32:b * 32 + len(take)] = take
+    rest = np.concatenate([lists[x][ptr[x]:] for x in range(8)])
+    holes = np.flatnonzero(out < 0)[:len(rest)]
+    out[holes] = rest
+    assert (np.sort(out[out >= 0]) == np.arange(n)).all()
+    return out[:n] if (out[:n] >= 0).all() else out
+
+
+def run_sched(name, sched_np):
+    sched = torch.from_numpy(sched_np.astype(np.int32)).to(dev)
+    y = torch.zeros_like(h)
+    f = lambda: lab.lab_v1s(C.c_void_p(rowptr.data_ptr()), C.c_void_p(col.data_ptr()), C.c_void_p(dis.data_ptr()),
+                            C.c_void_p(h.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(sched.data_ptr()),
+                            int(sched.numel()), C.c_void_p(stream))
+    assert f() == 0
+    t = ev(f)
+    print(f"v1s {name:28s} {t:6.2f} us  {algo/t/1e3:6.0f} GB/s  {check(y, 'v1s')}", flush=True)
+
+
+ident = np.arange(n)
+print("distinct (xcd,row) pairs, identity schedule:", distinct((ident // 32) % 8))
+run_sched("identity", ident)
+rng = np.random.default_rng(0)
+assign = (ident // 32) % 8
+w = degn + 1
+for it in range(12):
+    cnt = np.zeros((n, 8), dtype=np.int32)
+    np.add.at(cnt, (dst, assign[src]), 1)
+    load = np.bincount(assign, weights=w, minlength=8)
+    pen = (load / load.mean() - 1) * 6
+    new = np.argmax(cnt - pen[None, :], axis=1)
+    mv = rng.random(n) < 0.5
+    assign = np.where(mv, new, assign)
+    if it in (2, 5, 11):
+        load = np.bincount(assign, weights=w, minlength=8)
+        print(f"label-prop it {it}: distinct {distinct(assign)}  load max/mean {load.max()/load.mean():.3f}  rows max/mean {np.bincount(assign, minlength=8).max()/ (n/8):.3f}")
+        run_sched(f"label-prop it{it}", sched_from_assign(assign))
+# degree-sorted inside the schedule (heavy rows first) as a control
+run_sched("degree-desc", np.argsort(-degn, kind="stable"))
+sys.exit(0)
 for S in (4, 8, 16):
     for K in (1, 8, 16, 32):
         for remap in (0, 1):

@@ -144,6 +144,56 @@ __global__ __launch_bounds__(256) void v2_kernel(const int* __restrict__ rowptr,
   }
 }
 
+// v1s: rows taken from a schedule (sched[i] = row handled by row slot i; slot -> block -> XCD)
+__global__ __launch_bounds__(256) void v1s_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                  const float* __restrict__ dis, const float* __restrict__ H,
+                                                  float* __restrict__ Y, const int* __restrict__ sched, int n) {
+  const int lane = threadIdx.x & 63, wave = wave_id();
+  const int sub = lane & 7, grp = lane >> 3;
+  const int slot = (blockIdx.x * 4 + wave) * 8 + grp;
+  const int row = slot < n ? sched[slot] : -1;
+  const int rowc = max(row, 0);
+  const int e0 = rowptr[rowc], e1 = rowptr[rowc + 1];
+  const bool mine = row >= 0 && (e1 - e0) <= LONG;
+  const int deg = mine ? e1 - e0 : 0;
+  int nbat = (deg + 7) >> 3;
+  for (int off = 32; off > 0; off >>= 1) nbat = max(nbat, __shfl_xor(nbat, off));
+  nbat = __builtin_amdgcn_readfirstlane(nbat);
+  const int elast = max(e1 - 1, 0);
+  int cn = col[min(e0 + sub, elast)];
+  f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+  for (int it = 0; it < nbat; ++it) {
+    const int cc = cn;
+    const int eb = e0 + 8 * it;
+    cn = col[min(eb + 8 + sub, elast)];
+    f32x4 h[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int c = __shfl(cc, grp * 8 + u);
+      c = (eb + u < e0 + deg) ? c : rowc;
+      h[u] = *reinterpret_cast<const f32x4*>(H + static_cast<size_t>(c) * F + 4 * sub);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) h[u] = (eb + u < e0 + deg) ? h[u] : f32x4{0, 0, 0, 0};
+    acc0 += (h[0] + h[1]) + (h[2] + h[3]);
+    acc1 += (h[4] + h[5]) + (h[6] + h[7]);
+  }
+  if (mine) {
+    const size_t off = static_cast<size_t>(row) * F + 4 * sub;
+    const float di = dis[row];
+    f32x4 v = ((acc0 + acc1) + *reinterpret_cast<const f32x4*>(H + off)) * di;
+    v *= di;
+    *reinterpret_cast<f32x4*>(Y + off) = v;
+  }
+}
+
+extern "C" int lab_v1s(const int* rowptr, const int* col, const float* dis, const float* H, float* Y,
+                       const int* sched, int n, void* stream) {
+  const int grid = (n + 31) / 32;
+  v1s_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(rowptr, col, dis, H, Y, sched, n);
+  return static_cast<int>(hipGetLastError());
+}
+
 extern "C" int lab_v1(const int* rowptr, const int* col, const float* dis, const float* H, float* Y, int n,
                       int remap, void* stream) {
   const int grid = (n + 31) / 32;
