@@ -280,7 +280,9 @@ def measure_arxiv(device, iters: int = 50, banded_control: bool = False) -> dict
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "frac_of_measured_copy_peak": round(achieved / HBM_MEASURED_GBS, 4),
             "algorithmic_bytes": b, "avg_launch_us": round(ms * 1e3, 2), "traffic": None}
-    pmc = os.path.join(ROOT, "profiles", "r01_spmm_arxiv_pmc.json")
+    pmc = os.path.join(ROOT, "profiles", "r02_spmm_arxiv_pmc.json")
+    if not os.path.exists(pmc):
+        pmc = os.path.join(ROOT, "profiles", "r01_spmm_arxiv_pmc.json")
     if os.path.exists(pmc):   # PMC passes cannot run inside the timed bench: committed rocprofv3 result
         with open(pmc) as fh:
             dv = json.load(fh)["derived"]
@@ -288,7 +290,7 @@ def measure_arxiv(device, iters: int = 50, banded_control: bool = False) -> dict
         # the bytes that actually crossed L2 <-> memory per launch, at the live launch time
         roof["traffic_GBs"] = round(dv["traffic_bytes_per_launch"] / (ms * 1e-3) / 1e9, 1)
         roof["traffic_frac_of_measured_copy_peak"] = round(roof["traffic_GBs"] / HBM_MEASURED_GBS, 3)
-        roof["traffic_source"] = ("profiles/r01_spmm_arxiv_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE per launch "
+        roof["traffic_source"] = (f"profiles/{os.path.basename(pmc)}: 2 x FETCH_SIZE + WRITE_SIZE per launch "
                                   "(separate rocprofv3 --pmc passes, gfx950 x2 fetch correction); L2 hit rate "
                                   f"{dv['l2_hit_rate']:.2f}")
 
@@ -369,6 +371,42 @@ def measure_gin(device, name: str = "hiv4096") -> dict:
     return {f"{name}_gin_aggregate_fwd_us": round(fwd_ms * 1e3, 1), f"{name}_gin_aggregate_bwd_us": round(bwd_ms * 1e3, 1),
             f"{name}_gin_aggregate_fwd_GBs": round(fb / (fwd_ms * 1e-3) / 1e9, 1),
             f"{name}_gin_aggregate_bwd_GBs": round(bb / (bwd_ms * 1e-3) / 1e9, 1)}
+
+
+def measure_transductive(device, name: str) -> dict:
+    """configs[3]: one GConv-Adapter on a Cora / PubMed-sized graph, x as [1, N, 32], rank 16, normalized
+    adjacency with the loops pre-added (`scripts/finetune_transductive_learning.py:111-114`) — the shapes the
+    NodeFormer backbone hands the adapter (`nodeformer.py:406-409`). These graphs are launch-bound (a few
+    hundred KB per array): the figures are device time per call (HIP events) and the SpMM alone; the
+    general path runs K2' + K3 as one gather-fused launch at this size."""
+    batch, cfg = ga.synth.make_workload(name)
+    n, d, r = batch.num_nodes, cfg["d"], cfg["r"]
+    ei = batch.edge_index.to(device)
+    plan = ga.get_plan(ei, n, True)
+    lib = ga._lib.load()
+    fp = int(lib.gconv_padded_rank(r))
+    h = torch.randn(n, fp, device=device)
+    y = torch.empty_like(h)
+    ws = torch.empty(max(int(lib.gconv_spmm_workspace_bytes(plan.fwd.ref(), fp)), 16), dtype=torch.uint8,
+                     device=device)
+    flags = ga._lib.SPMM_IN_PRESCALED | ga._lib.SPMM_OUT_PRESCALE
+    sp_ms = event_time_ms(lambda: ga.spmm(plan, h, flags=flags, out=y, workspace=ws), 50)
+    mod = build_adapters(dict(d=d, r=r, adapters=1), True, device)[0]
+    x = batch.x.reshape(1, n, d).to(device).requires_grad_(True)
+    gout = torch.randn(1, n, d, device=device)
+    out = mod(x, ei)
+    fwd_ms = event_time_ms(lambda: mod(x, ei), 50)
+    leaves = [x] + list(mod.parameters())
+
+    def bwd():
+        for q in leaves:
+            q.grad = None
+        out.backward(gout, retain_graph=True)
+    bwd_ms = event_time_ms(bwd, 50)
+    ga.PLAN_CACHE.clear()
+    return {f"{name}_spmm_us": round(sp_ms * 1e3, 1),
+            f"{name}_spmm_GBs": round(spmm_algorithmic_bytes(n, plan.fwd.nnz, fp) / (sp_ms * 1e-3) / 1e9, 1),
+            f"{name}_adapter_fwd_us": round(fwd_ms * 1e3, 1), f"{name}_adapter_bwd_us": round(bwd_ms * 1e3, 1)}
 
 
 class _FinetuneModel(torch.nn.Module):
@@ -665,6 +703,8 @@ def main() -> None:
             extra.update(ax["extra"])
             extra.update(measure_tile_kernels(device))
             extra.update(measure_gin(device))
+            for tname in ("cora", "pubmed"):
+                extra.update(measure_transductive(device, tname))
             other = "esol" if args.workload != "esol" else "hiv"
             o = run_workload(other, normalize, max(20, args.steps // 2), args.warmup, rank, world,
                              device, with_cpu=not args.no_cpu_baseline)

@@ -216,12 +216,18 @@ class GConvAdapter(nn.Module):
         if x.dim() == 2:
             out = self._forward_2d(x, edge_index, fuse_scalar)
         else:
+            # B = 1 (what the reference passes, nodeformer.py:391): a VIEW both ways — x[0] would put
+            # a SelectBackward node behind the adapter (a zero-filled [1, N, d] tensor plus a copy per
+            # backward pass)
             out = torch.stack([self._forward_2d(x[b], edge_index, fuse_scalar)
                                for b in range(x.size(0))]) if x.size(0) != 1 else \
-                self._forward_2d(x[0], edge_index, fuse_scalar).unsqueeze(0)
+                self._forward_2d(x.view(x.size(1), x.size(2)) if x.is_contiguous() else x[0],
+                                 edge_index, fuse_scalar).unsqueeze(0)
 
         if isinstance(self.normalization, nn.BatchNorm1d):
             if out.size(0) > 1:  # reference :99 (always skipped for [1, N, d])
+                if self.scalar is not None and isinstance(self.normalization, BatchNorm1d) and out.dim() == 2:
+                    return self.normalization(out, self.scalar)   # scalar folded into the affine pair
                 out = self.normalization(out)
         elif isinstance(self.normalization, nn.LayerNorm) and not TORCH_LAYER_NORM:
             ln = self.normalization   # LayerNorm and the scalar in one HIP pass (csrc/norm.hip)

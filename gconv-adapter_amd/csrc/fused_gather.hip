@@ -1,16 +1,16 @@
-// K2' + K3 and B3 + B4 of the general path as ONE launch each (gfx950).
+// K2' + K3 of the general path as ONE launch (gfx950).
 //
 // Replaces, together with spmm.hip / gemm.hip: the second `propagate` of the adapter
 // (conv_up of /root/reference/src/finetune/gconv_adapter.py:92, reassociated to rank r), the
-// residual / bias / scalar tail (:94-95,105-106) and, in the backward, the transposed
-// propagation that feeds dX / dW_down.
+// residual / bias / scalar tail (:94-95,105-106).
 //
 // Why fuse: P = S H2' is needed row by row by the up-projection (a per-row dependency, unlike
-// K2 -> K2', which needs ALL rows of H2'). As separate launches the gather kernel is bound by
-// the fabric's random-row rate (25 us at S-arxiv) while HBM idles, then the projection streams
-// X / out (37 us) while the gather path idles. Fused, a workgroup requests its X tile, gathers
-// the P rows of the same nodes meanwhile, parks them in LDS (and in HBM for the backward) and
-// multiplies. Rows longer than GCONV_LONG_ROW edges keep their segment path (a small launch of
+// K2 -> K2', which needs ALL rows of H2'). A workgroup requests its X tile, gathers the P rows
+// of the same nodes meanwhile, parks them in LDS (and in HBM for the backward) and multiplies:
+// one launch and one kernel boundary less, which is what a Cora / PubMed-sized graph is made of
+// (forward 21 -> 15 us). At S-arxiv scale the separate launches stay faster (124 against 130 us:
+// a workgroup waits at its barrier for the wave with the longest rows) — see
+// fused_gather_enabled(). Rows longer than GCONV_LONG_ROW edges keep their segment path (a small launch of
 // the SpMM's segment blocks in front); every other row is summed by row_gather_sum — the same
 // code, hence the same bits, as the stand-alone SpMM.
 #include <cstdlib>
@@ -182,7 +182,5 @@ gconv_status_t launch_up_gather(const UpGatherArgs& a, hipStream_t stream) {
 #undef GCONV_UPG_CASE
   return GCONV_E_UNSUPPORTED;
 }
-
-gconv_status_t launch_bwd_gather(const BwdGatherArgs&, hipStream_t) { return GCONV_E_UNSUPPORTED; }
 
 }  // namespace gconv

@@ -350,9 +350,12 @@ BwdMainGeom bwd_main_geom(int n, int d) {
   g.nchunks = ceil_div(d, 64);
   g.nslots = chunk_slots(g.nchunks, 8);
   const int nblk = ceil_div(n, 16);
-  // >= 4 node blocks per wave slot amortise the partial write-out; <= 1 workgroup per CU
-  int grid = ceil_div(nblk, 4 * g.nslots);
-  if (grid > kNumCU) grid = kNumCU;   // one 8-wave workgroup per CU (measured best)
+  // <= 1 workgroup per CU (one 8-wave workgroup per CU measured best at S-arxiv); below that, one
+  // node block per wave slot: a Cora / PubMed-sized graph is latency-bound and wants every CU it
+  // can fill (PubMed: 39 workgroups x 4 blocks per wave 16.7 us -> 155 workgroups), the partial
+  // write-out it multiplies is a few KB per workgroup
+  int grid = ceil_div(nblk, g.nslots);
+  if (grid > kNumCU) grid = kNumCU;
   if (grid < 1) grid = 1;
   g.grid = grid;
   g.nparts = grid;

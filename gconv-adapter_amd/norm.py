@@ -105,13 +105,23 @@ class BatchNorm1d(nn.BatchNorm1d):
         return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] % 4 == 0
                 and x.shape[1] <= 1024 and x.shape[0] >= 1)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``scale`` (a one-element tensor, the adapter's learnable scalar): returns ``scale * BN(x)`` in the
+        same three launches — ``s (gamma xhat + beta) = (s gamma) xhat + (s beta)``, so the kernels run
+        with the scaled affine pair and autograd's chain rule through the two ``[d]``-sized products
+        yields d gamma, d beta and d scale; no extra pass over ``[N, d]`` in either direction (the
+        reference multiplies the whole output, ``gconv_adapter.py:105-106``)."""
+        gamma, beta = self.weight, self.bias
+        if scale is not None:
+            if self.fused_relu or gamma is None or beta is None or not self._native(x):
+                return self.forward(x) * scale
+            gamma, beta = gamma * scale, beta * scale
         if not self._native(x):
             y = super().forward(x)
             return torch.relu(y) if self.fused_relu else y
         use_batch_stats = self.training or self.running_mean is None
         if not use_batch_stats:
-            return batch_norm_eval(x, self.running_mean, self.running_var, self.weight, self.bias, self.eps,
+            return batch_norm_eval(x, self.running_mean, self.running_var, gamma, beta, self.eps,
                                    self.fused_relu)
         factor = 0.0
         if self.training and self.track_running_stats and self.num_batches_tracked is not None:
@@ -119,4 +129,4 @@ class BatchNorm1d(nn.BatchNorm1d):
             factor = (1.0 / float(self.num_batches_tracked)) if self.momentum is None else self.momentum
         rm = self.running_mean if self.training and self.track_running_stats else None
         rv = self.running_var if self.training and self.track_running_stats else None
-        return BatchNormFunction.apply(x, self.weight, self.bias, rm, rv, factor, self.eps, self.fused_relu)
+        return BatchNormFunction.apply(x, gamma, beta, rm, rv, factor, self.eps, self.fused_relu)

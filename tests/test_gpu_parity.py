@@ -987,3 +987,36 @@ def test_fused_gather_launches_equal_separate_launches(dev, kind, d, r, normaliz
         assert torch.equal(a, b)
     if kind == "hub":
         assert ga.get_plan(eid, n, normalize).fwd.n_long > 0
+
+
+def test_batch_norm_tail_with_folded_scalar(dev):
+    """`normalization='batch_norm'` + `learnable_scalar`: the scalar rides in the affine pair of the
+    BatchNorm kernels (s (gamma xhat + beta) = (s gamma) xhat + (s beta)) — same out and gradients
+    (incl. d scalar) as BatchNorm followed by `* scalar` in fp64, training and evaluation mode."""
+    torch.manual_seed(3)
+    n, d = 431, 300
+    x = torch.randn(n, d) * 2 + 0.5
+    g = torch.randn(n, d)
+    m = ga.BatchNorm1d(d).to(dev)
+    ref = torch.nn.BatchNorm1d(d).double()
+    with torch.no_grad():
+        m.weight.normal_(1, 0.2); m.bias.normal_(0, 0.2)
+        ref.weight.copy_(m.weight.cpu()); ref.bias.copy_(m.bias.cpu())
+    s = torch.tensor([0.6], device=dev, requires_grad=True)
+    s64 = torch.tensor([0.6], dtype=torch.float64, requires_grad=True)
+    for training in (True, False):
+        m.train(training); ref.train(training)
+        for t in (m.weight, m.bias, s, ref.weight, ref.bias, s64):
+            t.grad = None
+        xd = x.to(dev).requires_grad_(True)
+        x64 = x.double().requires_grad_(True)
+        out = m(xd, s)
+        out.backward(g.to(dev))
+        want = ref(x64) * s64
+        want.backward(g.double())
+        assert_close(out.detach().cpu().double(), want.detach(), "out")
+        assert_close(xd.grad.cpu().double(), x64.grad, "dx")
+        for got, w, name in ((m.weight.grad, ref.weight.grad, "dgamma"), (m.bias.grad, ref.bias.grad, "dbeta"),
+                             (s.grad, s64.grad, "dscalar")):
+            assert_close(got.cpu().double(), w, name, atol=grad_atol(w))
+    assert torch.allclose(m.running_mean.cpu().double(), ref.running_mean, atol=1e-6)
