@@ -3,8 +3,9 @@
 Drop-in for the ``torch.optim.Adam(param_groups, lr=..., weight_decay=...)`` of the reference's
 fine-tuning loops (``/root/reference/scripts/finetune_inductive_learning.py:375-379``,
 ``scripts/finetune_transductive_learning.py:205``): same constructor arguments (per-group
-``lr`` / ``weight_decay`` / ``betas`` / ``eps``), same update rule, ``state_dict()`` in the
-same per-parameter format — but the trainable parameters of a group live in ONE flat buffer
+``lr`` / ``weight_decay`` / ``betas`` / ``eps``), same update rule (the step count of the bias
+correction is kept PER PARAMETER, as torch does: a parameter without a gradient is skipped and its
+count does not advance), ``state_dict()`` in the same per-parameter format — but the trainable parameters of a group live in ONE flat buffer
 (``p.data`` of every parameter becomes a view of it; ``Parameter`` objects, names and
 ``state_dict`` keys of the model are untouched) and a step is ONE multi-tensor copy of the
 gradients plus ONE ``gconv_adam_step_f32`` launch per group instead of ~10 multi-tensor
@@ -140,6 +141,11 @@ class FusedAdam(torch.optim.Optimizer):
                     mine["exp_avg"].copy_(loaded["exp_avg"])
                     mine["exp_avg_sq"].copy_(loaded["exp_avg_sq"])
                     mine["step"] = torch.as_tensor(float(loaded["step"]))
+                    self.state[p] = mine
+                elif not loaded:   # torch's Adam keeps no state for a parameter that never had a gradient:
+                    mine["exp_avg"].zero_()          # it starts from zero moments at step 0
+                    mine["exp_avg_sq"].zero_()
+                    mine["step"] = torch.zeros((), dtype=torch.float32)
                     self.state[p] = mine
             if fl.get("params"):
                 fl["steps"] = [int(self.state[p]["step"]) for p in fl["params"]]

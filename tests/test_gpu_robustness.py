@@ -218,3 +218,25 @@ def test_fused_adam_counts_steps_per_parameter(dev):
         assert torch.allclose(pf.detach().cpu().double(), pr.detach(), rtol=1e-5, atol=1e-7)
     sd_ref, sd_f = opt_ref.state_dict()["state"], opt_f.state_dict()["state"]
     assert [int(sd_f[i]["step"]) for i in range(4)] == [int(sd_ref[i]["step"]) for i in range(4)] == [4, 3, 5, 4]
+    # a torch state dict in which one parameter has no state yet (it never had a gradient there)
+    ps_t = [torch.nn.Parameter(b.to(dev).clone()) for b in base]
+    opt_t = torch.optim.Adam(ps_t, lr=1e-2)
+    for i, p in enumerate(ps_t):
+        p.grad = None if i == 1 else grads[0][i].to(dev)
+    opt_t.step()
+    assert 1 not in opt_t.state_dict()["state"]
+    ps_g = [torch.nn.Parameter(p.detach().clone()) for p in ps_t]
+    opt_g = ga.FusedAdam(ps_g, lr=1e-2)
+    for i, p in enumerate(ps_g):                       # dirty the flat moments first
+        p.grad = grads[1][i].to(dev)
+    opt_g.step()
+    with torch.no_grad():
+        for pg, pt in zip(ps_g, ps_t):
+            pg.copy_(pt)
+    opt_g.load_state_dict(copy.deepcopy(opt_t.state_dict()))
+    for ps, opt in ((ps_t, opt_t), (ps_g, opt_g)):
+        for i, p in enumerate(ps):
+            p.grad = grads[2][i].to(dev)
+        opt.step()
+    for pt, pg in zip(ps_t, ps_g):
+        assert torch.allclose(pt.detach(), pg.detach(), rtol=1e-6, atol=1e-7)
