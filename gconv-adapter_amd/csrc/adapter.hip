@@ -118,7 +118,7 @@ static gconv_status_t check_common(const gconv_csr_t* g, const gconv_adapter_par
   if (p->act < GCONV_ACT_NONE || p->act > GCONV_ACT_SILU) return GCONV_E_INVALID_ARG;
   if (p->hidden % 4 != 0 || p->hidden > 1024 || padded_rank(p->rank) == 0)
     return GCONV_E_UNSUPPORTED;
-  if (rowsA_lds_bytes(p->hidden, padded_rank(p->rank)) > 64 * 1024) return GCONV_E_UNSUPPORTED;
+  if (rowsA_lds_bytes(p->hidden, padded_rank(p->rank)) > kRowsAMaxLds) return GCONV_E_UNSUPPORTED;
   if (g->n_long > 0 && (!g->long_rows || !g->long_seg_base || !g->seg_long))
     return GCONV_E_INVALID_ARG;
   return GCONV_OK;

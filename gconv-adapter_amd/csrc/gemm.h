@@ -24,6 +24,7 @@ struct RowsAArgs {
 };
 
 size_t rowsA_lds_bytes(int d, int fp);
+constexpr size_t kRowsAMaxLds = 160 * 1024;   // the whole LDS of a CU (hidden x padded rank <= 40960 floats)
 int rowsA_grid(int n);
 gconv_status_t launch_rowsA(const RowsAArgs& a, hipStream_t stream);
 

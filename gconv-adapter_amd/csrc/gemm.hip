@@ -202,7 +202,11 @@ static gconv_status_t launch_rowsA_ncb(const RowsAArgs& a, int nq, int grid, siz
   switch (nq) {
 #define GCONV_ROWSA_CASE(NQ_)                                                                      \
     case NQ_:                                                                                      \
-      if (depth_env >= 2 && NQ_ <= 12) gemm_rowsA_kernel<NCB, NQ_, 2><<<grid, 256, lds, stream>>>(a); \
+      if (lds > 48 * 1024)   /* wide rows x large rank: the fragment table needs opting in */      \
+        GCONV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rowsA_kernel<NCB, NQ_, 1>), \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds))); \
+      if (depth_env >= 2 && NQ_ <= 12 && lds <= 48 * 1024)                                         \
+        gemm_rowsA_kernel<NCB, NQ_, 2><<<grid, 256, lds, stream>>>(a);                             \
       else gemm_rowsA_kernel<NCB, NQ_, 1><<<grid, 256, lds, stream>>>(a);                          \
       break;
     GCONV_ROWSA_CASE(2) GCONV_ROWSA_CASE(4) GCONV_ROWSA_CASE(8) GCONV_ROWSA_CASE(12)
@@ -219,8 +223,9 @@ gconv_status_t launch_rowsA(const RowsAArgs& a, hipStream_t stream) {
   if (a.n == 0) return GCONV_OK;
   const int nq = rowsA_nq(a.d);
   const size_t lds = rowsA_lds_bytes(a.d, a.fp);
-  if (nq == 0 || lds > 64 * 1024) return GCONV_E_UNSUPPORTED;
-  const int grid = rowsA_grid(a.n);
+  if (nq == 0 || lds > kRowsAMaxLds) return GCONV_E_UNSUPPORTED;
+  int grid = rowsA_grid(a.n);
+  if (lds > 80 * 1024 && grid > kNumCU) grid = kNumCU;   // one workgroup per CU fits
   switch (a.fp >= 16 ? a.fp / 16 : 1) {
     case 1: return launch_rowsA_ncb<1>(a, nq, grid, lds, stream);
     case 2: return launch_rowsA_ncb<2>(a, nq, grid, lds, stream);

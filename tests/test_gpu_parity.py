@@ -1020,3 +1020,69 @@ def test_batch_norm_tail_with_folded_scalar(dev):
                              (s.grad, s64.grad, "dscalar")):
             assert_close(got.cpu().double(), w, name, atol=grad_atol(w))
     assert torch.allclose(m.running_mean.cpu().double(), ref.running_mean, atol=1e-6)
+
+
+@pytest.mark.parametrize("d,r,act", [(1024, 16, "relu"), (64, 64, "silu"), (128, 33, "none"), (512, 64, "relu")])
+def test_adapter_general_path_extreme_shapes(dev, d, r, act):
+    """Largest hidden size, largest rank, a rank that pads to 64 — on a connected random graph (no
+    component tiles, so the general path: K1, K2, K2'(+K3 fused), B1..B5)."""
+    n = 700
+    ei = _random_graph(n, 5000, 21, symmetric=True)
+    x = torch.randn(n, d, generator=torch.Generator().manual_seed(3))
+    batch = ga.synth.GraphBatch(x=x, edge_index=ei, graph_ptr=torch.tensor([0, n]), num_graphs=1)
+    flags = oracle.AdapterFlags(non_linearity=act, learnable_scalar=True, normalize=True)
+    _check_workload(dev, batch, d, r, flags)
+    assert ga.get_plan(ei.to(dev), n, True).n_tiles == 0
+    if d == 512:   # beyond the LDS of a CU (hidden x padded rank > 40960 floats): a RuntimeError, not a fault
+        with pytest.raises(RuntimeError, match="unsupported shape"):
+            ga.GConvAdapter(1024, 64).to(dev)(torch.randn(n, 1024, device=dev), ei.to(dev))
+
+
+def test_adapter_hub_with_ten_thousand_edges(dev):
+    """One row with > 10^4 edges (S-arxiv's node 0 has 10,875): ~85 long-row segments summed by
+    different waves and completed in-kernel, through the whole adapter forward and backward."""
+    n, d, r = 12000, 64, 8
+    g = torch.Generator().manual_seed(17)
+    spokes = torch.stack([torch.arange(1, 10501), torch.zeros(10500, dtype=torch.long)])
+    rnd = torch.stack([torch.randint(n, (20000,), generator=g), torch.randint(n, (20000,), generator=g)])
+    pairs = torch.cat([spokes, rnd], dim=1)
+    ei = torch.cat([pairs, pairs.flip(0)], dim=1)
+    x = torch.randn(n, d, generator=g)
+    batch = ga.synth.GraphBatch(x=x, edge_index=ei, graph_ptr=torch.tensor([0, n]), num_graphs=1)
+    for normalize in (True, False):
+        flags = oracle.AdapterFlags(learnable_scalar=True, normalize=normalize)
+        _check_workload(dev, batch, d, r, flags)
+    plan = ga.get_plan(ei.to(dev), n, True)
+    assert plan.fwd.max_degree > 10000 and plan.fwd.n_seg >= 80
+
+
+def test_adapter_batched_3d_and_non_contiguous_inputs(dev):
+    """[B, N, d] with B > 1 (node_dim = -2: every batch entry is propagated over the same graph,
+    SURVEY 8c item 6), a non-contiguous x (a transposed view) and a non-contiguous edge_index."""
+    batch, cfg = ga.synth.make_workload("cora")
+    n, d, r = batch.num_nodes, cfg["d"], cfg["r"]
+    flags = oracle.AdapterFlags(learnable_scalar=True, normalize=True)
+    params = {k: v.float().double() for k, v in oracle.init_params(d, r, flags, seed=4).items()}
+    mod = build_module(ga, d, r, flags, params, dev)
+    gen = torch.Generator().manual_seed(8)
+    x3 = torch.randn(3, n, d, generator=gen)
+    g3 = torch.randn(3, n, d, generator=gen)
+    want_out, want = oracle.adapter_forward_backward(x3.double(), batch.edge_index, params, flags, g3.double())
+    xd = x3.to(dev).requires_grad_(True)
+    mod.zero_grad(set_to_none=True)
+    out = mod(xd, batch.edge_index.to(dev))
+    out.backward(g3.to(dev))
+    assert_close(out.detach().cpu().double(), want_out, "out [3, N, d]")
+    assert_close(xd.grad.cpu().double(), want["x"], "dx [3, N, d]")
+    for k, p in mod.named_parameters():
+        assert_close(p.grad.cpu().double(), want[k], f"grad {k}", atol=grad_atol(want[k]))
+    # non-contiguous x / edge_index: same numbers as their contiguous copies
+    xt = torch.randn(d, n, generator=gen).to(dev).t()                 # [n, d] view with strides (1, n)
+    ei_nc = torch.stack([batch.edge_index[0], batch.edge_index[1]], dim=1).to(dev).t()   # [2, E] view of [E, 2]
+    assert not xt.is_contiguous() and not ei_nc.is_contiguous()
+    with torch.no_grad():
+        a = mod(xt, ei_nc)
+        b = mod(xt.contiguous(), batch.edge_index.to(dev))
+    assert torch.equal(a, b)
+    with pytest.raises(RuntimeError, match="int64"):
+        mod(xt.contiguous(), batch.edge_index.to(dev).int())
