@@ -240,3 +240,34 @@ def test_fused_adam_counts_steps_per_parameter(dev):
         opt.step()
     for pt, pg in zip(ps_t, ps_g):
         assert torch.allclose(pt.detach(), pg.detach(), rtol=1e-6, atol=1e-7)
+
+
+def test_distributed_data_parallel_wrapper_gets_its_hooks(dev):
+    """DistributedDataParallel installs post hooks on the parameters' grad accumulators. Direct
+    deposit would bypass them — DDP then raises 'Expected to have finished reduction in the prior
+    iteration' on the second forward. The binding sees the hooks and takes standard accumulation:
+    three iterations under DDP (one rank) run and give the gradients of the bare module."""
+    import os
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    batch, flags, params, mod, g = _setup(dev, seed=11)
+    ei = batch.edge_index.to(dev)
+    x = batch.x.to(dev)
+    mod(x, ei).backward(g.to(dev))
+    want = {k: p.grad.clone() for k, p in mod.named_parameters()}
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        ddp = DDP(mod, device_ids=[dev.index])
+        for _ in range(3):
+            ddp.zero_grad(set_to_none=True)
+            ddp(x, ei).backward(g.to(dev))
+            torch.cuda.synchronize()
+            for k, p in mod.named_parameters():
+                assert torch.allclose(p.grad, want[k], rtol=1e-6, atol=1e-7), k
+    finally:
+        if created:
+            dist.destroy_process_group()
