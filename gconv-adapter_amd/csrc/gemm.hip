@@ -667,30 +667,48 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& a, int block, 
 }
 
 // d(scalar) = sum_i (G_i W_up) . P_i  +  b_up . colsum(G)  +  [skip] sum(G . X)
+// ONE extra block of the finalize launch (general path with a learnable scalar; the fused tile
+// path hands over complete per-workgroup partials instead). It sums the colsum(G) partials
+// itself, in its own fixed order, rather than waiting for the blocks that reduce them: no second
+// launch behind the first (round 1 had one: a launch and a kernel boundary per backward pass).
 __device__ __forceinline__ void finalize_scalar_body(const FinalizeArgs& a, float* red) {
   float acc = 0.f;
   for (int i = threadIdx.x; i < a.n_ds1; i += 256) acc += a.part_ds1[i];
   if (a.skip)
     for (int i = threadIdx.x; i < a.n_dsx; i += 256) acc += a.part_dsx[i];
   if (a.b_up)
-    for (int j = threadIdx.x; j < a.d; j += 256) acc += a.b_up[j] * a.cs_tmp[j];
+    for (int j = threadIdx.x; j < a.d; j += 256) {
+      float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+      int p = 0;
+      for (; p + 3 < a.nparts; p += 4) {
+        c0 += a.part_cs[static_cast<size_t>(p) * a.d + j];
+        c1 += a.part_cs[static_cast<size_t>(p + 1) * a.d + j];
+        c2 += a.part_cs[static_cast<size_t>(p + 2) * a.d + j];
+        c3 += a.part_cs[static_cast<size_t>(p + 3) * a.d + j];
+      }
+      for (; p < a.nparts; ++p) c0 += a.part_cs[static_cast<size_t>(p) * a.d + j];
+      acc += a.b_up[j] * ((c0 + c1) + (c2 + c3));
+    }
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) a.g_s[0] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a) {
+// blocks of one reduction: ceil(total / kFinE) element blocks (+ 1 scalar block)
+static int finalize_main_blocks(const FinalizeArgs& f) {
+  return ceil_div(2 * f.r * f.d + f.d + f.r + (f.ds_complete ? 1 : 0), kFinE);
+}
+static bool finalize_wants_scalar_block(const FinalizeArgs& f) { return f.g_s && !f.ds_complete; }
+
+__global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a, int main_blocks) {
   __shared__ float red[kFinS][kFinE];
-  finalize_body(a, blockIdx.x, red);
+  if (static_cast<int>(blockIdx.x) < main_blocks) finalize_body(a, blockIdx.x, red);   // uniform
+  else finalize_scalar_body(a, &red[0][0]);
 }
 
-__global__ __launch_bounds__(256) void finalize_scalar_kernel(FinalizeArgs a) {
-  __shared__ float red[4];
-  finalize_scalar_body(a, red);
-}
-
-// Several pending reductions in one launch: blocks [start[j], start[j + 1]) belong to entry j.
+// Several pending reductions in one launch: blocks [start[j], start[j + 1]) belong to entry j,
+// the last of them being its scalar block when it has one.
 struct FinalizeBatch {
   FinalizeArgs a[GCONV_FINALIZE_BATCH];
   int start[GCONV_FINALIZE_BATCH + 1];
@@ -701,13 +719,11 @@ __global__ __launch_bounds__(256) void finalize_batched_kernel(FinalizeBatch b) 
   __shared__ float red[kFinS][kFinE];
   int j = 0;
   while (j + 1 < b.count && static_cast<int>(blockIdx.x) >= b.start[j + 1]) ++j;   // uniform
-  finalize_body(b.a[j], blockIdx.x - b.start[j], red);
-}
-
-__global__ __launch_bounds__(256) void finalize_scalar_batched_kernel(FinalizeBatch b) {
-  __shared__ float red[4];
-  const FinalizeArgs& a = b.a[blockIdx.x];
-  if (a.g_s && !a.ds_complete) finalize_scalar_body(a, red);   // uniform per block
+  const FinalizeArgs& a = b.a[j];
+  const int local = blockIdx.x - b.start[j];
+  const int main_blocks = ceil_div(2 * a.r * a.d + a.d + a.r + (a.ds_complete ? 1 : 0), kFinE);
+  if (local < main_blocks) finalize_body(a, local, red);
+  else finalize_scalar_body(a, &red[0][0]);
 }
 
 // Stage 1 for tall partial arrays: [rows, width] -> [kReduceBlocks, width], fixed order.
@@ -746,34 +762,23 @@ gconv_status_t launch_finalize_batched(const FinalizeArgs* a, int count, hipStre
   for (int base = 0; base < count; base += GCONV_FINALIZE_BATCH) {
     FinalizeBatch b;
     b.count = count - base < GCONV_FINALIZE_BATCH ? count - base : GCONV_FINALIZE_BATCH;
-    bool need_scalar = false;
     b.start[0] = 0;
     for (int j = 0; j < b.count; ++j) {
       b.a[j] = a[base + j];
       const FinalizeArgs& f = b.a[j];
-      const int total = 2 * f.r * f.d + f.d + f.r + (f.ds_complete ? 1 : 0);
-      b.start[j + 1] = b.start[j] + ceil_div(total, kFinE);
-      need_scalar = need_scalar || (f.g_s && !f.ds_complete);
+      b.start[j + 1] = b.start[j] + finalize_main_blocks(f) + (finalize_wants_scalar_block(f) ? 1 : 0);
     }
     for (int j = b.count; j < GCONV_FINALIZE_BATCH; ++j) b.start[j + 1] = b.start[b.count];
     finalize_batched_kernel<<<b.start[b.count], 256, 0, stream>>>(b);
     GCONV_LAUNCH_CHECK();
-    if (need_scalar) {
-      finalize_scalar_batched_kernel<<<b.count, 256, 0, stream>>>(b);
-      GCONV_LAUNCH_CHECK();
-    }
   }
   return GCONV_OK;
 }
 
 gconv_status_t launch_finalize(const FinalizeArgs& a, hipStream_t stream) {
-  const int total = 2 * a.r * a.d + a.d + a.r + (a.ds_complete ? 1 : 0);
-  finalize_kernel<<<ceil_div(total, kFinE), 256, 0, stream>>>(a);
+  const int main_blocks = finalize_main_blocks(a);
+  finalize_kernel<<<main_blocks + (finalize_wants_scalar_block(a) ? 1 : 0), 256, 0, stream>>>(a, main_blocks);
   GCONV_LAUNCH_CHECK();
-  if (a.g_s && !a.ds_complete) {
-    finalize_scalar_kernel<<<1, 256, 0, stream>>>(a);
-    GCONV_LAUNCH_CHECK();
-  }
   return GCONV_OK;
 }
 
