@@ -315,16 +315,27 @@ static gconv_status_t bwd_stages(const gconv_graph_t* gr, const gconv_adapter_pa
     SpmmArgs b3{};
     b3.dis = dis; b3.H = dh1; b3.Y = dp; b3.rank = r; b3.seg_partial = ws.seg;
     b3.row_lo = lo; b3.row_hi = hi;
-    st = launch_spmm(graph_t, b3, fp, EPI_STORE, stream);
-    if (st != GCONV_OK) return st;
-
     BwdMainArgs b4{};
     b4.G = grad_out; b4.X = x; b4.T = dp + shift; b4.P = saved_p + shift; b4.W_down = p->w_down;
     b4.scalar = p->scalar; b4.dX = grad_x;
     b4.part_wd = ws.part_wd; b4.part_wu = ws.part_wu; b4.part_cs = ws.part_cs;
     b4.part_dsx = ws.part_dsx;
     b4.n = n; b4.d = d; b4.r = r; b4.fp = fp; b4.skip = p->skip;
-    st = launch_bwd_main(b4, stream);
+    if (lo == 0 && hi == graph_t->num_nodes && fused_gather_enabled(graph_t->num_nodes)) {
+      // B3 + B4 in one launch (fused_gather.hip); only the long rows' segments run in front
+      if (graph_t->n_seg > 0) {
+        b3.seg_only = 1;
+        st = launch_spmm(graph_t, b3, fp, EPI_STORE, stream);
+        if (st != GCONV_OK) return st;
+      }
+      BwdGatherArgs f{};
+      f.rowptr = graph_t->rowptr; f.col = graph_t->col; f.dis = dis; f.H = dh1; f.T = dp; f.main = b4;
+      st = launch_bwd_gather(f, stream);
+    } else {
+      st = launch_spmm(graph_t, b3, fp, EPI_STORE, stream);
+      if (st != GCONV_OK) return st;
+      st = launch_bwd_main(b4, stream);
+    }
     if (st != GCONV_OK) return st;
   }
 

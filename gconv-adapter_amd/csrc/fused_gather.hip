@@ -1,8 +1,9 @@
-// K2' + K3 of the general path as ONE launch (gfx950).
+// K2' + K3 and B3 + B4 of the general path as ONE launch each (gfx950).
 //
 // Replaces, together with spmm.hip / gemm.hip: the second `propagate` of the adapter
 // (conv_up of /root/reference/src/finetune/gconv_adapter.py:92, reassociated to rank r), the
-// residual / bias / scalar tail (:94-95,105-106).
+// residual / bias / scalar tail (:94-95,105-106) and, in the backward, the transposed
+// propagation that feeds dX / dW_down.
 //
 // Why fuse: P = S H2' is needed row by row by the up-projection (a per-row dependency, unlike
 // K2 -> K2', which needs ALL rows of H2'). A workgroup requests its X tile, gathers the P rows
@@ -42,7 +43,7 @@ static int env_int(const char* name, int dflt) {
 template <int FP, bool NORM, bool STORE>
 __device__ __forceinline__ void gather_block_rows(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                   const float* __restrict__ dis, const float* __restrict__ H,
-                                                  float* __restrict__ store, float* tile, int sb0, int SB, int n,
+                                                  float* store, float* tile, int sb0, int SB, int n,
                                                   int w, int W, int lane) {
   constexpr int LPR = FP / 4, RPW = kWave / LPR, PST = FP + 4;
   const int sub = lane % LPR, grp = lane / LPR;
@@ -180,6 +181,161 @@ gconv_status_t launch_up_gather(const UpGatherArgs& a, hipStream_t stream) {
     GCONV_UPG_CASE(4) GCONV_UPG_CASE(8) GCONV_UPG_CASE(16) GCONV_UPG_CASE(32) GCONV_UPG_CASE(64)
   }
 #undef GCONV_UPG_CASE
+  return GCONV_E_UNSUPPORTED;
+}
+
+// ===========================================================================
+// B3 + B4
+// ===========================================================================
+template <int FP, bool NORM, bool NEED_DX, int TB>
+__global__ __launch_bounds__(TB) void bwd_gather_kernel(BwdGatherArgs g, int nchunks, int nslots) {
+  extern __shared__ float smem[];   // [16 nslots][FP + 4] T tile | B4's slot reduction buffer
+  constexpr int KS = FP / 4;
+  constexpr int NCB = FP >= 16 ? FP / 16 : 1;
+  constexpr int PST = FP + 4;
+  const BwdMainArgs& a = g.main;
+  const int lane = threadIdx.x & 63, w = wave_id();
+  const int J = w % nchunks, slot = w / nchunks;
+  const int jj = lane & 15, t = lane >> 4;
+  const int colbase = 64 * J + 4 * jj;
+  const bool colvalid = colbase < a.d;
+  const float sval = a.scalar ? a.scalar[0] : 1.f;
+  const int W = nchunks * nslots, SB = 16 * nslots;
+  float* ttile = smem;
+  float* red = smem + SB * PST;
+
+  // B fragments for dX: wd[s][c] = W_down[rank_k(s, t)][colbase + c]
+  float wd[NEED_DX ? KS : 1][4];
+  if (NEED_DX) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k = rank_k<FP>(s, t);
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (colvalid && k < a.r) v = ldg4(a.W_down + static_cast<size_t>(k) * a.d + colbase);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) wd[s][c] = v[c];
+    }
+  }
+  f32x4 awd[NCB][4], awu[NCB][4];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) awd[cb][c] = awu[cb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dsx = 0.f;
+
+  const int nsb = ceil_div(a.n, SB);
+  for (int sb = blockIdx.x; sb < nsb; sb += gridDim.x) {
+    const int i0 = sb * SB + slot * 16;
+    // this wave's G / X tiles and P fragments first: they fly while the T rows are gathered
+    f32x4 gv[4], xv[4];
+    load_tile_L(a.G, i0, t, a.n, a.d, colbase, colvalid, gv);
+    load_tile_L(a.X, i0, t, a.n, a.d, colbase, colvalid, xv);
+    float ap[4][NCB];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int row = i0 + 4 * t + m;
+      const size_t rb = static_cast<size_t>(min(row, a.n - 1)) * FP;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const int rc = 16 * cb + jj;
+        const float vp = a.P[rb + min(rc, FP - 1)];
+        ap[m][cb] = (row < a.n && rc < FP) ? vp : 0.f;
+      }
+    }
+    gather_block_rows<FP, NORM, false>(g.rowptr, g.col, g.dis, g.H, const_cast<float*>(g.T), ttile, sb * SB, SB,
+                                       a.n, w, W, lane);
+    __syncthreads();
+    float at[4][NCB];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int row = i0 + 4 * t + m;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const int rc = 16 * cb + jj;
+        const float vt = ttile[(slot * 16 + 4 * t + m) * PST + min(rc, FP - 1)];
+        at[m][cb] = (row < a.n && rc < FP) ? vt : 0.f;   // rows past n were never written
+      }
+    }
+    float ta[KS];
+    if constexpr (NEED_DX) tile_rank_frag<FP>(ttile, slot * 16 + jj, t, ta);
+
+    // contraction over the 16 nodes: k-step m covers nodes i0 + 4 t + m  (== bwd_main_kernel)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          awd[cb][c] = mfma16(at[m][cb], xv[m][c], awd[cb][c]);
+          awu[cb][c] = mfma16(ap[m][cb], gv[m][c], awu[cb][c]);
+        }
+      }
+      cs += gv[m];
+      if (a.skip) dsx = dot4_acc(gv[m], xv[m], dsx);
+    }
+    if (NEED_DX) {
+      f32x4 acc[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = mfma16(ta[s], wd[s][c], acc[c]);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int row = i0 + 4 * t + m;
+        if (colvalid && row < a.n) {
+          f32x4 o;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) o[c] = acc[c][m] + (a.skip ? sval * gv[m][c] : 0.f);
+          stg4(a.dX + static_cast<size_t>(row) * a.d + colbase, o);
+        }
+      }
+    }
+    __syncthreads();   // the T tile is rewritten by the next super-block
+  }
+  bwd_main_tail<FP>(a, awd, awu, cs, dsx, red, nchunks, nslots, J, slot, jj, t, lane, w, colbase, colvalid);
+}
+
+template <int FP, bool NORM>
+static gconv_status_t launch_bwd_gather_t(const BwdGatherArgs& a, const BwdMainGeom& g, hipStream_t stream) {
+  const int threads = 64 * g.nchunks * g.nslots;
+  const size_t lds = static_cast<size_t>(16 * g.nslots) * (FP + 4) * sizeof(float) +
+                     bwd_main_lds_bytes(g.nchunks, g.nslots, FP);
+  if (lds > 160 * 1024) return GCONV_E_UNSUPPORTED;
+#define GCONV_BWG_LAUNCH(DX, TB_)                                                                      \
+  do {                                                                                                 \
+    if (lds > 48 * 1024)                                                                               \
+      GCONV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_gather_kernel<FP, NORM, DX, TB_>), \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds))); \
+    bwd_gather_kernel<FP, NORM, DX, TB_><<<g.grid, threads, lds, stream>>>(a, g.nchunks, g.nslots);    \
+  } while (0)
+  if (a.main.dX) {
+    if (threads <= 256) GCONV_BWG_LAUNCH(true, 256);
+    else if (threads <= 512) GCONV_BWG_LAUNCH(true, 512);
+    else GCONV_BWG_LAUNCH(true, 1024);
+  } else {
+    if (threads <= 256) GCONV_BWG_LAUNCH(false, 256);
+    else if (threads <= 512) GCONV_BWG_LAUNCH(false, 512);
+    else GCONV_BWG_LAUNCH(false, 1024);
+  }
+#undef GCONV_BWG_LAUNCH
+  GCONV_LAUNCH_CHECK();
+  return GCONV_OK;
+}
+
+gconv_status_t launch_bwd_gather(const BwdGatherArgs& a, hipStream_t stream) {
+  const BwdMainGeom g = bwd_main_geom(a.main.n, a.main.d);
+  if (g.nchunks > 16) return GCONV_E_UNSUPPORTED;
+#define GCONV_BWG_CASE(FP_)                                                              \
+  case FP_:                                                                              \
+    return a.dis ? launch_bwd_gather_t<FP_, true>(a, g, stream) : launch_bwd_gather_t<FP_, false>(a, g, stream);
+  switch (a.main.fp) {
+    GCONV_BWG_CASE(4) GCONV_BWG_CASE(8) GCONV_BWG_CASE(16) GCONV_BWG_CASE(32) GCONV_BWG_CASE(64)
+  }
+#undef GCONV_BWG_CASE
   return GCONV_E_UNSUPPORTED;
 }
 

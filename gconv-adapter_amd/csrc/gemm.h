@@ -134,4 +134,101 @@ __device__ __forceinline__ void load_tile_L(const float* __restrict__ M, int i0,
 }
 
 
+// sum(G . X) contribution of one L-layout row pair, as an explicit fma chain: B4 exists twice
+// (bwd_main_kernel, bwd_gather_kernel) and hipcc contracts `a*b + c*d + ...` differently from
+// kernel to kernel — spelled out, both produce the same bits.
+__device__ __forceinline__ float dot4_acc(f32x4 g, f32x4 x, float acc) {
+  return __builtin_fmaf(g[0], x[0], __builtin_fmaf(g[1], x[1], __builtin_fmaf(g[2], x[2], __builtin_fmaf(g[3], x[3], acc))));
+}
+
+// LDS of B4's final slot reduction ([2 FP + 1][nchunks][64] floats when a chunk has several slots)
+inline size_t bwd_main_lds_bytes(int nchunks, int nslots, int fp) {
+  if (nslots == 1) return 0;
+  return (static_cast<size_t>(2) * fp + 1) * nchunks * 64 * sizeof(float);
+}
+
+// End of B4 (shared by bwd_main_kernel and the gather-fused bwd_gather_kernel): lane-quarter sums
+// of colsum(G) and sum(G.X), then the slots of each chunk added through LDS in slot order and ONE
+// partial per workgroup written out.
+template <int FP>
+__device__ __forceinline__ void bwd_main_tail(const BwdMainArgs& a, f32x4 (&awd)[FP >= 16 ? FP / 16 : 1][4],
+                                              f32x4 (&awu)[FP >= 16 ? FP / 16 : 1][4], f32x4 cs, float dsx,
+                                              float* red, int nchunks, int nslots, int J, int slot, int jj,
+                                              int t, int lane, int w, int colbase, bool colvalid) {
+  constexpr int NCB = FP >= 16 ? FP / 16 : 1;
+  // colsum(G): add the four lane quarters (fixed order); every quarter then holds the sum
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    cs[c] += __shfl_xor(cs[c], 16);
+    cs[c] += __shfl_xor(cs[c], 32);
+  }
+  for (int off = 32; off > 0; off >>= 1) dsx += __shfl_xor(dsx, off);
+  if (lane == 0) a.part_dsx[static_cast<size_t>(blockIdx.x) * nchunks * nslots + w] = dsx;
+
+  // ---- add the slots of each chunk in slot order, then one partial per workgroup
+  const int pid = blockIdx.x;
+  if (nslots > 1) {
+    float* rwd = red;                                   // [FP][nchunks * 64]
+    float* rwu = red + static_cast<size_t>(FP) * nchunks * 64;
+    float* rcs = red + static_cast<size_t>(2) * FP * nchunks * 64;
+    const int lc = J * 64 + 4 * jj;                     // column inside the LDS row
+    for (int s = 0; s < nslots; ++s) {
+      if (slot == s) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const int rk = 16 * cb + 4 * t + m;
+            if (rk < FP) {
+              float* pd = rwd + static_cast<size_t>(rk) * nchunks * 64 + lc;
+              float* pu = rwu + static_cast<size_t>(rk) * nchunks * 64 + lc;
+              f32x4 vd = f32x4{awd[cb][0][m], awd[cb][1][m], awd[cb][2][m], awd[cb][3][m]};
+              f32x4 vu = f32x4{awu[cb][0][m], awu[cb][1][m], awu[cb][2][m], awu[cb][3][m]};
+              if (s > 0) {
+                vd += *reinterpret_cast<f32x4*>(pd);
+                vu += *reinterpret_cast<f32x4*>(pu);
+              }
+              *reinterpret_cast<f32x4*>(pd) = vd;
+              *reinterpret_cast<f32x4*>(pu) = vu;
+            }
+          }
+        if (t == 0) {
+          f32x4 v = cs;
+          if (s > 0) v += *reinterpret_cast<f32x4*>(rcs + lc);
+          *reinterpret_cast<f32x4*>(rcs + lc) = v;
+        }
+      }
+      __syncthreads();
+    }
+    // cooperative, coalesced write-out of the reduced tiles
+    const int width = nchunks * 64;
+    for (int idx = threadIdx.x; idx < FP * width; idx += blockDim.x) {
+      const int rk = idx / width, col = idx % width;
+      if (col < a.d) {
+        const size_t o = (static_cast<size_t>(pid) * FP + rk) * a.d + col;
+        a.part_wd[o] = rwd[idx];
+        a.part_wu[o] = rwu[idx];
+      }
+    }
+    for (int col = threadIdx.x; col < width; col += blockDim.x)
+      if (col < a.d) a.part_cs[static_cast<size_t>(pid) * a.d + col] = rcs[col];
+  } else {
+    if (colvalid) {
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int rk = 16 * cb + 4 * t + m;  // D row = rank index
+          if (rk < FP) {
+            const size_t o = (static_cast<size_t>(pid) * FP + rk) * a.d + colbase;
+            stg4(a.part_wd + o, f32x4{awd[cb][0][m], awd[cb][1][m], awd[cb][2][m], awd[cb][3][m]});
+            stg4(a.part_wu + o, f32x4{awu[cb][0][m], awu[cb][1][m], awu[cb][2][m], awu[cb][3][m]});
+          }
+        }
+      }
+      if (t == 0) stg4(a.part_cs + static_cast<size_t>(pid) * a.d + colbase, cs);
+    }
+  }
+}
+
 }  // namespace gconv

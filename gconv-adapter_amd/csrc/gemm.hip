@@ -345,11 +345,6 @@ gconv_status_t launch_up_fwd(const UpArgs& a, hipStream_t stream) {
 // chunk are added through LDS in slot order (deterministic) and ONE partial per
 // workgroup goes to HBM.
 // ===========================================================================
-static size_t bwd_main_lds_bytes(int nchunks, int nslots, int fp) {
-  if (nslots == 1) return 0;
-  return (static_cast<size_t>(2) * fp + 1) * nchunks * 64 * sizeof(float);
-}
-
 BwdMainGeom bwd_main_geom(int n, int d) {
   BwdMainGeom g;
   g.nchunks = ceil_div(d, 64);
@@ -452,7 +447,7 @@ __global__ __launch_bounds__(TB) void bwd_main_kernel(BwdMainArgs a, int nchunks
         }
       }
       cs += gv[m];
-      if (a.skip) dsx += gv[m][0] * xv[m][0] + gv[m][1] * xv[m][1] + gv[m][2] * xv[m][2] + gv[m][3] * xv[m][3];
+      if (a.skip) dsx = dot4_acc(gv[m], xv[m], dsx);
     }
 
     if (NEED_DX) {
@@ -480,79 +475,7 @@ __global__ __launch_bounds__(TB) void bwd_main_kernel(BwdMainArgs a, int nchunks
     blk = nxt;
   }
 
-  // colsum(G): add the four lane quarters (fixed order); every quarter then holds the sum
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    cs[c] += __shfl_xor(cs[c], 16);
-    cs[c] += __shfl_xor(cs[c], 32);
-  }
-  for (int off = 32; off > 0; off >>= 1) dsx += __shfl_xor(dsx, off);
-  if (lane == 0) a.part_dsx[static_cast<size_t>(blockIdx.x) * nchunks * nslots + w] = dsx;
-
-  // ---- add the slots of each chunk in slot order, then one partial per workgroup
-  const int pid = blockIdx.x;
-  if (nslots > 1) {
-    float* rwd = red;                                   // [FP][nchunks * 64]
-    float* rwu = red + static_cast<size_t>(FP) * nchunks * 64;
-    float* rcs = red + static_cast<size_t>(2) * FP * nchunks * 64;
-    const int lc = J * 64 + 4 * jj;                     // column inside the LDS row
-    for (int s = 0; s < nslots; ++s) {
-      if (slot == s) {
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            const int rk = 16 * cb + 4 * t + m;
-            if (rk < FP) {
-              float* pd = rwd + static_cast<size_t>(rk) * nchunks * 64 + lc;
-              float* pu = rwu + static_cast<size_t>(rk) * nchunks * 64 + lc;
-              f32x4 vd = f32x4{awd[cb][0][m], awd[cb][1][m], awd[cb][2][m], awd[cb][3][m]};
-              f32x4 vu = f32x4{awu[cb][0][m], awu[cb][1][m], awu[cb][2][m], awu[cb][3][m]};
-              if (s > 0) {
-                vd += *reinterpret_cast<f32x4*>(pd);
-                vu += *reinterpret_cast<f32x4*>(pu);
-              }
-              *reinterpret_cast<f32x4*>(pd) = vd;
-              *reinterpret_cast<f32x4*>(pu) = vu;
-            }
-          }
-        if (t == 0) {
-          f32x4 v = cs;
-          if (s > 0) v += *reinterpret_cast<f32x4*>(rcs + lc);
-          *reinterpret_cast<f32x4*>(rcs + lc) = v;
-        }
-      }
-      __syncthreads();
-    }
-    // cooperative, coalesced write-out of the reduced tiles
-    const int width = nchunks * 64;
-    for (int idx = threadIdx.x; idx < FP * width; idx += blockDim.x) {
-      const int rk = idx / width, col = idx % width;
-      if (col < a.d) {
-        const size_t o = (static_cast<size_t>(pid) * FP + rk) * a.d + col;
-        a.part_wd[o] = rwd[idx];
-        a.part_wu[o] = rwu[idx];
-      }
-    }
-    for (int col = threadIdx.x; col < width; col += blockDim.x)
-      if (col < a.d) a.part_cs[static_cast<size_t>(pid) * a.d + col] = rcs[col];
-  } else {
-    if (colvalid) {
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const int rk = 16 * cb + 4 * t + m;  // D row = rank index
-          if (rk < FP) {
-            const size_t o = (static_cast<size_t>(pid) * FP + rk) * a.d + colbase;
-            stg4(a.part_wd + o, f32x4{awd[cb][0][m], awd[cb][1][m], awd[cb][2][m], awd[cb][3][m]});
-            stg4(a.part_wu + o, f32x4{awu[cb][0][m], awu[cb][1][m], awu[cb][2][m], awu[cb][3][m]});
-          }
-        }
-      }
-      if (t == 0) stg4(a.part_cs + static_cast<size_t>(pid) * a.d + colbase, cs);
-    }
-  }
+  bwd_main_tail<FP>(a, awd, awu, cs, dsx, red, nchunks, nslots, J, slot, jj, t, lane, w, colbase, colvalid);
 }
 
 template <int FP>
