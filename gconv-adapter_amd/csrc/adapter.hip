@@ -73,7 +73,7 @@ static BwdWs carve_bwd(void* ws, const gconv_csr_t* gt, int d, int fp, int rows,
   BwdWs w;
   const size_t n = slab ? 0 : gt->num_nodes;
   w.geom = bwd_main_geom(rows, d);
-  w.n_ds1 = rowsA_grid(rows);
+  w.n_ds1 = rowsA_grid(rows, d, fp);
   w.n_bd = spmm_bias_partial_rows(gt, fp, rows);
   w.dp = c.take<float>(n * fp);
   w.dh1 = c.take<float>(n * fp);

@@ -25,7 +25,7 @@ struct RowsAArgs {
 
 size_t rowsA_lds_bytes(int d, int fp);
 constexpr size_t kRowsAMaxLds = 160 * 1024;   // the whole LDS of a CU (hidden x padded rank <= 40960 floats)
-int rowsA_grid(int n);
+int rowsA_grid(int n, int d, int fp);   // also the number of ds_partial entries a ROWSA_DP launch writes
 gconv_status_t launch_rowsA(const RowsAArgs& a, hipStream_t stream);
 
 // ---- K3: out[N, d] = s * (P[N, Fp] * W_up^T + b_up + (skip ? X : 0))

@@ -185,11 +185,13 @@ size_t rowsA_lds_bytes(int d, int fp) {
   return static_cast<size_t>(nq) * ncb * 64 * sizeof(f32x4);
 }
 
-int rowsA_grid(int n) {
+int rowsA_grid(int n, int d, int fp) {
   const int nblk = ceil_div(n, 16);
   int g = ceil_div(nblk, 4);  // persistent: <= 2 workgroups per CU walk the node blocks
   static const int wgpc = std::getenv("GCONV_ROWSA_WGPC") ? std::atoi(std::getenv("GCONV_ROWSA_WGPC")) : 2;
-  return g < 1 ? 1 : (g > wgpc * kNumCU ? wgpc * kNumCU : g);   // measured best at S-arxiv: 2 (27 us) vs 3-6 (28-29 us)
+  // (a weight table above 80 KB of LDS leaves room for one workgroup per CU)
+  const int per_cu = rowsA_lds_bytes(d, fp) > 80 * 1024 ? 1 : wgpc;
+  return g < 1 ? 1 : (g > per_cu * kNumCU ? per_cu * kNumCU : g);   // measured best at S-arxiv: 2 (27 us) vs 3-6 (28-29 us)
 }
 
 // Ring depth: 1. A second ring (two block periods for a load to arrive, 123 VGPRs) was measured
@@ -224,8 +226,7 @@ gconv_status_t launch_rowsA(const RowsAArgs& a, hipStream_t stream) {
   const int nq = rowsA_nq(a.d);
   const size_t lds = rowsA_lds_bytes(a.d, a.fp);
   if (nq == 0 || lds > kRowsAMaxLds) return GCONV_E_UNSUPPORTED;
-  int grid = rowsA_grid(a.n);
-  if (lds > 80 * 1024 && grid > kNumCU) grid = kNumCU;   // one workgroup per CU fits
+  const int grid = rowsA_grid(a.n, a.d, a.fp);
   switch (a.fp >= 16 ? a.fp / 16 : 1) {
     case 1: return launch_rowsA_ncb<1>(a, nq, grid, lds, stream);
     case 2: return launch_rowsA_ncb<2>(a, nq, grid, lds, stream);

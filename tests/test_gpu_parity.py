@@ -1088,3 +1088,15 @@ def test_adapter_batched_3d_and_non_contiguous_inputs(dev):
     assert torch.equal(a, b)
     with pytest.raises(RuntimeError, match="int64"):
         mod(xt.contiguous(), batch.edge_index.to(dev).int())
+
+
+def test_adapter_large_weight_table_on_many_rows(dev):
+    """hidden 512 x rank 64: K1's weight-fragment table takes 128 KB of LDS (one workgroup per CU),
+    on enough rows (20000) that the persistent grid is capped by the CU count — the number of
+    d(scalar) partials B1 writes must be the number the finalize launch sums."""
+    n, d, r = 20000, 512, 64
+    ei = _random_graph(n, 60000, 31, symmetric=True)
+    x = torch.randn(n, d, generator=torch.Generator().manual_seed(5))
+    batch = ga.synth.GraphBatch(x=x, edge_index=ei, graph_ptr=torch.tensor([0, n]), num_graphs=1)
+    flags = oracle.AdapterFlags(learnable_scalar=True, normalize=True)
+    _check_workload(dev, batch, d, r, flags)
