@@ -317,7 +317,7 @@ static gconv_status_t bwd_stages(const gconv_graph_t* gr, const gconv_adapter_pa
     b3.row_lo = lo; b3.row_hi = hi;
     BwdMainArgs b4{};
     b4.G = grad_out; b4.X = x; b4.T = dp + shift; b4.P = saved_p + shift; b4.W_down = p->w_down;
-    b4.scalar = p->scalar; b4.dX = grad_x;
+    b4.scalar = p->scalar; b4.b_up = grad_scalar ? p->b_up : nullptr; b4.dX = grad_x;
     b4.part_wd = ws.part_wd; b4.part_wu = ws.part_wu; b4.part_cs = ws.part_cs;
     b4.part_dsx = ws.part_dsx;
     b4.n = n; b4.d = d; b4.r = r; b4.fp = fp; b4.skip = p->skip;
@@ -375,7 +375,7 @@ static gconv_status_t adapter_bwd(const gconv_graph_t* gr, const gconv_adapter_p
   if (p->act == GCONV_ACT_SILU && n > 0 && !saved_h1) return GCONV_E_INVALID_ARG;
   if (!aligned16(x) || !aligned16(grad_out) || !aligned16(saved_h) || !aligned16(saved_p) ||
       (saved_h1 && !aligned16(saved_h1)) || (grad_x && !aligned16(grad_x)) ||
-      !aligned16(workspace) || !aligned16(p->w_down))
+      !aligned16(workspace) || !aligned16(p->w_down) || (p->b_up && !aligned16(p->b_up)))
     return GCONV_E_ALIGNMENT;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (n > 0 && tile_path_ok(gr, d, fp)) {  // block-diagonal batch: fused launch + finalize
@@ -515,7 +515,7 @@ extern "C" gconv_status_t gconv_adapter_slab_bwd_f32(
   if (p->act == GCONV_ACT_SILU && rows > 0 && !saved_h1) return GCONV_E_INVALID_ARG;
   if (!aligned16(x) || !aligned16(grad_out) || !aligned16(saved_h) || !aligned16(saved_p) ||
       (saved_h1 && !aligned16(saved_h1)) || (grad_x && !aligned16(grad_x)) || !aligned16(dp) ||
-      !aligned16(dh1) || !aligned16(workspace) || !aligned16(p->w_down))
+      !aligned16(dh1) || !aligned16(workspace) || !aligned16(p->w_down) || (p->b_up && !aligned16(p->b_up)))
     return GCONV_E_ALIGNMENT;
   const BwdWs ws = carve_bwd(workspace, &gr->bwd, p->hidden, padded_rank(p->rank), rows, true);
   if (workspace_bytes < ws.bytes) return GCONV_E_WORKSPACE;

@@ -49,11 +49,12 @@ struct BwdMainArgs {
   const float* P;       // [n, Fp]  saved P
   const float* W_down;  // [r, d]
   const float* scalar;  // device scalar or nullptr
+  const float* b_up;    // [d] or nullptr: its share b_up . colsum(G) of d(scalar) rides in part_dsx
   float* dX;            // [n, d] or nullptr
   float* part_wd;       // [nparts, Fp, d]
   float* part_wu;       // [nparts, Fp, d]
   float* part_cs;       // [nparts, d]
-  float* part_dsx;      // [nparts * nchunks]
+  float* part_dsx;      // [nparts * nchunks * nslots]: per-wave sum(G . X) [skip] + b_up . colsum(G)
   int n, d, r, fp;
   int skip;
 };
@@ -162,6 +163,10 @@ __device__ __forceinline__ void bwd_main_tail(const BwdMainArgs& a, f32x4 (&awd)
     cs[c] += __shfl_xor(cs[c], 16);
     cs[c] += __shfl_xor(cs[c], 32);
   }
+  // d(scalar) also holds b_up . colsum(G): this wave's share of the column sums is final here, so
+  // its dot product with b_up joins the wave's sum(G . X) partial (one lane quarter only: all four
+  // hold the same sums) and the finalize launch never has to re-reduce colsum(G) for it
+  if (a.b_up && colvalid && t == 0) dsx = dot4_acc(ldg4(a.b_up + colbase), cs, dsx);
   for (int off = 32; off > 0; off >>= 1) dsx += __shfl_xor(dsx, off);
   if (lane == 0) a.part_dsx[static_cast<size_t>(blockIdx.x) * nchunks * nslots + w] = dsx;
 

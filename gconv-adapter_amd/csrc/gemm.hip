@@ -592,27 +592,13 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& a, int block, 
 
 // d(scalar) = sum_i (G_i W_up) . P_i  +  b_up . colsum(G)  +  [skip] sum(G . X)
 // ONE extra block of the finalize launch (general path with a learnable scalar; the fused tile
-// path hands over complete per-workgroup partials instead). It sums the colsum(G) partials
-// itself, in its own fixed order, rather than waiting for the blocks that reduce them: no second
-// launch behind the first (round 1 had one: a launch and a kernel boundary per backward pass).
+// path hands over complete per-workgroup partials instead): part_ds1 comes from B1, part_dsx from
+// B4's waves, which fold their share of b_up . colsum(G) in (bwd_main_tail) — round 1 reduced
+// colsum(G) first and ran this as a second launch behind the first.
 __device__ __forceinline__ void finalize_scalar_body(const FinalizeArgs& a, float* red) {
   float acc = 0.f;
   for (int i = threadIdx.x; i < a.n_ds1; i += 256) acc += a.part_ds1[i];
-  if (a.skip)
-    for (int i = threadIdx.x; i < a.n_dsx; i += 256) acc += a.part_dsx[i];
-  if (a.b_up)
-    for (int j = threadIdx.x; j < a.d; j += 256) {
-      float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-      int p = 0;
-      for (; p + 3 < a.nparts; p += 4) {
-        c0 += a.part_cs[static_cast<size_t>(p) * a.d + j];
-        c1 += a.part_cs[static_cast<size_t>(p + 1) * a.d + j];
-        c2 += a.part_cs[static_cast<size_t>(p + 2) * a.d + j];
-        c3 += a.part_cs[static_cast<size_t>(p + 3) * a.d + j];
-      }
-      for (; p < a.nparts; ++p) c0 += a.part_cs[static_cast<size_t>(p) * a.d + j];
-      acc += a.b_up[j] * ((c0 + c1) + (c2 + c3));
-    }
+  for (int i = threadIdx.x; i < a.n_dsx; i += 256) acc += a.part_dsx[i];
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
