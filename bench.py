@@ -453,6 +453,30 @@ def measure_transductive(device, name: str) -> dict:
             f"{name}_adapter_fwd_us": round(fwd_ms * 1e3, 1), f"{name}_adapter_bwd_us": round(bwd_ms * 1e3, 1)}
 
 
+def measure_graph_build(device) -> dict:
+    """K0 for molecule batches, in-stream and synchronous (what a caller that does NOT use
+    `prefetch_plan` pays in front of a batch's first adapter): wall time per `GraphPlan` for the
+    reference's batch size (32 molecules: the single-workgroup builder) and for the 512-molecule shard
+    (the multi-launch pipeline)."""
+    out = {}
+    for name, graphs, key in (("esol", None, "esol32"), ("hiv", None, "hiv512")):
+        batch, _ = ga.synth.make_workload(name, graphs=graphs)
+        ei = batch.edge_index.to(device)
+        n = batch.num_nodes
+        for _ in range(5):
+            ga.GraphPlan(ei, n, True)
+        best = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(50):
+                ga.GraphPlan(ei, n, True)
+            torch.cuda.synchronize(device)
+            best = min(best, (time.perf_counter() - t0) / 50)
+        out[f"{key}_graph_build_wall_us"] = round(best * 1e6, 1)
+    return out
+
+
 class _FinetuneModel(torch.nn.Module):
     """The reference's inductive model in the shape its fine-tune loop sees it (`MolecularGNN.forward`,
     `src/models/inductive/gnn.py:85-130`, sequential pre-adapters; mean pool; `graph_pred_linear`):
@@ -748,6 +772,7 @@ def main() -> None:
             extra.update(measure_tile_kernels(device))
             extra.update(measure_gin(device))
             extra.update(measure_arxiv_projections(device))
+            extra.update(measure_graph_build(device))
             for tname in ("cora", "pubmed"):
                 extra.update(measure_transductive(device, tname))
             other = "esol" if args.workload != "esol" else "hiv"

@@ -16,6 +16,8 @@
 //   7. D2H of the counters, sync; S^T (second sort) only when the test failed
 #include <hipcub/hipcub.hpp>
 
+#include <cstdlib>
+
 #include "common.h"
 
 namespace gconv {
@@ -311,6 +313,303 @@ static gconv_status_t build_direction(const int64_t* ei, int64_t E, int32_t n, i
   return GCONV_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Small graphs (a 32-molecule batch: ~430 nodes, ~870 edges): the WHOLE build in ONE workgroup.
+// The pipeline above is ~18 launches of which each is a few microseconds of latency — 75 us of
+// wall time per ESOL batch, half of the five-adapter step it precedes when the caller does not
+// prefetch. Here keys, CSR, span counters and tile starts live in LDS; same outputs, same info
+// words (long rows come out in ascending row order: the multi-launch path lists them in atomic
+// arrival order, both are valid), and the transposed CSR of a directed edge list is built in the
+// same launch, so there is ONE host synchronisation whatever the graph.
+// ---------------------------------------------------------------------------
+// up to 4096 edges; beyond that the multi-launch pipeline is as fast (6960 edges: 103 us against 94).
+// One workgroup of 1024 threads: with 256 (cheaper barriers, 4-8 keys per thread) the dependent
+// binary searches per thread dominate and the ESOL batch builds in 53 us instead of 48.
+constexpr int kSmallMaxEdges = 4096, kSmallMaxNodes = 4096;
+
+__device__ __forceinline__ int small_lower_bound(const uint32_t* keys, int count, uint32_t v) {
+  int lo = 0, hi = count;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (keys[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// in-place exclusive prefix sum of data[0 .. count) (any count); returns the total.
+// Chunk sums are scanned inside each wave by shuffles, the wave totals through LDS: two
+// barriers per scan (a Hillis-Steele over 1024 LDS words costs twenty, ~0.4 us each at 16 waves).
+template <int T>
+__device__ __forceinline__ int small_exclusive_scan(int32_t* data, int count, int32_t* tmp) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (count + T - 1) / T;
+  const int b0 = min(tid * per, count), b1 = min(b0 + per, count);
+  int sum = 0;
+  for (int i = b0; i < b1; ++i) sum += data[i];
+  int incl = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) tmp[wave] = incl;
+  __syncthreads();
+  int wave_base = 0, total = 0;
+  for (int wv = 0; wv < T / 64; ++wv) {
+    const int v = tmp[wv];
+    if (wv < wave) wave_base += v;
+    total += v;
+  }
+  int run = wave_base + incl - sum;
+  for (int i = b0; i < b1; ++i) { const int v = data[i]; data[i] = run; run += v; }
+  __syncthreads();
+  return total;
+}
+
+// Bitonic sort of nsort = T * NR keys (ascending), NR keys per thread in registers:
+// key i lives in register i / 1024 of thread i % 1024, so a compare-exchange distance j is a lane
+// shuffle (j < 64: no memory, no barrier), an LDS exchange between waves (64 <= j < 1024) or a
+// swap between two registers of the same thread (j >= 1024). Ten LDS stages at any size instead of
+// one barrier per stage of the network (55 at 1024 keys, 91 at 8192).
+template <int NR, int T>
+__device__ __forceinline__ void small_bitonic_sort(uint32_t (&v)[NR], uint32_t* xch) {
+  const int tid = threadIdx.x;
+  constexpr int nsort = T * NR;
+  for (int k = 2; k <= nsort; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= T) {          // partner = another register of this thread
+        const int jr = j / T;
+#pragma unroll
+        for (int jb = 1; jb < NR; jb <<= 1) {   // (register indices stay compile-time constants)
+          if (jr == jb) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+              if ((r & jb) == 0) {
+                const int i = r * T + tid;
+                const bool up = (i & k) == 0;
+                const uint32_t x = v[r], y = v[r | jb];
+                if ((x > y) == up) { v[r] = y; v[r | jb] = x; }
+              }
+            }
+          }
+        }
+      } else if (j >= 64) {              // partner in another wave: through LDS
+#pragma unroll
+        for (int r = 0; r < NR; ++r) xch[r * T + tid] = v[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const int i = r * T + tid;
+          const uint32_t y = xch[r * T + (tid ^ j)];
+          const bool up = (i & k) == 0, lower = (tid & j) == 0;
+          const uint32_t x = v[r];
+          v[r] = (lower == up) ? min(x, y) : max(x, y);
+        }
+        __syncthreads();
+      } else {                           // partner in this wave: shuffle
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const int i = r * T + tid;
+          const uint32_t x = v[r];
+          const uint32_t y = static_cast<uint32_t>(__shfl_xor(static_cast<int>(x), j));
+          const bool up = (i & k) == 0, lower = (tid & j) == 0;
+          v[r] = (lower == up) ? min(x, y) : max(x, y);
+        }
+      }
+    }
+  }
+}
+
+struct SmallBuildArgs {
+  const int64_t* ei; int32_t E, n, normalize, shift, nsort, ntiles;
+  // outputs (device): forward / transposed CSR slots, dis, tiles, info
+  int32_t *rowptr_f, *col_f, *long_rows_f, *long_seg_base_f, *seg_long_f; uint32_t* long_sync_f;
+  int32_t *rowptr_b, *col_b, *long_rows_b, *long_seg_base_b, *seg_long_b; uint32_t* long_sync_b;
+  float* dis; int32_t* tile_ptr; uint64_t* tile_order; int32_t* info;
+};
+
+// sort + CSR + row statistics of one direction out of LDS; counters -> sinfo[base .. base + 3]
+template <int NR, int T>
+__device__ __forceinline__ void small_direction(const SmallBuildArgs& a, int transpose, uint32_t* keys,
+                                                int32_t* rowptr, int32_t* span, int32_t* tmp, int32_t* flags,
+                                                int32_t* flags2, int32_t* out_rowptr, int32_t* out_col,
+                                                float* out_dis, int32_t* out_long_rows,
+                                                int32_t* out_long_seg_base, int32_t* out_seg_long,
+                                                uint32_t* out_long_sync, int base, int32_t* sinfo) {
+  const int tid = threadIdx.x;
+  const KeyOps<uint32_t> ko{a.shift};
+  const int n = a.n, E = a.E;
+  uint32_t kv[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int e = r * T + tid;
+    uint32_t key = 0xFFFFFFFFu;   // padding of the bitonic network
+    if (e < E) {
+      const int64_t s = a.ei[e], d = a.ei[static_cast<int64_t>(E) + e];
+      if (s < 0 || s >= n || d < 0 || d >= n) {
+        sinfo[INFO_BAD] = 1;
+        key = ko.make(n, 0);
+      } else if (a.normalize && s == d) {
+        key = ko.make(n, 0);  // add_remaining_self_loops drops it
+      } else {
+        key = transpose ? ko.make(static_cast<uint32_t>(s), static_cast<uint32_t>(d))
+                        : ko.make(static_cast<uint32_t>(d), static_cast<uint32_t>(s));
+        if (span && s != d) {
+          const int lo = static_cast<int>(s < d ? s : d), hi = static_cast<int>(s < d ? d : s);
+          if (hi - lo > kTileSpan) sinfo[INFO_NOTILE] = 1;
+          else { atomicAdd(&span[lo + 1], 1); atomicAdd(&span[hi + 1], -1); }
+        }
+      }
+    }
+    kv[r] = key;
+  }
+  small_bitonic_sort<NR, T>(kv, keys);
+#pragma unroll
+  for (int r = 0; r < NR; ++r) keys[r * T + tid] = kv[r];
+  __syncthreads();
+  // CSR: rowptr[r] = first key of row >= r; nnz = first key of row n
+  for (int r = tid; r <= n; r += T) {
+    const int p = small_lower_bound(keys, a.nsort, ko.make(static_cast<uint32_t>(r), 0));
+    rowptr[r] = p;
+    out_rowptr[r] = p;
+  }
+  __syncthreads();
+  const int nnz = rowptr[n];
+  for (int p = tid; p < nnz; p += T) out_col[p] = static_cast<int32_t>(ko.col(keys[p]));
+  // row statistics
+  int maxdeg = 0;
+  for (int i = tid; i < n; i += T) {
+    const int deg = rowptr[i + 1] - rowptr[i];
+    if (out_dis) out_dis[i] = 1.0f / sqrtf(static_cast<float>(deg + 1));
+    maxdeg = max(maxdeg, deg);
+  }
+  for (int off = 32; off > 0; off >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, off));
+  if ((tid & 63) == 0 && maxdeg > 0) atomicMax(&sinfo[base + 3], maxdeg);
+  __syncthreads();
+  int n_long = 0, n_seg = 0;
+  if (sinfo[base + 3] > GCONV_LONG_ROW) {   // uniform; long rows in ascending row order (two scans)
+    for (int i = tid; i < n; i += T) {
+      const int deg = rowptr[i + 1] - rowptr[i];
+      const bool is_long = deg > GCONV_LONG_ROW;
+      flags[i] = is_long ? 1 : 0;
+      flags2[i] = is_long ? (deg + GCONV_SEG_EDGES - 1) / GCONV_SEG_EDGES : 0;
+    }
+    __syncthreads();
+    n_long = small_exclusive_scan<T>(flags, n, tmp);     // flags[i]  = index of row i among the long rows
+    n_seg = small_exclusive_scan<T>(flags2, n, tmp);     // flags2[i] = first segment of row i
+    for (int i = tid; i < n; i += T) {
+      const int deg = rowptr[i + 1] - rowptr[i];
+      if (deg > GCONV_LONG_ROW) {
+        const int lr = flags[i], sb = flags2[i], nseg = (deg + GCONV_SEG_EDGES - 1) / GCONV_SEG_EDGES;
+        out_long_rows[lr] = i;
+        out_long_seg_base[lr] = sb;
+        out_long_sync[lr] = 0u;
+        for (int k = 0; k < nseg; ++k) out_seg_long[sb + k] = lr;
+      }
+    }
+  }
+  if (tid == 0) { sinfo[base + 0] = nnz; sinfo[base + 1] = n_long; sinfo[base + 2] = n_seg; }
+  __syncthreads();
+}
+
+template <int NR, int T>
+__global__ __launch_bounds__(T) void small_graph_build_kernel(SmallBuildArgs a) {
+  extern __shared__ int32_t sm[];
+  // layout: keys[nsort] | rowptr[n + 1] | span[n + 2] | flags[n] | flags2[n] | tmp[1024] | tptr[ntiles + 1] | sinfo[64]
+  uint32_t* keys = reinterpret_cast<uint32_t*>(sm);
+  int32_t* rowptr = sm + a.nsort;
+  int32_t* span = rowptr + a.n + 1;
+  int32_t* flags = span + a.n + 2;
+  int32_t* flags2 = flags + a.n;
+  int32_t* tmp = flags2 + a.n;
+  int32_t* tptr = tmp + T;
+  int32_t* sinfo = tptr + a.ntiles + 1;   // the info words (enum above; forward counters at 16, transposed at 24)
+  const int tid = threadIdx.x, n = a.n;
+  for (int i = tid; i < n + 2; i += T) span[i] = 0;
+  if (tid < 64) sinfo[tid] = 0;
+  __syncthreads();
+
+  small_direction<NR, T>(a, 0, keys, rowptr, span, tmp, flags, flags2, a.rowptr_f, a.col_f, a.dis, a.long_rows_f,
+                  a.long_seg_base_f, a.seg_long_f, a.long_sync_f, 16, sinfo);
+  const KeyOps<uint32_t> ko{a.shift};
+  const int nnz = rowptr[n];
+
+  // exact symmetry test (sym_check_kernel) on the LDS copy: col(p) = low field of keys[p]
+  for (int p = tid; p < nnz; p += T) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (rowptr[mid + 1] <= p) lo = mid + 1; else hi = mid;
+    }
+    const uint32_t i = static_cast<uint32_t>(lo), j = ko.col(keys[p]);
+    const int k = p - (rowptr[i] + small_lower_bound(keys + rowptr[i], rowptr[i + 1] - rowptr[i], ko.make(i, j)));  // rank among duplicates
+    const int q = rowptr[j] + small_lower_bound(keys + rowptr[j], rowptr[j + 1] - rowptr[j], ko.make(j, i)) + k;
+    if (q >= rowptr[j + 1] || keys[q] != ko.make(j, i)) sinfo[INFO_ASYM] = 1;
+  }
+  __syncthreads();
+
+  // component tiles: inclusive scan of the span diff, tile starts (tile_start_kernel), tile maxima
+  {
+    const int total = small_exclusive_scan<T>(span, n + 2, tmp);   // exclusive; inclusive[q] = excl[q] + diff[q]
+    (void)total;
+    // span now holds the EXCLUSIVE prefix: inclusive value at q = span[q + 1] for q <= n
+    const int B = tile_nodes(n), back = kTileSpan - B;
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int t = wave; t <= a.ntiles; t += T / 64) {   // one wave per tile
+      if (t == a.ntiles) { if (lane == 0) tptr[t] = n; continue; }
+      const int q0 = t * B;
+      int found = -1;
+      for (int base = 0; base <= back && found < 0; base += 64) {
+        const int q = q0 - base - lane;
+        const bool cand = q >= 0 && base + lane <= back;
+        const bool ok = cand && (q == 0 || span[min(q, n) + 1] == 0);
+        const unsigned long long m = __ballot(ok);
+        if (m) found = q0 - base - (__ffsll(static_cast<long long>(m)) - 1);
+        if (q0 - base - 63 <= 0) break;
+      }
+      if (lane == 0) {
+        if (found < 0) { sinfo[INFO_NOTILE] = 1; found = max(q0 - back, 0); }
+        tptr[t] = found;
+      }
+    }
+    __syncthreads();
+    int sz = 0, ed = 0;
+    for (int t = tid; t < a.ntiles; t += T) {
+      sz = max(sz, tptr[t + 1] - tptr[t]);
+      ed = max(ed, rowptr[tptr[t + 1]] - rowptr[tptr[t]]);
+    }
+    for (int off = 32; off > 0; off >>= 1) { sz = max(sz, __shfl_xor(sz, off)); ed = max(ed, __shfl_xor(ed, off)); }
+    if (lane == 0) {
+      if (sz > 0) atomicMax(&sinfo[INFO_TILEMAX], sz);
+      if (ed > 0) atomicMax(&sinfo[INFO_TILEEDGES], ed);
+    }
+    for (int t = tid; t <= a.ntiles; t += T) a.tile_ptr[t] = tptr[t];
+    // size-sorted tile list: rank by (size descending, index ascending) == small_tile_sort_kernel
+    for (int t = tid; t < a.ntiles; t += T) {
+      const int s0 = tptr[t + 1] - tptr[t];
+      int rank = 0;
+      for (int u = 0; u < a.ntiles; ++u) {
+        const int su = tptr[u + 1] - tptr[u];
+        rank += (su > s0) || (su == s0 && u < t);
+      }
+      a.tile_order[rank] = static_cast<uint64_t>(static_cast<uint32_t>(tptr[t])) |
+                           (static_cast<uint64_t>(static_cast<uint32_t>(s0)) << 32);
+    }
+  }
+  __syncthreads();
+  if (sinfo[INFO_ASYM])   // uniform: directed edge list -> S^T as well, in the same launch
+    small_direction<NR, T>(a, 1, keys, rowptr, nullptr, tmp, flags, flags2, a.rowptr_b, a.col_b, nullptr, a.long_rows_b,
+                    a.long_seg_base_b, a.seg_long_b, a.long_sync_b, 24, sinfo);
+  __syncthreads();
+  if (tid < 64) a.info[tid] = sinfo[tid];
+}
+
+static bool small_build_ok(int64_t E, int32_t n) {   // (env read per call: the tests compare both builders)
+  const char* v = std::getenv("GCONV_NO_SMALL_BUILD");
+  const bool off = v != nullptr && v[0] != '\0' && v[0] != '0';
+  return !off && n >= 1 && n <= kSmallMaxNodes && E <= kSmallMaxEdges;
+}
+
 }  // namespace gconv
 
 using namespace gconv;
@@ -351,6 +650,64 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
   // info words: [0..7] flags (enum above); forward counters at 16.., transposed at 24..
   const int FWD = 16, BWD = 24;
 
+  auto fill = [&](gconv_csr_t& c, const CsrOut& o, const int32_t* cnt) {
+    c.num_nodes = n; c.nnz = cnt[0];
+    c.rowptr = o.rowptr; c.col = o.col;
+    c.n_long = cnt[1]; c.n_seg = cnt[2];
+    c.long_rows = o.long_rows; c.long_seg_base = o.long_seg_base; c.seg_long = o.seg_long;
+    c.long_sync = o.long_sync;
+  };
+  if (small_build_ok(E, n)) {   // ONE launch, ONE synchronisation (see small_graph_build_kernel)
+    SmallBuildArgs a{};
+    a.ei = edge_index; a.E = static_cast<int32_t>(E); a.n = n; a.normalize = normalize ? 1 : 0;
+    a.shift = index_bits(n); a.ntiles = L.ntiles;
+    const int threads = 1024;
+    a.nsort = threads;
+    while (a.nsort < E) a.nsort <<= 1;
+    a.rowptr_f = of.rowptr; a.col_f = of.col; a.long_rows_f = of.long_rows; a.long_seg_base_f = of.long_seg_base;
+    a.seg_long_f = of.seg_long; a.long_sync_f = of.long_sync;
+    a.rowptr_b = ob.rowptr; a.col_b = ob.col; a.long_rows_b = ob.long_rows; a.long_seg_base_b = ob.long_seg_base;
+    a.seg_long_b = ob.seg_long; a.long_sync_b = ob.long_sync;
+    a.dis = dis; a.tile_ptr = tile_ptr; a.tile_order = reinterpret_cast<uint64_t*>(arena + L.tile_order);
+    a.info = info;
+    const size_t lds = (static_cast<size_t>(a.nsort) + (n + 1) + (n + 2) + 2 * static_cast<size_t>(n) + threads +
+                        (L.ntiles + 1) + 64) * sizeof(int32_t);
+#define GCONV_SMALL_BUILD(NR_, T_)                                                                     \
+  do {                                                                                                 \
+    if (lds > 48 * 1024)                                                                               \
+      GCONV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&small_graph_build_kernel<NR_, T_>), \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds))); \
+    small_graph_build_kernel<NR_, T_><<<1, T_, lds, stream>>>(a);                                      \
+  } while (0)
+    switch (a.nsort / 1024) {
+      case 1: GCONV_SMALL_BUILD(1, 1024); break;
+      case 2: GCONV_SMALL_BUILD(2, 1024); break;
+      default: GCONV_SMALL_BUILD(4, 1024); break;
+    }
+#undef GCONV_SMALL_BUILD
+    GCONV_LAUNCH_CHECK();
+    int32_t h[64];
+    GCONV_HIP(hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, stream));
+    GCONV_HIP(hipStreamSynchronize(stream));
+    if (h[INFO_BAD]) {
+      g->bad_index = 1;
+      return GCONV_E_BAD_INDEX;
+    }
+    fill(g->fwd, of, h + 16);
+    g->max_degree = h[16 + 3];
+    g->symmetric = h[INFO_ASYM] ? 0 : 1;
+    if (g->symmetric) g->bwd = g->fwd; else fill(g->bwd, ob, h + 24);
+    g->dis = dis;
+    g->tile_ptr = tile_ptr;
+    g->tile_order = reinterpret_cast<int32_t*>(arena + L.tile_order);
+    g->n_tiles = h[INFO_NOTILE] ? 0 : L.ntiles;
+    g->tile_nodes_max = h[INFO_TILEMAX];
+    g->tile_edges_max = h[INFO_TILEEDGES];
+    g->normalize = normalize ? 1 : 0;
+    g->bad_index = 0;
+    return GCONV_OK;
+  }
+
   GCONV_HIP(hipMemsetAsync(info, 0, 64 * sizeof(int32_t), stream));
   GCONV_HIP(hipMemsetAsync(span, 0, (static_cast<size_t>(n) + 2) * sizeof(int32_t), stream));
   const int b = index_bits(n);
@@ -385,13 +742,6 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
     return GCONV_E_BAD_INDEX;
   }
 
-  auto fill = [&](gconv_csr_t& c, const CsrOut& o, const int32_t* cnt) {
-    c.num_nodes = n; c.nnz = cnt[0];
-    c.rowptr = o.rowptr; c.col = o.col;
-    c.n_long = cnt[1]; c.n_seg = cnt[2];
-    c.long_rows = o.long_rows; c.long_seg_base = o.long_seg_base; c.seg_long = o.seg_long;
-    c.long_sync = o.long_sync;
-  };
   fill(g->fwd, of, h + FWD);
   g->max_degree = h[FWD + 3];
   g->symmetric = h[INFO_ASYM] ? 0 : 1;

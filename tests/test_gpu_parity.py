@@ -1100,3 +1100,101 @@ def test_adapter_large_weight_table_on_many_rows(dev):
     batch = ga.synth.GraphBatch(x=x, edge_index=ei, graph_ptr=torch.tensor([0, n]), num_graphs=1)
     flags = oracle.AdapterFlags(learnable_scalar=True, normalize=True)
     _check_workload(dev, batch, d, r, flags)
+
+
+def _plan_arrays(plan):
+    """Everything a plan holds, long rows keyed by row (their order in the lists is not specified)."""
+    def csr(v):
+        s = v.struct
+        out = {"nnz": v.nnz, "rowptr": v.rowptr.cpu(), "col": v.col.cpu(), "n_long": v.n_long, "n_seg": v.n_seg}
+        if v.n_long:
+            rows = plan.arena_view(s.long_rows, v.n_long, torch.int32).cpu().tolist()
+            base = plan.arena_view(s.long_seg_base, v.n_long, torch.int32).cpu().tolist()
+            seg = plan.arena_view(s.seg_long, v.n_seg, torch.int32).cpu().tolist()
+            rp = out["rowptr"].tolist()
+            per_row = {}
+            for lr, (r, b) in enumerate(zip(rows, base)):
+                nseg = -(-(rp[r + 1] - rp[r]) // 128)
+                assert seg[b:b + nseg] == [lr] * nseg       # the row's segments point back at it
+                per_row[r] = nseg
+            assert sorted(b for b in base) == sorted(set(base)) and sum(per_row.values()) == v.n_seg
+            out["long"] = per_row
+        return out
+    res = {"fwd": csr(plan.fwd), "symmetric": plan.symmetric, "n_tiles": plan.n_tiles,
+           "max_degree": plan.struct.max_degree}
+    if not plan.symmetric:
+        res["bwd"] = csr(plan.bwd)
+    if plan.normalize:
+        res["dis"] = plan.dis.cpu()
+    if plan.n_tiles:
+        res["tile_ptr"] = plan.tile_ptr.cpu()
+        res["tile_order"] = plan.tile_order.cpu()
+        res["tile_max"] = (plan.struct.tile_nodes_max, plan.struct.tile_edges_max)
+    return res
+
+
+def _same(a, b, path=""):
+    assert type(a) is type(b), path
+    if isinstance(a, dict):
+        assert a.keys() == b.keys(), (path, a.keys(), b.keys())
+        for k in a:
+            _same(a[k], b[k], f"{path}.{k}")
+    elif isinstance(a, torch.Tensor):
+        assert torch.equal(a, b), path
+    else:
+        assert a == b, (path, a, b)
+
+
+@pytest.mark.parametrize("normalize", [True, False])
+@pytest.mark.parametrize("kind", ["esol", "hiv32", "random", "random_2k", "directed", "hub", "empty", "single",
+                                  "loops_only", "wide_edge", "max_size"])
+def test_single_workgroup_graph_build_equals_multi_launch_build(dev, kind, normalize, monkeypatch):
+    """Graphs of up to 4096 nodes / 4096 edges are built by ONE workgroup in ONE launch
+    (small_graph_build_kernel: keys, bitonic sort, CSR, dis, long rows, exact symmetry test, S^T for
+    directed lists, component tiles, size-sorted tile list — all in LDS): every array and counter
+    must equal the multi-launch builder's (long-row lists up to their order)."""
+    g = torch.Generator().manual_seed(41)
+    if kind == "esol":
+        b, _ = ga.synth.make_workload("esol"); ei, n = b.edge_index, b.num_nodes
+    elif kind == "hiv32":
+        b, _ = ga.synth.make_workload("hiv", graphs=32); ei, n = b.edge_index, b.num_nodes
+    elif kind == "random":
+        n = 777; ei = _random_graph(n, 1500, 42, symmetric=True)          # duplicates and self-loops included
+    elif kind == "random_2k":   # 256-thread variant at its largest key count
+        n = 300; ei = _random_graph(n, 2040, 45, symmetric=False)
+    elif kind == "directed":
+        n = 500; ei = _random_graph(n, 4000, 43, symmetric=False)
+    elif kind == "hub":
+        n = 1500
+        spokes = torch.stack([torch.randint(1, n, (900,), generator=g), torch.zeros(900, dtype=torch.long)])
+        rnd = torch.stack([torch.randint(n, (1000,), generator=g), torch.randint(n, (1000,), generator=g)])
+        pairs = torch.cat([spokes, rnd], dim=1)
+        ei = torch.cat([pairs, pairs.flip(0)], dim=1)
+    elif kind == "empty":
+        n = 40; ei = torch.zeros(2, 0, dtype=torch.long)
+    elif kind == "single":
+        n = 1; ei = torch.tensor([[0, 0], [0, 0]])
+    elif kind == "loops_only":
+        n = 9; ei = torch.arange(9).repeat(2, 1)
+    elif kind == "wide_edge":      # an edge spanning more than a tile can hold: not tileable
+        n = 2000; ei = torch.tensor([[0, 1999, 5, 6], [1999, 0, 6, 5]])
+    else:                          # the size limits themselves
+        n = 4096; ei = _random_graph(n, 2048, 44, symmetric=True)
+        assert ei.shape[1] == 4096
+    eid = ei.to(dev)
+    plans = []
+    for off in ("1", "0"):
+        monkeypatch.setenv("GCONV_NO_SMALL_BUILD", off)
+        plans.append(_plan_arrays(ga.GraphPlan(eid, n, normalize)))
+    _same(plans[0], plans[1])
+    if kind == "hub":
+        assert plans[1]["fwd"]["n_long"] >= 1
+    if kind == "directed":
+        assert not plans[1]["symmetric"]
+    # a bad endpoint is reported, never a fault, by both builders
+    if ei.shape[1]:
+        bad = ei.clone(); bad[0, 0] = n
+        for off in ("1", "0"):
+            monkeypatch.setenv("GCONV_NO_SMALL_BUILD", off)
+            with pytest.raises(RuntimeError, match="outside"):
+                ga.GraphPlan(bad.to(dev), n, normalize)
