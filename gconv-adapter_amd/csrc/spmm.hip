@@ -24,32 +24,62 @@ namespace gconv {
 // ---------------------------------------------------------------------------
 // Epilogue shared by the row path and the long-row completion of the row kernel.
 //   `sum` = plain sum over the row's stored edges of the gathered rows.
+// Its operands (dis, the row's own H line, bias, saved activation) do not depend on the gathers:
+// the row path requests them BEFORE walking the edge list (load_row_operands), so that their
+// latency passes under the gathers instead of forming a second dependent round trip at the end
+// of every wave's short life (round 2; the epilogue used to issue them itself).
 // ---------------------------------------------------------------------------
+struct RowOperands {
+  float di;
+  f32x4 self, bias, saved;
+};
+
+template <int F, bool NORM, int EPI>
+__device__ __forceinline__ RowOperands load_row_operands(const SpmmArgs& a, int rowc, int sub) {
+  RowOperands o;
+  const size_t off = static_cast<size_t>(rowc) * F + 4 * sub;
+  o.di = 1.f;
+  o.self = o.bias = o.saved = zero4();
+  if (NORM) {
+    o.di = a.dis[rowc];
+    o.self = ldg4(a.H + off);
+  }
+  if (EPI == EPI_GENERIC) {
+    if (a.bias) o.bias = ldg4(a.bias + 4 * sub);          // (uniform branch)
+  } else if (EPI == EPI_FWD1) {
+    if (a.bias) {                                         // clamped addresses, masked in the epilogue
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o.bias[k] = a.bias[min(4 * sub + k, a.rank - 1)];
+    }
+  } else if (EPI == EPI_BWD1) {
+    if (a.act != GCONV_ACT_NONE) o.saved = ldg4(a.saved + off);
+  }
+  return o;
+}
+
 template <int F, bool NORM, int EPI>
 __device__ __forceinline__ void spmm_epilogue(const SpmmArgs& a, int row, int sub, f32x4 sum,
-                                              f32x4& bias_grad) {
-  constexpr int LPR = RowShape<F>::LPR;
+                                              f32x4& bias_grad, const RowOperands& o) {
   const size_t off = static_cast<size_t>(row) * F + 4 * sub;
-  float di = 1.f;
+  const float di = o.di;
   f32x4 v = sum;
   if (NORM) {
-    di = a.dis[row];
-    f32x4 self = ldg4(a.H + off);
+    f32x4 self = o.self;
     if (EPI == EPI_GENERIC && !(a.flags & GCONV_SPMM_IN_PRESCALED)) self *= di;
     v = (sum + self) * di;
   }
   if (EPI == EPI_STORE) {
     stg4(a.Y + off, v);
   } else if (EPI == EPI_GENERIC) {
-    if (a.bias) v += ldg4(a.bias + 4 * sub);
+    if (a.bias) v += o.bias;
     for (int k = 0; k < 4; ++k) v[k] = act_fwd(a.act, v[k]);
     if (NORM && (a.flags & GCONV_SPMM_OUT_PRESCALE)) v *= di;
     stg4(a.Y + off, v);
   } else if (EPI == EPI_FWD1) {
     // h1 = v + b_down ; h2 = act(h1) ; store h2 (row-scaled for the next hop)
     for (int k = 0; k < 4; ++k) {
-      int c = 4 * sub + k;
-      if (a.bias && c < a.rank) v[k] += a.bias[c];
+      const int c = 4 * sub + k;
+      v[k] = (a.bias && c < a.rank) ? v[k] + o.bias[k] : v[k];
     }
     if (a.act == GCONV_ACT_SILU && a.Y2) stg4(a.Y2 + off, v);
     for (int k = 0; k < 4; ++k) v[k] = act_fwd(a.act, v[k]);
@@ -57,17 +87,16 @@ __device__ __forceinline__ void spmm_epilogue(const SpmmArgs& a, int row, int su
     stg4(a.Y + off, v);
   } else {  // EPI_BWD1: dh1 = dh2 * act'(h1); accumulate bias grad; store row-scaled dh1
     if (a.act == GCONV_ACT_RELU) {
-      f32x4 h2 = ldg4(a.saved + off);  // dis * relu(h1): same sign pattern as relu(h1)
+      const f32x4 h2 = o.saved;  // dis * relu(h1): same sign pattern as relu(h1)
       for (int k = 0; k < 4; ++k) v[k] = h2[k] > 0.f ? v[k] : 0.f;
     } else if (a.act == GCONV_ACT_SILU) {
-      f32x4 h1 = ldg4(a.saved + off);
+      const f32x4 h1 = o.saved;
       for (int k = 0; k < 4; ++k) v[k] *= silu_grad(h1[k]);
     }
     bias_grad += v;
     if (NORM) v *= di;
     stg4(a.Y + off, v);
   }
-  (void)LPR;
 }
 
 // Sums `bias_grad` over the lanes of a block that own the same column slot and
@@ -160,7 +189,8 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(SpmmArgs a) {
           for (int q = 0; q < 4; ++q) sum[q] += __shfl_xor(sum[q], off);
         }
         if (grp == 0) {
-          spmm_epilogue<F, NORM, EPI>(a, row, sub, sum, bias_grad);
+          const RowOperands ops = load_row_operands<F, NORM, EPI>(a, row, sub);
+          spmm_epilogue<F, NORM, EPI>(a, row, sub, sum, bias_grad, ops);
           // the row's bias-gradient term goes to the row's OWN partial slot, whichever wave
           // completes it: the later reduction adds the same numbers in the same order every run
           if (EPI == EPI_BWD1) stg4(a.bias_partial + static_cast<size_t>(a.row_blocks + lr) * F + 4 * sub, bias_grad);
@@ -180,8 +210,9 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(SpmmArgs a) {
   const bool mine = row < a.row_hi && (e1 - e0) <= GCONV_LONG_ROW;  // long rows: segment path
   const int deg = mine ? e1 - e0 : 0;
 
+  const RowOperands ops = load_row_operands<F, NORM, EPI>(a, rowc, sub);   // in flight under the gathers
   const f32x4 sum = row_gather_sum<F>(H, col, e0, e1, deg, rowc, sub, grp, gather_scale, a.dis);
-  if (mine) spmm_epilogue<F, NORM, EPI>(a, row, sub, sum, bias_grad);
+  if (mine) spmm_epilogue<F, NORM, EPI>(a, row, sub, sum, bias_grad, ops);
   if (EPI == EPI_BWD1) block_bias_partial<F>(bias_grad, a.bias_partial + static_cast<size_t>(rblock) * F);
 }
 
