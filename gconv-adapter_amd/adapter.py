@@ -126,9 +126,19 @@ class GConvAdapter(nn.Module):
     def _forward_2d(self, x2d: torch.Tensor, edge_index: torch.Tensor, fuse_scalar: bool) -> torch.Tensor:
         plan = get_plan(edge_index, x2d.shape[0], self.normalize)
         p = self.__dict__.get("_flat_params")
-        if p is None:   # Parameter objects are stable across .to() / load_state_dict()
+        if p is not None:
+            # Parameter objects survive .to() / load_state_dict() / optimizer steps, but a caller may
+            # REPLACE one (module surgery, `adapter.scalar = nn.Parameter(...)`): five dict look-ups
+            # and identity tests per call keep the cache honest
+            d = p[6]
+            if not (d[0].get("weight") is p[0] and d[1].get("bias") is p[1] and d[2].get("weight") is p[2]
+                    and d[3].get("bias") is p[3] and d[4].get("scalar") is p[4]):
+                p = None
+        if p is None:
             p = (self.conv_down.lin.weight, self.conv_down.bias, self.conv_up.lin.weight,
-                 self.conv_up.bias, self.scalar, _lib.ACT_CODES[self.non_linearity])
+                 self.conv_up.bias, self.scalar, _lib.ACT_CODES[self.non_linearity],
+                 (self.conv_down.lin._parameters, self.conv_down._parameters, self.conv_up.lin._parameters,
+                  self.conv_up._parameters, self._parameters))
             self.__dict__["_flat_params"] = p
         ext = _torch_ext.get()
         if ext is None:   # pure-Python binding of the same C ABI

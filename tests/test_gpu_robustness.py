@@ -272,3 +272,23 @@ def test_distributed_data_parallel_wrapper_gets_its_hooks(dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_replaced_parameter_is_picked_up(dev):
+    """Module surgery after the first forward (`adapter.scalar = nn.Parameter(...)`, a re-created
+    weight): the per-instance cache of Parameter objects must not keep computing with the old ones."""
+    batch, flags, params, mod, g = _setup(dev, seed=13)
+    ei = batch.edge_index.to(dev)
+    x = batch.x.to(dev)
+    with torch.no_grad():
+        before = mod(x, ei)
+    mod.scalar = torch.nn.Parameter(torch.tensor([0.25], device=dev))
+    mod.conv_up.bias = torch.nn.Parameter(mod.conv_up.bias.detach() + 1.0)
+    params2 = dict(params)
+    params2["scalar"] = torch.tensor([0.25], dtype=torch.float64)
+    params2["conv_up.bias"] = params["conv_up.bias"] + 1.0
+    xg = x.clone().requires_grad_(True)
+    out = mod(xg, ei)
+    out.backward(g.to(dev))
+    assert not torch.allclose(out.detach(), before)
+    _check_against_oracle(mod, batch, flags, params2, g, xg, out)
