@@ -246,6 +246,17 @@ class RowSlabGConvAdapter(GConvAdapter):
     ``layer_norm`` is row-local and exact; ``batch_norm`` would use per-rank statistics (the
     reference's transductive inputs are [1, N, d], where it is skipped: ``:98-100``)."""
 
+    #: a copy (deepcopy / pickle / torch.save) keeps its partition only if it is default-group based:
+    #: a process-group handle cannot travel, so the group is dropped and the copy re-partitions
+    _TRANSIENT = GConvAdapter._TRANSIENT + ("_group",)
+
+    def __getstate__(self):
+        state = super().__getstate__()
+        if self.__dict__.get("_group") is not None:   # partition of a sub-group: call partition() again
+            state.pop("_slabs", None)
+            state.pop("_reduce_grads", None)
+        return state
+
     def partition(self, num_nodes: int, group=None, world: Optional[int] = None,
                   rank: Optional[int] = None, reduce_param_grads: bool = False) -> RowSlabs:
         if world is None:

@@ -274,3 +274,16 @@ def test_copies_drop_the_per_instance_caches():
         assert twin.conv_down.lin.weight is not mod.conv_down.lin.weight
     assert "_flat_params" in mod.__dict__
     del mod.__dict__["_flat_params"], mod.__dict__["_anchor"]
+
+
+def test_row_slab_adapter_copies_drop_the_process_group():
+    """A RowSlabGConvAdapter partitioned over the default group keeps its slabs through a deepcopy;
+    one partitioned over an explicit group drops handle and slabs (the copy must call partition())."""
+    import copy
+    m = ga.RowSlabGConvAdapter(32, 4)
+    m.partition(100, world=2, rank=1)
+    c = copy.deepcopy(m)
+    assert (c.__dict__["_slabs"].lo, c.__dict__["_slabs"].hi) == (50, 100) and "_group" not in c.__dict__
+    m.__dict__["_group"] = object()           # stands in for a ProcessGroup (not picklable)
+    c = copy.deepcopy(m)
+    assert "_slabs" not in c.__dict__ and "_group" not in c.__dict__
