@@ -191,3 +191,65 @@ def test_gin_shares_the_batch_plan_with_the_adapters_and_validates_attributes(de
         layer(x, ei, bad2)
     with pytest.raises(RuntimeError, match="edge_attr must be int64"):
         layer(x, ei, ea.float())
+
+
+# ---------------------------------------------------------------------------
+# NodeFormer's relational bias on the adapter's SpMM
+# ---------------------------------------------------------------------------
+def test_relational_bias_restatement_matches_dense_form():
+    """CPU: oracle/nodeformer_rb_restated.py (index_add form of nodeformer.py:202-224) against the
+    dense matrix D_in^-1/2 A_in D_out^-1/2 with duplicates, a loop and a directed edge."""
+    from oracle import nodeformer_rb_restated as rb
+    n = 7
+    ei = torch.tensor([[0, 1, 1, 2, 3, 3, 5, 6, 0], [1, 0, 2, 1, 3, 4, 5, 6, 1]])
+    x = torch.randn(1, n, 2, 4, dtype=torch.float64, generator=torch.Generator().manual_seed(0))
+    b = torch.tensor([0.3, -0.2], dtype=torch.float64)
+    out = rb.add_conv_relational_bias(x, ei, b)
+    row, col = ei
+    din = torch.bincount(col, minlength=n).double()
+    dout = torch.bincount(row, minlength=n).double()
+    a = torch.zeros(n, n, dtype=torch.float64)
+    for r, c in zip(row.tolist(), col.tolist()):
+        a[c, r] += (1 / din[c]).sqrt() * (1 / dout[r]).sqrt()
+    for i in range(2):
+        assert torch.allclose(out[0, :, i], torch.sigmoid(b[i]) * a @ x[0, :, i], atol=1e-14)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("heads,d,trans,kind", [(1, 32, "sigmoid", "adjs0"), (2, 32, "sigmoid", "adjs0"),
+                                                (4, 32, "identity", "adjs1"), (1, 16, "sigmoid", "directed")])
+def test_relational_bias_matches_restatement(dev, heads, d, trans, kind):
+    """ga.add_conv_relational_bias (row scaling, ONE unnormalised CSR product, row scaling) against the
+    restated reference function: output, d x and d b — on the adjacencies the transductive script
+    builds (`finetune_transductive_learning.py:110-119`: loops re-added, then its square's pattern)
+    and on a directed list with duplicates (separate in / out degrees)."""
+    import gconv_adapter_amd as ga
+    from oracle import nodeformer_rb_restated as rb
+    g = torch.Generator().manual_seed(3)
+    n = 600
+    if kind == "directed":
+        ei = torch.stack([torch.randint(n, (4000,), generator=g), torch.randint(n, (4000,), generator=g)])
+    else:
+        u = torch.randint(n, (1500,), generator=g); v = torch.randint(n, (1500,), generator=g)
+        keep = u != v
+        und = torch.unique(torch.cat([torch.stack([u[keep], v[keep]]), torch.stack([v[keep], u[keep]])], 1), dim=1)
+        loops = torch.arange(n).repeat(2, 1)
+        ei = torch.cat([und, loops], 1)
+        if kind == "adjs1":   # pattern of the square (adj_mul, data_utils.py:208-213)
+            a = torch.zeros(n, n); a[ei[0], ei[1]] = 1
+            ei = (a @ a).nonzero().t().contiguous()
+    x = torch.randn(1, n, heads, d, generator=g)
+    b = torch.randn(heads, generator=g) * 0.5
+    gout = torch.randn(1, n, heads, d, generator=g)
+    x64 = x.double().requires_grad_(True); b64 = b.double().requires_grad_(True)
+    want = rb.add_conv_relational_bias(x64, ei, b64, trans)
+    want.backward(gout.double())
+    xd = x.to(dev).requires_grad_(True); bd = b.to(dev).requires_grad_(True)
+    got = ga.add_conv_relational_bias(xd, ei.to(dev), bd, trans)
+    got.backward(gout.to(dev))
+    def close(a, w, what, atol=1e-5):
+        err = (a.detach().cpu().double() - w).abs()
+        assert bool((err <= atol + 1e-5 * w.abs()).all()), f"{what}: max err {err.max().item():.3e}"
+    close(got, want.detach(), "out")
+    close(xd.grad, x64.grad, "dx")
+    close(bd.grad, b64.grad, "db", atol=1e-5 * max(1.0, float(b64.grad.abs().max())))
