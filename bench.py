@@ -98,8 +98,9 @@ class BatchStream:
     started before the current step's adapters run, so it overlaps them — the role the
     DataLoader's prefetching workers play for collation in the reference."""
 
-    def __init__(self, name: str, rank: int, device, k: int, fresh: bool):
+    def __init__(self, name: str, rank: int, device, k: int, fresh: bool, prefetch: bool = True):
         self.fresh = fresh
+        self.prefetch = prefetch   # False: the plan is built in-stream by the step's first adapter
         self.items = []
         cfg = None
         for i in range(k if fresh else 1):
@@ -117,7 +118,7 @@ class BatchStream:
     def next(self, normalize: bool):
         batch, x, ei, gout = self.items[self.pos % len(self.items)]
         self.pos += 1
-        if self.fresh:  # start the next batch's graph build now
+        if self.fresh and self.prefetch:  # start the next batch's graph build now
             nb, nx, nei, _ = self.items[self.pos % len(self.items)]
             ga.prefetch_plan(nei, nx.shape[-2], normalize)
         return batch, x, ei, gout
@@ -453,6 +454,32 @@ def measure_transductive(device, name: str) -> dict:
             f"{name}_adapter_fwd_us": round(fwd_ms * 1e3, 1), f"{name}_adapter_bwd_us": round(bwd_ms * 1e3, 1)}
 
 
+def measure_no_prefetch_step(device, normalize: bool, name: str = "esol", steps: int = 200) -> dict:
+    """The reference's own batch size with NO change to its train loop: nobody calls `prefetch_plan`,
+    every batch's graph plan is built in-stream, synchronously, by the step's first adapter (K0 on the
+    critical path: the case the single-workgroup builder is for)."""
+    stream = BatchStream(name, 0, device, 4, fresh=True, prefetch=False)
+    cfg = stream.cfg
+    mods = build_adapters(cfg, normalize, device)
+    params = [p for m in mods for p in m.parameters()]
+
+    def step():
+        adapter_step(mods, params, stream, normalize, None)
+    for _ in range(300):
+        step()
+    best = 1e9
+    for _ in range(3):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(device)
+        best = min(best, (time.perf_counter() - t0) / steps)
+    ga.PLAN_CACHE.clear()
+    return {f"{name}_no_prefetch_ms_per_step": round(best * 1e3, 4),
+            f"{name}_no_prefetch_graphs_per_s": round(stream.avg("num_graphs") / best, 1)}
+
+
 def measure_graph_build(device) -> dict:
     """K0 for molecule batches, in-stream and synchronous (what a caller that does NOT use
     `prefetch_plan` pays in front of a batch's first adapter): wall time per `GraphPlan` for the
@@ -773,6 +800,7 @@ def main() -> None:
             extra.update(measure_gin(device))
             extra.update(measure_arxiv_projections(device))
             extra.update(measure_graph_build(device))
+            extra.update(measure_no_prefetch_step(device, normalize))
             for tname in ("cora", "pubmed"):
                 extra.update(measure_transductive(device, tname))
             other = "esol" if args.workload != "esol" else "hiv"

@@ -172,8 +172,41 @@ def local_core_set(local_rank: int = 0, local_world: int = 1, cores_per_rank: in
     phys = node_cpus[:max(len(node_cpus) // 2, 1)] if len(node_cpus) >= 2 * cores_per_rank else node_cpus
     slot = sum(1 for g in range(local_rank) if nodes[g] == node)
     per = max(1, min(cores_per_rank, len(phys) // max(1, nodes.count(node))))
+    if local_world == 1:
+        # A single process per container: every tenant of a shared host that reasons like this
+        # function would land on the SAME first cores of the node (seen as 0.23 -> 0.29 ms steps when
+        # two boxes of one host ran at once). Take the least busy aligned block of cores instead.
+        return _least_busy_block(phys, per)
     start = (slot * per) % max(len(phys) - per + 1, 1)
     return phys[start:start + per]
+
+
+def _cpu_busy_jiffies() -> dict:
+    busy = {}
+    try:
+        with open("/proc/stat") as fh:
+            for line in fh:
+                if line.startswith("cpu") and line[3].isdigit():
+                    f = line.split()
+                    vals = [int(v) for v in f[1:9]]
+                    busy[int(f[0][3:])] = sum(vals) - vals[3] - vals[4]   # everything but idle and iowait
+    except (OSError, ValueError, IndexError):
+        pass
+    return busy
+
+
+def _least_busy_block(cpus: List[int], per: int, sample_s: float = 0.05) -> List[int]:
+    """The aligned block of `per` consecutive entries of `cpus` (one CCD's worth of cores share an L3)
+    that was least busy over a short sample of /proc/stat; the first block when nothing can be read."""
+    import time
+    blocks = [cpus[i:i + per] for i in range(0, len(cpus) - per + 1, per)] or [cpus[:per]]
+    a = _cpu_busy_jiffies()
+    if not a:
+        return blocks[0]
+    time.sleep(sample_s)
+    b = _cpu_busy_jiffies()
+    load = [sum(b.get(c, 0) - a.get(c, 0) for c in blk) for blk in blocks]
+    return blocks[min(range(len(blocks)), key=lambda i: (load[i], i))]
 
 
 def pin_to_local_cores(local_rank: Optional[int] = None, local_world: Optional[int] = None,
