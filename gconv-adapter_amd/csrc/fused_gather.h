@@ -35,7 +35,8 @@ struct BwdGatherArgs {
 gconv_status_t launch_bwd_gather(const BwdGatherArgs& a, hipStream_t stream);
 
 // the fused launches are used for graphs of up to GCONV_FUSED_GATHER_MAX_NODES nodes (default
-// 65536) unless GCONV_NO_FUSED_GATHER is set (A/B knob: the separate K2' / K3 and B3 / B4 launches)
-bool fused_gather_enabled(int num_nodes);
+// 65536) WITHOUT long rows, unless GCONV_NO_FUSED_GATHER is set (A/B knob: the separate K2' / K3 and
+// B3 / B4 launches; GCONV_FUSED_GATHER_MAX_NODES set explicitly also lifts the long-row condition)
+bool fused_gather_enabled(const gconv_csr_t* graph);
 
 }  // namespace gconv

@@ -9,9 +9,8 @@
 // K2 -> K2', which needs ALL rows of H2'). A workgroup requests its X tile, gathers the P rows
 // of the same nodes meanwhile, parks them in LDS (and in HBM for the backward) and multiplies:
 // one launch and one kernel boundary less, which is what a Cora / PubMed-sized graph is made of
-// (forward 21 -> 15 us). At S-arxiv scale the separate launches stay faster (124 against 130 us:
-// a workgroup waits at its barrier for the wave with the longest rows) — see
-// fused_gather_enabled(). Rows longer than GCONV_LONG_ROW edges keep their segment path (a small launch of
+// (forward 21 -> 15 us). On graphs with hub rows the separate launches stay faster at every size
+// — see fused_gather_enabled(). Rows longer than GCONV_LONG_ROW edges keep their segment path (a small launch of
 // the SpMM's segment blocks in front); every other row is summed by row_gather_sum — the same
 // code, hence the same bits, as the stand-alone SpMM.
 #include <cstdlib>
@@ -21,15 +20,19 @@
 
 namespace gconv {
 
-// Read per call: tests and tools flip the knobs inside one process. Above the node limit the
-// separate launches win (S-arxiv forward 124 us against 130 fused: a workgroup waits at its
-// barrier for the wave with the longest rows, a stand-alone SpMM wave only delays itself);
-// below it the launch that disappears is what counts (Cora forward 21 -> 15 us).
-bool fused_gather_enabled(int num_nodes) {
+// Read per call: tests and tools flip the knobs inside one process. Measured (tools/lab/
+// fuse_threshold.py, tools/fusebench.py): on uniform low-degree graphs of Cora / PubMed size the
+// launch that disappears is what counts (forward 21 -> 15 us, backward 5 + 2 -> 4 + 1 launches); on
+// power-law graphs (S-arxiv's generator at 8 k ... 170 k nodes, d = 128) the separate launches win
+// at every size (8 k nodes: 29 against 34 us forward; 170 k: 117 against 125) — a workgroup waits
+// at its barrier for the wave with the longest rows, a stand-alone SpMM wave only delays itself.
+// Hence: up to 65536 nodes AND no row above GCONV_LONG_ROW edges.
+bool fused_gather_enabled(const gconv_csr_t* graph) {
   const char* v = std::getenv("GCONV_NO_FUSED_GATHER");
   if (!(v == nullptr || v[0] == '\0' || v[0] == '0')) return false;
   const char* m = std::getenv("GCONV_FUSED_GATHER_MAX_NODES");
-  return num_nodes <= (m ? std::atoi(m) : 65536);
+  if (m) return graph->num_nodes <= std::atoi(m);
+  return graph->num_nodes <= 65536 && graph->n_long == 0;
 }
 
 static int env_int(const char* name, int dflt) {

@@ -7,6 +7,7 @@ import torch
 import gconv_adapter_amd as ga
 
 dev = torch.device("cuda:0")
+os.environ.setdefault("GCONV_FUSED_GATHER_MAX_NODES", "100000000")   # force the fused path in "fused" mode
 
 
 def ev(fn, iters=30, warm=5):
