@@ -355,7 +355,8 @@ BwdMainGeom bwd_main_geom(int n, int d) {
   // node block per wave slot: a Cora / PubMed-sized graph is latency-bound and wants every CU it
   // can fill (PubMed: 39 workgroups x 4 blocks per wave 16.7 us -> 155 workgroups), the partial
   // write-out it multiplies is a few KB per workgroup
-  int grid = ceil_div(nblk, g.nslots);
+  static const int per_slot = std::getenv("GCONV_B4_BLOCKS_PER_SLOT") ? std::atoi(std::getenv("GCONV_B4_BLOCKS_PER_SLOT")) : 1;
+  int grid = ceil_div(nblk, per_slot * g.nslots);
   if (grid > kNumCU) grid = kNumCU;
   if (grid < 1) grid = 1;
   g.grid = grid;
