@@ -210,7 +210,7 @@ static gconv_status_t fwd_stages(const gconv_graph_t* gr, const gconv_adapter_pa
     SpmmArgs k2b{};
     k2b.dis = dis; k2b.H = saved_h; k2b.Y = saved_p; k2b.rank = r; k2b.seg_partial = seg;
     k2b.row_lo = lo; k2b.row_hi = hi;
-    if (lo == 0 && hi == graph->num_nodes && fused_gather_enabled(graph)) {
+    if (lo == 0 && hi == graph->num_nodes && fused_gather_enabled(graph, d)) {
       // K2' + K3 in one launch (fused_gather.hip); only the long rows' segments run in front
       if (graph->n_seg > 0) {
         k2b.seg_only = 1;
@@ -321,7 +321,7 @@ static gconv_status_t bwd_stages(const gconv_graph_t* gr, const gconv_adapter_pa
     b4.part_wd = ws.part_wd; b4.part_wu = ws.part_wu; b4.part_cs = ws.part_cs;
     b4.part_dsx = ws.part_dsx;
     b4.n = n; b4.d = d; b4.r = r; b4.fp = fp; b4.skip = p->skip;
-    if (lo == 0 && hi == graph_t->num_nodes && fused_gather_enabled(graph_t)) {
+    if (lo == 0 && hi == graph_t->num_nodes && fused_gather_enabled(graph_t, d)) {
       // B3 + B4 in one launch (fused_gather.hip); only the long rows' segments run in front
       if (graph_t->n_seg > 0) {
         b3.seg_only = 1;

@@ -34,9 +34,9 @@ struct BwdGatherArgs {
 };
 gconv_status_t launch_bwd_gather(const BwdGatherArgs& a, hipStream_t stream);
 
-// the fused launches are used for graphs of up to GCONV_FUSED_GATHER_MAX_NODES nodes (default
-// 65536) WITHOUT long rows, unless GCONV_NO_FUSED_GATHER is set (A/B knob: the separate K2' / K3 and
-// B3 / B4 launches; GCONV_FUSED_GATHER_MAX_NODES set explicitly also lifts the long-row condition)
-bool fused_gather_enabled(const gconv_csr_t* graph);
+// the fused launches are used for graphs WITHOUT long rows whose [N, hidden] operand has at most
+// 2.5 M elements (10 MB), unless GCONV_NO_FUSED_GATHER is set (A/B knob: the separate K2' / K3 and
+// B3 / B4 launches); GCONV_FUSED_GATHER_MAX_NODES, when set, replaces both conditions by a node limit
+bool fused_gather_enabled(const gconv_csr_t* graph, int hidden);
 
 }  // namespace gconv

@@ -26,13 +26,17 @@ namespace gconv {
 // power-law graphs (S-arxiv's generator at 8 k ... 170 k nodes, d = 128) the separate launches win
 // at every size (8 k nodes: 29 against 34 us forward; 170 k: 117 against 125) — a workgroup waits
 // at its barrier for the wave with the longest rows, a stand-alone SpMM wave only delays itself.
-// Hence: up to 65536 nodes AND no row above GCONV_LONG_ROW edges.
-bool fused_gather_enabled(const gconv_csr_t* graph) {
+// On uniform graphs (tools/lab/fuse_uniform.py) the fused launches win while the [N, d] streams are
+// small — d = 32 up to 65 k nodes, d = 128 up to ~20 k, d = 300 up to ~8 k — and lose beyond
+// (d = 300, 40 k nodes: 45 -> 50 us forward, 70 -> 80 backward): one launch less is worth a few
+// microseconds, not a pipeline stall per super-block. Hence: no row above GCONV_LONG_ROW edges AND
+// N * d <= 2.5 M elements.
+bool fused_gather_enabled(const gconv_csr_t* graph, int hidden) {
   const char* v = std::getenv("GCONV_NO_FUSED_GATHER");
   if (!(v == nullptr || v[0] == '\0' || v[0] == '0')) return false;
   const char* m = std::getenv("GCONV_FUSED_GATHER_MAX_NODES");
   if (m) return graph->num_nodes <= std::atoi(m);
-  return graph->num_nodes <= 65536 && graph->n_long == 0;
+  return graph->n_long == 0 && static_cast<int64_t>(graph->num_nodes) * hidden <= 2500000;
 }
 
 static int env_int(const char* name, int dflt) {
