@@ -832,6 +832,8 @@ static int tile_threads_bwd(int d) {
   return 64 * w;
 }
 
+constexpr size_t kTileMaxLds = 144 * 1024;
+
 size_t tile_lds_bytes(int d, int fp, int tile_nodes_max, int tile_edges_max) {
   const int nq = tile_nq(d), ncb = fp >= 16 ? fp / 16 : 1;
   const int cap = ceil_div(tile_nodes_max > 0 ? tile_nodes_max : 1, 16) * 16;
@@ -853,14 +855,28 @@ bool tile_path_ok(const gconv_graph_t* g, int d, int fp) {
   if ((fp >= 32 && tile_nq(d) > 19) || (fp >= 16 && tile_nq(d) > 24)) return false;
   static const bool off = getenv("GCONV_NO_TILE_PATH") != nullptr;  // debugging / A-B knob
   if (off) return false;
-  return tile_lds_bytes(d, fp, g->tile_nodes_max, g->tile_edges_max) <= 64 * 1024;
+  // one workgroup per CU: the tile state may take most of the CU's 160 KB (round 1 stopped at 64 KB,
+  // which sent a batch with one 150-atom molecule at rank 16 down the multi-launch path)
+  return tile_lds_bytes(d, fp, g->tile_nodes_max, g->tile_edges_max) <= kTileMaxLds;
 }
+
+#define GCONV_TILE_LDS_OPT_IN(KERNEL)                                                          \
+  do {                                                                                         \
+    if (lds > 48 * 1024)                                                                       \
+      GCONV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL),                    \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds))); \
+  } while (0)
 
 template <int FP, int NQ>
 static gconv_status_t launch_tile_fwd_t(const TileFwdArgs& a, int grid, int threads, size_t lds,
                                         hipStream_t stream) {
-  if (a.dis) tile_fwd_kernel<FP, NQ, true><<<grid, threads, lds, stream>>>(a);
-  else tile_fwd_kernel<FP, NQ, false><<<grid, threads, lds, stream>>>(a);
+  if (a.dis) {
+    GCONV_TILE_LDS_OPT_IN((tile_fwd_kernel<FP, NQ, true>));
+    tile_fwd_kernel<FP, NQ, true><<<grid, threads, lds, stream>>>(a);
+  } else {
+    GCONV_TILE_LDS_OPT_IN((tile_fwd_kernel<FP, NQ, false>));
+    tile_fwd_kernel<FP, NQ, false><<<grid, threads, lds, stream>>>(a);
+  }
   GCONV_LAUNCH_CHECK();
   return GCONV_OK;
 }
@@ -869,11 +885,21 @@ template <int FP, int NQ>
 static gconv_status_t launch_tile_bwd_t(const TileBwdArgs& a, int grid, int threads, size_t lds,
                                         hipStream_t stream) {
   if (a.dis) {
-    if (a.dx) tile_bwd_kernel<FP, NQ, true, true><<<grid, threads, lds, stream>>>(a);
-    else tile_bwd_kernel<FP, NQ, true, false><<<grid, threads, lds, stream>>>(a);
+    if (a.dx) {
+      GCONV_TILE_LDS_OPT_IN((tile_bwd_kernel<FP, NQ, true, true>));
+      tile_bwd_kernel<FP, NQ, true, true><<<grid, threads, lds, stream>>>(a);
+    } else {
+      GCONV_TILE_LDS_OPT_IN((tile_bwd_kernel<FP, NQ, true, false>));
+      tile_bwd_kernel<FP, NQ, true, false><<<grid, threads, lds, stream>>>(a);
+    }
   } else {
-    if (a.dx) tile_bwd_kernel<FP, NQ, false, true><<<grid, threads, lds, stream>>>(a);
-    else tile_bwd_kernel<FP, NQ, false, false><<<grid, threads, lds, stream>>>(a);
+    if (a.dx) {
+      GCONV_TILE_LDS_OPT_IN((tile_bwd_kernel<FP, NQ, false, true>));
+      tile_bwd_kernel<FP, NQ, false, true><<<grid, threads, lds, stream>>>(a);
+    } else {
+      GCONV_TILE_LDS_OPT_IN((tile_bwd_kernel<FP, NQ, false, false>));
+      tile_bwd_kernel<FP, NQ, false, false><<<grid, threads, lds, stream>>>(a);
+    }
   }
   GCONV_LAUNCH_CHECK();
   return GCONV_OK;

@@ -325,10 +325,31 @@ def test_adapter_tile_path_large_components(dev):
     ptr = torch.tensor([0] + list(np.cumsum(sizes)))
     batch = ga.synth.GraphBatch(x=x, edge_index=ei, graph_ptr=ptr, num_graphs=len(sizes))
     plan = ga.GraphPlan(ei.to(dev), off, True)
-    assert plan.n_tiles > 0 and plan.tile_nodes_max >= 400      # the fused tile path takes it
+    lib = ga._lib.load()
+    assert plan.n_tiles > 0 and plan.tile_nodes_max >= 400
+    # the fused tile path takes it: its forward "workspace" is the nominal 256 bytes (83 KB of LDS per
+    # workgroup at rank 8 — above round 1's 64 KB limit, which silently chose the multi-launch path)
+    assert plan.sizes(lib, 300, 8)[1] == 256
     for normalize in (True, False):
         flags = oracle.AdapterFlags(learnable_scalar=True, normalize=normalize)
         _check_workload(dev, batch, 300, 8, flags)
+    # rank 16 (the reference's YAML default) with a 230-atom molecule in the batch: 87 KB of LDS
+    keep = torch.tensor([i for i in range(len(sizes))])
+    sizes2 = [230, 12, 1, 25, 31]
+    src, dst, off2 = [], [], 0
+    for n in sizes2:
+        if n > 1:
+            a = torch.arange(n)
+            e = torch.stack([a, (a + 1) % n])
+            e = torch.cat([e, e.flip(0)], dim=1) + off2
+            src.append(e[0]); dst.append(e[1])
+        off2 += n
+    ei2 = torch.stack([torch.cat(src), torch.cat(dst)])
+    batch2 = ga.synth.GraphBatch(x=torch.randn(off2, 300, generator=gen), edge_index=ei2,
+                                 graph_ptr=torch.tensor([0] + list(np.cumsum(sizes2))), num_graphs=len(sizes2))
+    plan2 = ga.GraphPlan(ei2.to(dev), off2, True)
+    assert plan2.tile_nodes_max >= 230 and plan2.sizes(lib, 300, 16)[1] == 256
+    _check_workload(dev, batch2, 300, 16, oracle.AdapterFlags(learnable_scalar=True, normalize=True))
 
 
 def test_adapter_many_tiles_per_workgroup(dev):
