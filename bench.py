@@ -50,6 +50,14 @@ import torch.distributed as dist  # noqa: E402
 # addmm path blocks the host at every call until the GPU has caught up (the step ran at GPU time +
 # host time, 3.3 ms); with rocBLAS the host runs ahead again (2.4 ms). Read at the first addmm.
 os.environ.setdefault("DISABLE_ADDMM_HIP_LT", "1")
+# ... and PyTorch's TunableOp picks the library GEMM kernel per shape: at [13104, 300] x [300, 600] the
+# default rocBLAS choice runs at 60-69 TFLOP/s fp32, the tuned one at 82-92 (tools/lab/mlp_gemm.py).
+# Only the fine-tune step of the extras contains torch GEMMs; the tuning result goes to /tmp.
+os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
+os.environ.setdefault("PYTORCH_TUNABLEOP_VERBOSE", "0")
+os.environ.setdefault("PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS", "100")
+os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", os.path.join(os.environ.get("TMPDIR", "/tmp"),
+                                                                 "gconv_bench_tunableop_%d.csv"))
 import gconv_adapter_amd as ga  # noqa: E402
 
 RESIDENT = 0
