@@ -56,8 +56,12 @@ enum { GCONV_ACT_NONE = 0, GCONV_ACT_RELU = 1, GCONV_ACT_SILU = 2 };
 
 /* rows with more than GCONV_LONG_ROW edges are split into segments of
  * GCONV_SEG_EDGES edges that separate waves reduce (deterministic, no atomics) */
+#ifndef GCONV_LONG_ROW      /* (overridable at build time for kernel-variant experiments only) */
 #define GCONV_LONG_ROW  64
+#endif
+#ifndef GCONV_SEG_EDGES
 #define GCONV_SEG_EDGES 128
+#endif
 
 /* ------------------------------------------------------------------------- */
 /* Introspection                                                             */
