@@ -367,6 +367,8 @@ __global__ __launch_bounds__(256) void bn_colsums_kernel(const float* __restrict
 // reduces the partial rows (16 columns x 16 row groups per block, fixed order) and finishes:
 //   STATS: mean, rstd (biased variance), running statistics (unbiased variance, torch's rule)
 //   GRAD : dgamma = sum g' xhat, dbeta = sum g'
+constexpr int kBnFinCl = 4, kBnFinRg = 64;   // columns x row groups of one bn_finalize block (256 threads)
+
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nparts,
                                                           const float* __restrict__ x_row0, int n, int d,
@@ -374,19 +376,23 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float* __restrict__ out0, float* __restrict__ out1,
                                                           float* __restrict__ running_mean,
                                                           float* __restrict__ running_var) {
-  __shared__ float red[2][16][17];
-  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  // 4 columns x 64 row groups per block: a thread adds nparts / 64 partial rows with all its loads
+  // in flight at once, then a fixed-order tree over the row groups. (Round 1: 16 columns x 16 row
+  // groups — 19 blocks for d = 300, each thread walking 32 rows two at a time: 7-8 us of dependent
+  // loads per launch, twice per layer and direction.)
+  __shared__ float red[2][kBnFinRg][kBnFinCl + 1];
+  const int cl = threadIdx.x % kBnFinCl, rg = threadIdx.x / kBnFinCl;
+  const int c = blockIdx.x * kBnFinCl + cl;
   float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
   if (c < d) {
     int r = rg;
-    for (; r + 16 < nparts; r += 32) {
+    for (; r + kBnFinRg < nparts; r += 2 * kBnFinRg) {
       a0 += part[static_cast<size_t>(r) * 2 * d + c];
       b0 += part[static_cast<size_t>(r) * 2 * d + d + c];
-      a1 += part[static_cast<size_t>(r + 16) * 2 * d + c];
-      b1 += part[static_cast<size_t>(r + 16) * 2 * d + d + c];
+      a1 += part[static_cast<size_t>(r + kBnFinRg) * 2 * d + c];
+      b1 += part[static_cast<size_t>(r + kBnFinRg) * 2 * d + d + c];
     }
-    for (; r < nparts; r += 16) {
+    for (; r < nparts; r += kBnFinRg) {
       a0 += part[static_cast<size_t>(r) * 2 * d + c];
       b0 += part[static_cast<size_t>(r) * 2 * d + d + c];
     }
@@ -394,12 +400,15 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   red[0][rg][cl] = a0 + a1;
   red[1][rg][cl] = b0 + b1;
   __syncthreads();
-  if (rg != 0 || c >= d) return;
-  float sa = 0.f, sb = 0.f;
-  for (int k = 0; k < 16; ++k) {
-    sa += red[0][k][cl];
-    sb += red[1][k][cl];
+  for (int w = kBnFinRg / 2; w >= 1; w >>= 1) {   // fixed tree: (k, k + w) pairs, halving
+    if (rg < w) {
+      red[0][rg][cl] += red[0][rg + w][cl];
+      red[1][rg][cl] += red[1][rg + w][cl];
+    }
+    __syncthreads();
   }
+  if (rg != 0 || c >= d) return;
+  const float sa = red[0][0][cl], sb = red[1][0][cl];
   if (MODE == BN_SUMS_STATS) {
     const float inv_n = 1.f / static_cast<float>(n);
     const float m1 = sa * inv_n;                        // mean - x[0]
@@ -537,7 +546,7 @@ extern "C" gconv_status_t gconv_batch_norm_fwd_f32(const float* x, const float* 
   GCONV_BN_DISPATCH((bn_colsums_kernel<NP, BN_SUMS_STATS><<<grid, 256, 0, stream>>>(
       x, nullptr, nullptr, nullptr, nullptr, ws.part, num_nodes, hidden)))
   GCONV_LAUNCH_CHECK();
-  bn_finalize_kernel<BN_SUMS_STATS><<<ceil_div(hidden, 16), 256, 0, stream>>>(
+  bn_finalize_kernel<BN_SUMS_STATS><<<ceil_div(hidden, kBnFinCl), 256, 0, stream>>>(
       ws.part, grid, x, num_nodes, hidden, eps, momentum, save_mean, save_rstd, running_mean, running_var);
   GCONV_LAUNCH_CHECK();
   GCONV_BN_DISPATCH((bn_apply_kernel<NP><<<ceil_div(num_nodes, 4), 256, 0, stream>>>(
@@ -588,7 +597,7 @@ extern "C" gconv_status_t gconv_batch_norm_bwd_f32(const float* grad_y, const fl
   // the column sums are needed by dx whether or not the caller wants them back
   float* dg = grad_gamma ? grad_gamma : ws.dgamma;
   float* db = grad_beta ? grad_beta : ws.dbeta;
-  bn_finalize_kernel<BN_SUMS_GRAD><<<ceil_div(hidden, 16), 256, 0, stream>>>(
+  bn_finalize_kernel<BN_SUMS_GRAD><<<ceil_div(hidden, kBnFinCl), 256, 0, stream>>>(
       ws.part, grid, nullptr, num_nodes, hidden, 0.f, 0.f, dg, db, nullptr, nullptr);
   GCONV_LAUNCH_CHECK();
   if (grad_x) {
