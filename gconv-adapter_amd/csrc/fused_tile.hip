@@ -804,6 +804,7 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
 // ===========================================================================
 // launchers
 // ===========================================================================
+#if !defined(GCONV_TILE_ONLY_FP) || GCONV_TILE_ONLY_FP == 0
 static int tile_nq(int d) {
   static const int kNq[] = {2, 4, 8, 12, 16, 19, 24, 32};
   const int need = ceil_div(d, 16);
@@ -859,6 +860,7 @@ bool tile_path_ok(const gconv_graph_t* g, int d, int fp) {
   // which sent a batch with one 150-atom molecule at rank 16 down the multi-launch path)
   return tile_lds_bytes(d, fp, g->tile_nodes_max, g->tile_edges_max) <= kTileMaxLds;
 }
+#endif  // host side
 
 #define GCONV_TILE_LDS_OPT_IN(KERNEL)                                                          \
   do {                                                                                         \
@@ -905,18 +907,46 @@ static gconv_status_t launch_tile_bwd_t(const TileBwdArgs& a, int grid, int thre
   return GCONV_OK;
 }
 
-#define GCONV_TILE_DISPATCH(FN, ARGS)                                                   \
-  switch (a.fp * 100 + nq) {                                                            \
-    /* molecule ranks first; every (Fp, NQ) pair here is a compiled kernel */           \
-    GCONV_TILE_CASES(FN, ARGS, 4) GCONV_TILE_CASES(FN, ARGS, 8)                          \
-    GCONV_TILE_CASES(FN, ARGS, 16) GCONV_TILE_CASES(FN, ARGS, 32)                        \
+// One entry point per padded rank: every (Fp, NQ) pair below is a compiled kernel. The build
+// compiles this file once per rank (-DGCONV_TILE_ONLY_FP=4|8|16|32: the kernels of that rank and
+// its entry points) plus once for the host side (=0), so that the five pieces compile in
+// parallel; without the define everything lands in one translation unit.
+#define GCONV_TILE_NQ_SWITCH(FN, FP_, ARGS)                                             \
+  switch (nq) {                                                                         \
+    case 2:  return FN<FP_, 2> ARGS;  case 4:  return FN<FP_, 4> ARGS;                  \
+    case 8:  return FN<FP_, 8> ARGS;  case 12: return FN<FP_, 12> ARGS;                 \
+    case 16: return FN<FP_, 16> ARGS; case 19: return FN<FP_, 19> ARGS;                 \
+    case 24: return FN<FP_, 24> ARGS; case 32: return FN<FP_, 32> ARGS;                 \
     default: return GCONV_E_UNSUPPORTED;                                                \
   }
-#define GCONV_TILE_CASES(FN, ARGS, FP_)                                                 \
-  case FP_ * 100 + 2:  return FN<FP_, 2> ARGS;  case FP_ * 100 + 4:  return FN<FP_, 4> ARGS;   \
-  case FP_ * 100 + 8:  return FN<FP_, 8> ARGS;  case FP_ * 100 + 12: return FN<FP_, 12> ARGS;  \
-  case FP_ * 100 + 16: return FN<FP_, 16> ARGS; case FP_ * 100 + 19: return FN<FP_, 19> ARGS;  \
-  case FP_ * 100 + 24: return FN<FP_, 24> ARGS; case FP_ * 100 + 32: return FN<FP_, 32> ARGS;
+template <int FP>
+gconv_status_t launch_tile_fwd_fp(const TileFwdArgs& a, int nq, int grid, int threads, size_t lds, hipStream_t stream);
+template <int FP>
+gconv_status_t launch_tile_bwd_fp(const TileBwdArgs& a, int nq, int grid, int threads, size_t lds, hipStream_t stream);
+#define GCONV_TILE_DEFINE_FP(FP_)                                                                          \
+  template <>                                                                                              \
+  gconv_status_t launch_tile_fwd_fp<FP_>(const TileFwdArgs& a, int nq, int grid, int threads, size_t lds,  \
+                                         hipStream_t stream) {                                             \
+    GCONV_TILE_NQ_SWITCH(launch_tile_fwd_t, FP_, (a, grid, threads, lds, stream))                          \
+  }                                                                                                        \
+  template <>                                                                                              \
+  gconv_status_t launch_tile_bwd_fp<FP_>(const TileBwdArgs& a, int nq, int grid, int threads, size_t lds,  \
+                                         hipStream_t stream) {                                             \
+    GCONV_TILE_NQ_SWITCH(launch_tile_bwd_t, FP_, (a, grid, threads, lds, stream))                          \
+  }
+#if !defined(GCONV_TILE_ONLY_FP)
+GCONV_TILE_DEFINE_FP(4) GCONV_TILE_DEFINE_FP(8) GCONV_TILE_DEFINE_FP(16) GCONV_TILE_DEFINE_FP(32)
+#elif GCONV_TILE_ONLY_FP > 0
+GCONV_TILE_DEFINE_FP(GCONV_TILE_ONLY_FP)
+#endif
+
+#if !defined(GCONV_TILE_ONLY_FP) || GCONV_TILE_ONLY_FP == 0
+#define GCONV_TILE_DISPATCH(FN, ARGS)                                                   \
+  switch (a.fp) {                                                                       \
+    case 4: return FN<4> ARGS;   case 8: return FN<8> ARGS;                             \
+    case 16: return FN<16> ARGS; case 32: return FN<32> ARGS;                           \
+    default: return GCONV_E_UNSUPPORTED;                                                \
+  }
 
 int tile_grid(int n_tiles) {  // persistent: one workgroup per CU
   return n_tiles < kNumCU ? (n_tiles > 0 ? n_tiles : 1) : kNumCU;
@@ -930,7 +960,7 @@ gconv_status_t launch_tile_fwd(TileFwdArgs a, int n_tiles, int tile_nodes_max,
   a.cap = ceil_div(tile_nodes_max > 0 ? tile_nodes_max : 1, 16) * 16;
   const size_t lds = tile_lds_bytes(a.d, a.fp, tile_nodes_max, tile_edges_max);
   const int threads = tile_threads_fwd(a.d, a.fp);
-  GCONV_TILE_DISPATCH(launch_tile_fwd_t, (a, n_tiles, threads, lds, stream))
+  GCONV_TILE_DISPATCH(launch_tile_fwd_fp, (a, nq, n_tiles, threads, lds, stream))
 }
 
 gconv_status_t launch_tile_bwd(TileBwdArgs a, int n_tiles, int tile_nodes_max,
@@ -941,7 +971,8 @@ gconv_status_t launch_tile_bwd(TileBwdArgs a, int n_tiles, int tile_nodes_max,
   a.cap = ceil_div(tile_nodes_max > 0 ? tile_nodes_max : 1, 16) * 16;
   const size_t lds = tile_lds_bytes(a.d, a.fp, tile_nodes_max, tile_edges_max);
   const int threads = tile_threads_bwd(a.d);
-  GCONV_TILE_DISPATCH(launch_tile_bwd_t, (a, n_tiles, threads, lds, stream))
+  GCONV_TILE_DISPATCH(launch_tile_bwd_fp, (a, nq, n_tiles, threads, lds, stream))
 }
+#endif  // host side
 
 }  // namespace gconv

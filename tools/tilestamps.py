@@ -2,7 +2,7 @@
     python tools/tilestamps.py [hiv|esol]
 Builds lib/libgconv_adapter_stamps.so on first use (hipcc), runs one adapter forward+backward through the
 ctypes binding and prints, for the largest and some median tiles, the time spent in each phase."""
-import ctypes as C, glob, os, subprocess, sys
+import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["GCONV_PY_BINDING"] = "1"
@@ -10,13 +10,14 @@ import numpy as np, torch
 import gconv_adapter_amd as ga
 from gconv_adapter_amd import _lib
 alt = os.environ.get("GCONV_STAMPS_LIB") or _lib.LIB_PATH.replace("libgconv_adapter.so", "libgconv_adapter_stamps.so")
-if not os.path.exists(alt):
-    srcs = sorted(glob.glob(os.path.join(ROOT, "gconv-adapter_amd", "csrc", "*.hip")))
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                    "-DGCONV_TILE_STAMPS", "-Wno-unused-value", "-Wno-pass-failed", "-o", alt] + srcs, check=True)
+if not os.path.exists(alt):   # (build it here, where hipcc cross-compiles: python tools/tilestamps.py --build-only)
+    import __graft_entry__ as ge
+    ge.build_library(alt, defines=("-DGCONV_TILE_STAMPS",), tag="_stamps")
+if "--build-only" in sys.argv:
+    sys.exit(0)
 _lib.LIB_PATH = alt
 dev = torch.device("cuda:0")
-batch, cfg = ga.synth.make_workload(sys.argv[1] if len(sys.argv) > 1 else "hiv")
+batch, cfg = ga.synth.make_workload(next((a for a in sys.argv[1:] if not a.startswith("-")), "hiv"))
 d, r = cfg["d"], cfg["r"]
 x = batch.x.to(dev); ei = batch.edge_index.to(dev); g = torch.randn_like(x)
 m = ga.GConvAdapter(d, r, learnable_scalar=True).to(dev)
