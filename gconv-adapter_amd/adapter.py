@@ -152,12 +152,10 @@ class GConvAdapter(nn.Module):
         if self.direct_param_grads and torch.is_grad_enabled():
             pack = self._param_pack(ext, p, fuse_scalar)
             if pack is not None:
-                anchor = None
-                if not x2d.requires_grad:   # keeps the node alive when only the parameters train
-                    anchor = self.__dict__.get("_anchor")
-                    if anchor is None or anchor.device != dev:
-                        anchor = torch.zeros(1, device=dev, requires_grad=True)
-                        self.__dict__["_anchor"] = anchor
+                # W_down rides along as an autograd input whose gradient slot stays undefined: the
+                # node stays alive when only the parameters train, and `backward(inputs=params)`
+                # finds it on the path to a named parameter (the deposit itself is per parameter)
+                anchor = p[0]
                 return ext.adapter_apply_direct(x2d, anchor, pack, plan.arena, plan.struct_addr, fp, ws_fwd,
                                                 ws_bwd, p[5], bool(self.skip_connection), _stream(dev.index))
         return ext.adapter_apply(x2d, p[0], p[1], p[2], p[3], p[4] if fuse_scalar else None,
@@ -183,8 +181,8 @@ class GConvAdapter(nn.Module):
 
     #: per-instance caches that must not travel with a copy: ``_pack`` is a handle into the C++
     #: ParamPack table keyed on the ORIGINAL's Parameter objects, ``_flat_params`` holds those
-    #: objects, ``_anchor`` is a device tensor of the original's device
-    _TRANSIENT = ("_pack", "_flat_params", "_anchor")
+    #: objects
+    _TRANSIENT = ("_pack", "_flat_params")
 
     def __getstate__(self):
         """copy.deepcopy / pickle / torch.save(model): drop the caches — the copy builds its own

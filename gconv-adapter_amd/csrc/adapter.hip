@@ -163,7 +163,7 @@ extern "C" size_t gconv_adapter_fwd_workspace_bytes(const gconv_graph_t* graph, 
 #ifdef GCONV_TILE_STAMPS
   if (tile_path_ok(graph, hidden, fp)) return 1 << 20;
 #endif
-  if (tile_path_ok(graph, hidden, fp)) return 256;
+  if (tile_path_ok(graph, hidden, fp)) return 0;   // the fused tile kernel keeps its state in LDS
   return carve_fwd(nullptr, &graph->fwd, fp).bytes;
 }
 

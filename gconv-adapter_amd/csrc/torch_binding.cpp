@@ -88,16 +88,19 @@ void load_library(const std::string& path) {
 
 const float* fptr(const at::Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
 
-// Forward workspace. The fused tile path asks for a nominal 256 bytes that its kernel never
-// touches: one such block per device is allocated once and shared by every call (an allocation
-// per adapter call is ~1 us of a ~10 us host path); real workspaces are allocated per call.
+// Forward workspace. The fused tile path needs none (gconv_adapter_fwd_workspace_bytes == 0; the
+// Python side rounds that up to a 16-byte placeholder because the C ABI wants a non-null pointer):
+// one placeholder per device is allocated once and shared by every call — nothing ever touches it
+// (an allocation per adapter call is ~1 us of a ~10 us host path). Any workspace a kernel really
+// uses is allocated per call: two forwards on different streams must not share scratch. The map is
+// leaked on purpose (static destructors run after the caching allocator is gone).
 at::Tensor forward_workspace(const at::Tensor& like, int64_t bytes) {
-  if (bytes > 256) return at::empty({bytes}, like.options().dtype(at::kByte));
+  if (bytes > 16) return at::empty({bytes}, like.options().dtype(at::kByte));
   static std::mutex mu;
-  static std::unordered_map<int, at::Tensor> dummy;
+  static auto* dummy = new std::unordered_map<int, at::Tensor>();
   std::lock_guard<std::mutex> lk(mu);
-  at::Tensor& t = dummy[like.get_device()];
-  if (!t.defined()) t = at::empty({256}, like.options().dtype(at::kByte));
+  at::Tensor& t = (*dummy)[like.get_device()];
+  if (!t.defined()) t = at::empty({16}, like.options().dtype(at::kByte));
   return t;
 }
 float* fptr_mut(at::Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
@@ -286,9 +289,9 @@ void flush_locked(TaskState& st) {
   }
 }
 
-void queue_grad(const at::Tensor& p, at::Tensor g, TaskState& st) {
+void queue_grad(const at::Tensor& p, at::Tensor g, bool wanted, TaskState& st) {
   if (!g.defined()) return;
-  if (!p.defined() || !p.requires_grad()) {
+  if (!wanted) {
     st.keep.push_back(std::move(g));   // still written by the reduction
     return;
   }
@@ -342,7 +345,10 @@ struct AdapterFnDirect : public torch::autograd::Function<AdapterFnDirect> {
                             c10::optional<at::Tensor> anchor, int64_t pack_id, at::Tensor arena,
                             int64_t graph_addr, int64_t fp, int64_t ws_fwd, int64_t ws_bwd, int64_t act,
                             bool skip, int64_t stream) {
-    (void)anchor;  // differentiable dummy: keeps the node alive when x needs no gradient
+    // `anchor` is the module's W_down: a real edge to a parameter's grad accumulator keeps the node
+    // alive when x needs no gradient AND puts it on the path of backward(inputs=parameters); its
+    // gradient slot stays undefined (the accumulator is a no-op), the deposit happens below.
+    (void)anchor;
     TORCH_CHECK(g_lib.handle, "gconv_adapter_amd: library not loaded");
     TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat,
                 "gconv_adapter_amd computes in fp32 on a HIP device (no CPU path)");
@@ -415,13 +421,25 @@ struct AdapterFnDirect : public torch::autograd::Function<AdapterFnDirect> {
                             fptr_mut(gbu), fptr_mut(gsc), ws.data_ptr(), static_cast<size_t>(ws_bwd),
                             &pend, reinterpret_cast<void*>(stream)),
           "adapter_bwd");
-    // torch.autograd.grad(out, x) / backward(inputs=[x]): the task names its inputs and the
-    // parameters (not graph inputs of this node) are not among them — AccumulateGrad would not
-    // run for them either, so nothing is stored and the partials are dropped.
+    // A graph task that names its inputs (torch.autograd.grad(out, x), backward(inputs=[...])):
+    // a parameter receives its gradient only if it is one of them — its grad accumulator is then
+    // in the task's exec_info, marked for execution. AccumulateGrad would run for exactly those.
+    // With none of them named the partials are dropped (nothing is stored, no reduction runs).
     const auto* exec_info = torch::autograd::get_current_graph_task_exec_info();
-    if (exec_info && !exec_info->empty()) return {gx, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
-                                                   at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
-                                                   at::Tensor(), at::Tensor()};
+    const bool named = exec_info && !exec_info->empty();
+    auto wanted = [&](const at::Tensor& prm) {
+      if (!prm.defined() || !prm.requires_grad()) return false;
+      if (!named) return true;
+      const auto acc = torch::autograd::impl::try_get_grad_accumulator(prm);
+      if (!acc) return false;
+      const auto it = exec_info->find(acc.get());
+      return it != exec_info->end() && it->second.should_execute();
+    };
+    const bool want[5] = {wanted(pk->w_down), wanted(pk->b_down), wanted(pk->w_up), wanted(pk->b_up),
+                          wanted(pk->scalar)};
+    if (named && !(want[0] || want[1] || want[2] || want[3] || want[4]))
+      return {gx, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
+              at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
     const std::shared_ptr<TaskState> st = current_task_state();
     {
       std::lock_guard<std::mutex> lk(st->mu);
@@ -430,11 +448,11 @@ struct AdapterFnDirect : public torch::autograd::Function<AdapterFnDirect> {
       st->device = x.get_device();
       st->pending.push_back(pend);
       st->keep.push_back(ws);
-      queue_grad(pk->w_down, std::move(gwd), *st);
-      queue_grad(pk->b_down, std::move(gbd), *st);
-      queue_grad(pk->w_up, std::move(gwu), *st);
-      queue_grad(pk->b_up, std::move(gbu), *st);
-      queue_grad(pk->scalar, std::move(gsc), *st);
+      queue_grad(pk->w_down, std::move(gwd), want[0], *st);
+      queue_grad(pk->b_down, std::move(gbd), want[1], *st);
+      queue_grad(pk->w_up, std::move(gwu), want[2], *st);
+      queue_grad(pk->b_up, std::move(gbu), want[3], *st);
+      queue_grad(pk->scalar, std::move(gsc), want[4], *st);
     }
     at::Tensor none;
     return {gx, none, none, none, none, none, none, none, none, none, none};

@@ -202,10 +202,14 @@ gconv_status_t gconv_gemm_up_fused_f32(const float* p, const float* w_up, const 
 /* Whole adapter                                                             */
 /* ------------------------------------------------------------------------- */
 typedef struct gconv_adapter_params {
-  const float* w_down;  /* conv_down.lin.weight [rank, hidden]                */
+  const float* w_down;  /* conv_down.lin.weight [rank, hidden]   16-byte aligned */
   const float* b_down;  /* conv_down.bias       [rank]         (nullable)     */
   const float* w_up;    /* conv_up.lin.weight   [hidden, rank]                */
-  const float* b_up;    /* conv_up.bias         [hidden]       (nullable)     */
+  const float* b_up;    /* conv_up.bias         [hidden]  (nullable) 16-byte aligned:
+                         * forward AND backward read it 4 floats per lane; a view at an odd
+                         * offset of a foreign flat buffer returns GCONV_E_ALIGNMENT — torch
+                         * allocations, state_dict tensors and FusedAdam's / FlatGradBucket's
+                         * flat buffers (every parameter padded to 16 bytes) satisfy it       */
   const float* scalar;  /* scalar [1], NULL when learnable_scalar = False     */
   int32_t hidden;       /* d, multiple of 4, <= 1024                          */
   int32_t rank;         /* r, 1..64                                           */

@@ -94,3 +94,18 @@ def assert_close(got: torch.Tensor, want: torch.Tensor, what: str, rtol=RTOL, at
     bad = err > tol
     assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.numel()} elements out of tolerance, "
                            f"max abs err {err.max().item():.3e}, max |want| {want.abs().max().item():.3e}")
+
+
+def check_workload(ga, dev, batch, d, r, flags, seed=0, need_dx=True, rtol=RTOL, atol=ATOL):
+    """Module forward + backward on `dev` against the fp64 oracle (PyG op order, torch autograd) on
+    the same seeded inputs: `out`, dX element-wise at (rtol, atol); parameter gradients with the
+    scale-relative absolute term of `grad_atol`."""
+    params = {k: v.float().double() for k, v in oracle.init_params(d, r, flags, seed=seed).items()}
+    g = torch.randn(batch.x.shape, generator=torch.Generator().manual_seed(seed + 1))
+    want_out, want_grads = oracle.adapter_forward_backward(batch.x.double(), batch.edge_index, params,
+                                                           flags, g.double(), need_dx=need_dx)
+    mod = build_module(ga, d, r, flags, params, dev)
+    got = run_module(mod, batch.x, batch.edge_index, g, dev, need_dx=need_dx)
+    assert_close(got["out"], want_out, "out", rtol, atol)
+    for k, want in want_grads.items():
+        assert_close(got[k], want, f"grad {k}", rtol, atol if k == "x" else grad_atol(want, atol))
