@@ -19,13 +19,29 @@ SPMM_IN_PRESCALED = 1
 SPMM_OUT_PRESCALE = 2
 LONG_ROW = 64
 SEG_EDGES = 128
-TILE_NODES = 32
-TILE_WIDE_FROM = 16384
+TILE_NODES = 32            # GCONV_TILE_NODES: smallest nominal tile
+TILE_NODES_MAX = 64        # GCONV_TILE_NODES_MAX
+TILE_HALO_NODES = 64       # GCONV_TILE_HALO_NODES
+TILE_HALO_EDGES = 256      # GCONV_TILE_HALO_EDGES
+TILE_HALO_SLOT = 456       # GCONV_TILE_HALO_SLOT (4-byte words per tile)
+NUM_CU = 256
 
 
 def tile_nodes(num_nodes: int) -> int:
-    """Nominal nodes per component tile of a batch (``tile_nodes`` in ``csrc/common.h``)."""
-    return 2 * TILE_NODES if num_nodes >= TILE_WIDE_FROM else TILE_NODES
+    """Nominal nodes per tile of a graph (``tile_nominal`` in ``csrc/graph_prep.hip`` without
+    its environment overrides; ``gconv_tile_nodes`` is the library's own answer): about N / 256 —
+    one tile per persistent workgroup — never below ``TILE_NODES``; beyond 256 x ``TILE_NODES_MAX``
+    nodes, N / (256 k) for the smallest k that keeps it under that maximum."""
+    if num_nodes <= 0:
+        return TILE_NODES
+    per_wg = -(-num_nodes // NUM_CU)
+    k = -(-per_wg // TILE_NODES_MAX)
+    return max(TILE_NODES, -(-num_nodes // (NUM_CU * k)))
+
+
+def tile_slack(tile: int) -> int:
+    """How far below its nominal position a cut may sit (``tile_slack`` in ``csrc/common.h``)."""
+    return max(tile // 4, 1)
 
 _i32p = C.POINTER(C.c_int32)
 
@@ -46,6 +62,11 @@ class CsrStruct(C.Structure):
     ]
 
 
+class TilingStruct(C.Structure):
+    """``gconv_tiling_t``"""
+    _fields_ = [("tiles", C.c_void_p), ("lcol", C.c_void_p), ("halo", C.c_void_p)]
+
+
 class GraphStruct(C.Structure):
     """``gconv_graph_t``"""
     _fields_ = [
@@ -53,7 +74,8 @@ class GraphStruct(C.Structure):
         ("bwd", CsrStruct),
         ("dis", C.c_void_p),
         ("tile_ptr", C.c_void_p),
-        ("tile_order", C.c_void_p),
+        ("tiles_fwd", TilingStruct),
+        ("tiles_bwd", TilingStruct),
         ("n_tiles", C.c_int32),
         ("tile_nodes_max", C.c_int32),
         ("tile_edges_max", C.c_int32),
@@ -70,7 +92,7 @@ class PendingFinalize(C.Structure):
 
 
 FINALIZE_BATCH = 5
-ABI_VERSION = 5   # GCONV_ABI_VERSION of include/gconv_adapter.h this binding was written against
+ABI_VERSION = 6   # GCONV_ABI_VERSION of include/gconv_adapter.h this binding was written against
 
 
 class AdapterParams(C.Structure):
@@ -98,6 +120,7 @@ SIGNATURES = {
     "gconv_abi_struct_bytes": (_i32, [_i32]),
     "gconv_status_string": (C.c_char_p, [_i32]),
     "gconv_padded_rank": (_i32, [_i32]),
+    "gconv_tile_nodes": (_i32, [_i32]),
     "gconv_graph_build_bytes": (_sz, [_i64, _i32]),
     "gconv_graph_build": (_i32, [_vp, _i64, _i32, _i32, _vp, _sz, _graph_p, _vp]),
     "gconv_spmm_workspace_bytes": (_sz, [_csr_p, _i32]),

@@ -135,6 +135,8 @@ extern "C" int32_t gconv_abi_struct_bytes(int32_t which) {
     case 1: return sizeof(gconv_graph_t);
     case 2: return sizeof(gconv_adapter_params_t);
     case 3: return sizeof(gconv_pending_finalize_t);
+    case 4: return sizeof(gconv_tile_t);
+    case 5: return sizeof(gconv_tiling_t);
     default: return -1;
   }
 }
@@ -255,7 +257,8 @@ extern "C" gconv_status_t gconv_adapter_fwd_f32(const gconv_graph_t* gr,
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (tile_path_ok(gr, d, fp)) {  // block-diagonal batch: one fused launch
     TileFwdArgs t{};
-    t.tile_ptr = gr->tile_ptr; t.tile_order = gr->tile_order; t.rowptr = graph->rowptr; t.col = graph->col; t.dis = dis;
+    t.tiles = gr->tiles_fwd.tiles; t.lcol = gr->tiles_fwd.lcol; t.halo = gr->tiles_fwd.halo;
+    t.rowptr = graph->rowptr; t.dis = dis; t.n = n;
     t.x = x; t.out = out; t.saved_h = saved_h; t.saved_h1 = saved_h1; t.saved_p = saved_p;
     t.w_down = p->w_down; t.b_down = p->b_down; t.w_up = p->w_up; t.b_up = p->b_up;
     t.scalar = p->scalar; t.d = d; t.r = r; t.fp = fp; t.act = p->act; t.skip = p->skip;
@@ -382,7 +385,8 @@ static gconv_status_t adapter_bwd(const gconv_graph_t* gr, const gconv_adapter_p
     const TileBwdWs tw = carve_bwd_tile(workspace, gr->n_tiles, d, fp);
     if (workspace_bytes < tw.bytes) return GCONV_E_WORKSPACE;
     TileBwdArgs t{};
-    t.tile_ptr = gr->tile_ptr; t.tile_order = gr->tile_order; t.rowptr = graph_t->rowptr; t.col = graph_t->col; t.dis = dis;
+    t.tiles = gr->tiles_bwd.tiles; t.lcol = gr->tiles_bwd.lcol; t.halo = gr->tiles_bwd.halo;
+    t.rowptr = graph_t->rowptr; t.dis = dis; t.n = n;
     t.x = x; t.g = grad_out; t.saved_h = saved_h; t.saved_h1 = saved_h1; t.saved_p = saved_p;
     t.w_down = p->w_down; t.w_up = p->w_up; t.b_up = p->b_up; t.scalar = p->scalar;
     t.dx = grad_x;

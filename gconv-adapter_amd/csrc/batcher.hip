@@ -13,6 +13,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "common.h"
+#include "tiles.h"
 
 namespace gconv {
 
@@ -101,14 +102,15 @@ __global__ __launch_bounds__(256) void plan_copy_kernel(
   if (p == nb - 1 && threadIdx.x == 0) rowptr_b[no + nn] = eo + ne;
 }
 
-// tile t starts at the last graph boundary at or below t * tile_nodes(n) (graphs are the
-// components: no edge crosses a graph boundary); spans + size keys for the size sort
-__global__ void plan_tiles_kernel(const int32_t* __restrict__ noff, int nb, int n, int ntiles,
+// tile t starts at the last graph boundary at or below t * T (graphs are the components: no edge
+// crosses a graph boundary, so these tiles carry no halo and the bounds of the LDS budget are
+// known without reading anything back — this call never synchronises)
+__global__ void plan_tiles_kernel(const int32_t* __restrict__ noff, int nb, int n, int ntiles, int T,
                                   int32_t* __restrict__ tile_ptr) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t > ntiles) return;
   if (t == ntiles) { tile_ptr[t] = n; return; }
-  const int q = t * tile_nodes(n);
+  const int q = t * T;
   int lo = 0, hi = nb;                       // largest p with noff[p] <= q  (noff[0] = 0)
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -116,38 +118,36 @@ __global__ void plan_tiles_kernel(const int32_t* __restrict__ noff, int nb, int 
   }
   tile_ptr[t] = noff[lo];
 }
-__global__ void plan_spans_kernel(const int32_t* __restrict__ tile_ptr, int ntiles,
-                                  uint32_t* __restrict__ size_key, uint64_t* __restrict__ tile_span) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= ntiles) return;
-  const int sz = tile_ptr[t + 1] - tile_ptr[t];
-  size_key[t] = static_cast<uint32_t>(1023 - min(sz, 1023));
-  tile_span[t] = static_cast<uint64_t>(static_cast<uint32_t>(tile_ptr[t])) |
-                 (static_cast<uint64_t>(static_cast<uint32_t>(sz)) << 32);
-}
 
 struct StoreLayout {
-  size_t rowptr, col, dis, tile_ptr, tile_order, key, key_out, span, noff, cub, total, cub_bytes;
-  int ntiles;
+  size_t rowptr, col, dis, tile_ptr, recs, tiles, lcol, halo, key, key_out, id, id_out, info, noff, cub, total, cub_bytes;
+  int ntiles, T;
 };
 static StoreLayout store_layout(int32_t n, int64_t nnz, int32_t nb) {
   StoreLayout L{};
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes + 16, 256); return o; };
-  L.ntiles = ceil_div(n > 0 ? n : 1, tile_nodes(n));
+  L.T = tile_nominal(n);
+  L.ntiles = ceil_div(n > 0 ? n : 1, L.T);
+  const size_t nt = static_cast<size_t>(L.ntiles), e1 = static_cast<size_t>(nnz > 0 ? nnz : 1);
   L.rowptr = take((static_cast<size_t>(n) + 1) * 4);
-  L.col = take(static_cast<size_t>(nnz > 0 ? nnz : 1) * 4);
+  L.col = take(e1 * 4);
   L.dis = take((static_cast<size_t>(n) + 1) * 4);
-  L.tile_ptr = take((static_cast<size_t>(L.ntiles) + 1) * 4);
-  L.tile_order = take(static_cast<size_t>(L.ntiles) * 8);
-  L.key = take(static_cast<size_t>(L.ntiles) * 4);
-  L.key_out = take(static_cast<size_t>(L.ntiles) * 4);
-  L.span = take(static_cast<size_t>(L.ntiles) * 8);
+  L.tile_ptr = take((nt + 1) * 4);
+  L.recs = take(nt * sizeof(gconv_tile_t));
+  L.tiles = take(nt * sizeof(gconv_tile_t));
+  L.lcol = take(e1 * 4);
+  L.halo = take(nt * kHaloSlot * 4);
+  L.key = take(nt * 4);
+  L.key_out = take(nt * 4);
+  L.id = take(nt * 4);
+  L.id_out = take(nt * 4);
+  L.info = take(64 * 4);
   L.noff = take(2 * (static_cast<size_t>(nb) + 1) * 4);
   size_t cb = 0;
   hipcub::DeviceRadixSort::SortPairs(nullptr, cb, static_cast<const uint32_t*>(nullptr),
-                                     static_cast<uint32_t*>(nullptr), static_cast<const uint64_t*>(nullptr),
-                                     static_cast<uint64_t*>(nullptr), L.ntiles, 0, 10, nullptr);
+                                     static_cast<uint32_t*>(nullptr), static_cast<const uint32_t*>(nullptr),
+                                     static_cast<uint32_t*>(nullptr), L.ntiles, 0, kTileSizeBits, nullptr);
   L.cub_bytes = cb;
   L.cub = take(cb + 256);
   L.total = off;
@@ -189,20 +189,33 @@ extern "C" gconv_status_t gconv_graph_from_store(const gconv_graph_t* dataset, c
                                                    graph_ids, noff, eoff, rowptr, col, dis, num_graphs);
   GCONV_LAUNCH_CHECK();
   const int T = 256;
-  plan_tiles_kernel<<<(L.ntiles + 1 + T - 1) / T, T, 0, stream>>>(noff, num_graphs, num_nodes, L.ntiles, tile_ptr);
+  plan_tiles_kernel<<<(L.ntiles + 1 + T - 1) / T, T, 0, stream>>>(noff, num_graphs, num_nodes, L.ntiles, L.T, tile_ptr);
+  GCONV_LAUNCH_CHECK();
+  gconv_tile_t* recs = reinterpret_cast<gconv_tile_t*>(arena + L.recs);
+  gconv_tile_t* tiles = reinterpret_cast<gconv_tile_t*>(arena + L.tiles);
+  int32_t* lcol = reinterpret_cast<int32_t*>(arena + L.lcol);
+  int32_t* halo = reinterpret_cast<int32_t*>(arena + L.halo);
+  int32_t* info = reinterpret_cast<int32_t*>(arena + L.info);
+  GCONV_HIP(hipMemsetAsync(info, 0, 64 * sizeof(int32_t), stream));
+  // records and tile-local columns on the given cuts (graph boundaries: every halo is empty)
+  tile_build_kernel<false><<<(L.ntiles + 3) / 4, 256, 0, stream>>>(rowptr, col, dis, num_nodes, L.ntiles, L.T, 0, tile_ptr,
+                                                                   lcol, halo, recs, info, TileInfoSlots{0, 1, 2});
   GCONV_LAUNCH_CHECK();
   if (L.ntiles <= kSmallSortMax) {
-    small_tile_sort_kernel<<<1, 1024, 0, stream>>>(tile_ptr, L.ntiles, reinterpret_cast<uint64_t*>(arena + L.tile_order));
+    tile_sort_small_kernel<<<1, 1024, 0, stream>>>(recs, nullptr, L.ntiles, tiles, nullptr);
     GCONV_LAUNCH_CHECK();
   } else {
-    plan_spans_kernel<<<(L.ntiles + T - 1) / T, T, 0, stream>>>(
-        tile_ptr, L.ntiles, reinterpret_cast<uint32_t*>(arena + L.key), reinterpret_cast<uint64_t*>(arena + L.span));
+    uint32_t* key = reinterpret_cast<uint32_t*>(arena + L.key);
+    uint32_t* key_out = reinterpret_cast<uint32_t*>(arena + L.key_out);
+    uint32_t* id = reinterpret_cast<uint32_t*>(arena + L.id);
+    uint32_t* id_out = reinterpret_cast<uint32_t*>(arena + L.id_out);
+    tile_sort_keys_kernel<<<(L.ntiles + T - 1) / T, T, 0, stream>>>(recs, L.ntiles, key, id);
     GCONV_LAUNCH_CHECK();
     size_t cub_bytes = L.cub_bytes;
-    GCONV_HIP(hipcub::DeviceRadixSort::SortPairs(
-        arena + L.cub, cub_bytes, reinterpret_cast<const uint32_t*>(arena + L.key),
-        reinterpret_cast<uint32_t*>(arena + L.key_out), reinterpret_cast<const uint64_t*>(arena + L.span),
-        reinterpret_cast<uint64_t*>(arena + L.tile_order), L.ntiles, 0, 10, stream));
+    GCONV_HIP(hipcub::DeviceRadixSort::SortPairs(arena + L.cub, cub_bytes, key, key_out, id, id_out, L.ntiles, 0,
+                                                 kTileSizeBits, stream));
+    tile_sort_gather_kernel<<<(L.ntiles + T - 1) / T, T, 0, stream>>>(recs, nullptr, id_out, L.ntiles, tiles, nullptr);
+    GCONV_LAUNCH_CHECK();
   }
   *g = gconv_graph_t{};
   g->fwd.num_nodes = num_nodes; g->fwd.nnz = static_cast<int32_t>(nnz);
@@ -210,12 +223,13 @@ extern "C" gconv_status_t gconv_graph_from_store(const gconv_graph_t* dataset, c
   g->bwd = g->fwd;
   g->dis = dis;
   g->tile_ptr = tile_ptr;
-  g->tile_order = reinterpret_cast<int32_t*>(arena + L.tile_order);
+  g->tiles_fwd = gconv_tiling_t{tiles, lcol, halo};
+  g->tiles_bwd = g->tiles_fwd;
   g->n_tiles = L.ntiles;
-  // upper bounds known without reading anything back: a tile starts at most
-  // tile_nodes(n) - 1 nodes before its nominal start and ends inside the graph that covers
-  // its nominal end (they only size the LDS of the fused kernels)
-  const int bound = tile_nodes(num_nodes) + max_graph_nodes;
+  // upper bounds known without reading anything back: a tile starts at most T - 1 nodes before
+  // its nominal start and ends inside the graph that covers its nominal end (they only size the
+  // LDS of the fused kernels)
+  const int bound = L.T + max_graph_nodes;
   g->tile_nodes_max = bound < num_nodes ? bound : num_nodes;
   const int64_t eb = static_cast<int64_t>(g->tile_nodes_max) * (dataset->max_degree > 0 ? dataset->max_degree : 1);
   g->tile_edges_max = static_cast<int32_t>(eb < nnz ? eb : nnz);

@@ -23,18 +23,17 @@ constexpr int kNumCU = 256;
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-// Nominal nodes per component tile of an n-node batch: GCONV_TILE_NODES (32), and twice that as
-// soon as there are enough 64-node tiles to give each of the 256 persistent workgroups one
-// (n >= 16384). Measured with libraries built at 32 / 48 / 64 / 96 / 128 and at batch sizes from
-// 512 to 4096 molecules: below that size 64 only halves the number of busy workgroups (ESOL
-// 24 -> 29 us, the 512-molecule shard 46.7 -> 47.6), above it a workgroup walks half as many
-// latency chains (768 molecules 68.5 -> 50.3 us forward + backward, 1024: 70.3 -> 57.1, 4096:
-// 181 -> 162); 96 and 128 lose everywhere. A tile never exceeds kTileSpan nodes (its start may be
-// pulled back to the previous edge-free boundary).
-constexpr int kTileSpan = 512;
-__host__ __device__ inline int tile_nodes(int n) {
-  return n >= GCONV_TILE_WIDE_FROM ? 2 * GCONV_TILE_NODES : GCONV_TILE_NODES;
-}
+// Nominal nodes per tile of an n-node graph (include/gconv_adapter.h, "Tiles"): about n / 256, so
+// that every one of the 256 persistent workgroups gets ONE tile; never below GCONV_TILE_NODES (the
+// per-tile chain of latencies does not shrink with the tile) and, beyond 256 x
+// GCONV_TILE_NODES_MAX nodes, n / (256 k) for the smallest k that keeps it under that maximum
+// (k tiles of equal size per workgroup). Round 2 used 32 (64 from 16384 nodes on) and cut only at
+// edge-free boundaries; libraries built at 32 / 48 / 64 / 96 / 128 were compared then: with the
+// largest molecule as one tile the 512-molecule shard did not care (46.7 .. 47.6 us), larger
+// batches gained from fewer chains per workgroup (4096 molecules: 181 -> 162 us at 64).
+// A cut may lie up to tile_slack(T) nodes below its nominal position (on an edge-free boundary).
+int tile_nominal(int n);                       // graph_prep.hip (reads GCONV_TILE_NODES_OVERRIDE)
+inline int tile_slack(int T) { return T / 4 > 0 ? T / 4 : 1; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -117,28 +116,6 @@ __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirs
 // 16x16x4 form pads the rank dimension to 16.
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
-}
-
-// Size-sorted tile list for small tile counts (a molecule batch has a few hundred tiles): ONE
-// workgroup ranks every tile by (size descending, tile index ascending) — exactly the order of
-// the stable radix sort used for large counts — instead of the four launches rocprim spends on
-// a 400-element sort. span[t] = first node | size << 32.
-constexpr int kSmallSortMax = 2048;
-static __global__ __launch_bounds__(1024) void small_tile_sort_kernel(const int32_t* __restrict__ tile_ptr, int ntiles,
-                                                               uint64_t* __restrict__ order_out) {
-  __shared__ int32_t start[kSmallSortMax + 1];
-  for (int t = threadIdx.x; t <= ntiles; t += 1024) start[t] = tile_ptr[t];
-  __syncthreads();
-  for (int t = threadIdx.x; t < ntiles; t += 1024) {
-    const int sz = start[t + 1] - start[t];
-    int rank = 0;
-    for (int u = 0; u < ntiles; ++u) {
-      const int su = start[u + 1] - start[u];
-      rank += (su > sz) || (su == sz && u < t);
-    }
-    order_out[rank] = static_cast<uint64_t>(static_cast<uint32_t>(start[t])) |
-                      (static_cast<uint64_t>(static_cast<uint32_t>(sz)) << 32);
-  }
 }
 
 // Wave index inside the workgroup as a provably wave-uniform (SGPR) value. Without the

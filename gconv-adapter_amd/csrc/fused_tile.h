@@ -6,16 +6,18 @@
 namespace gconv {
 
 struct TileFwdArgs {
-  const int32_t* tile_ptr; const int32_t* tile_order; const int32_t* rowptr; const int32_t* col; const float* dis;
+  const gconv_tile_t* tiles; const int32_t* lcol; const int32_t* halo;   // gconv_tiling_t of S
+  const int32_t* rowptr; const float* dis;
   const float* x; float* out; float* saved_h; float* saved_h1; float* saved_p;
   const float* w_down; const float* b_down; const float* w_up; const float* b_up;
   const float* scalar;
-  int d, r, fp, act, skip, cap, n_tiles;
+  int d, r, fp, act, skip, cap, n_tiles, n;   // n = nodes of the graph (rows of x)
   long long* stamps;   // diagnostic build only (-DGCONV_TILE_STAMPS, tools/tilestamps.py)
 };
 
 struct TileBwdArgs {
-  const int32_t* tile_ptr; const int32_t* tile_order; const int32_t* rowptr; const int32_t* col; const float* dis;  // S^T
+  const gconv_tile_t* tiles; const int32_t* lcol; const int32_t* halo;   // gconv_tiling_t of S^T
+  const int32_t* rowptr; const float* dis;
   const float* x; const float* g; const float* saved_h; const float* saved_h1;
   const float* saved_p;
   const float* w_down; const float* w_up; const float* b_up; const float* scalar;
@@ -23,7 +25,7 @@ struct TileBwdArgs {
   // one partial row per (persistent) workgroup: [grid, Fp, d] x2, [grid, d], [grid, Fp], [grid]
   float* part_wd; float* part_wu; float* part_cs; float* part_bd;
   float* part_ds;   // complete scalar-gradient partial: (G Wu).P + [skip] G.X + b_up.colsum(G)
-  int d, r, fp, act, skip, cap, want_ds, n_tiles;
+  int d, r, fp, act, skip, cap, want_ds, n_tiles, n;
   long long* stamps;   // diagnostic build only
 };
 

@@ -1,11 +1,14 @@
 // Fused tile-local adapter forward / backward for block-diagonal graphs (molecule batches).
 //
-// A collated molecule batch is a block-diagonal graph: graph prep cuts the node range
-// into component tiles that no edge crosses (gconv_graph_t::tile_ptr). ONE workgroup then
+// Graph prep cuts the node range into tiles of about N / 256 nodes (tiles.h): on a boundary
+// between two molecules where there is one nearby, else through a component, and then the
+// tile carries its two-hop halo — the rank-width rows of the nodes just outside that its own
+// rows depend on are recomputed by the tile itself, so tiles exchange nothing. ONE workgroup
 // runs the whole adapter for its tile — the three rank-width intermediates (H0', H2', P,
 // resp. dP', dH1', T) never leave LDS, the grid-wide dependencies of the four-launch path
 // become lds_barrier(), and X is read from HBM once (its second read, for the
-// residual, comes out of L2 a few microseconds later):
+// residual, comes out of L2 a few microseconds later). Phase 1 runs on own + halo rows (n0),
+// phase 2 on own + 1-hop halo rows (n1), phases 3 / 4 on the own rows:
 //
 //   forward   phase 1  H0' = dis . (X_t Wd^T)                   MFMA, A layout, W_d frags in LDS
 //             phase 2  H2' = dis . act(dis . (A0 H0' + H0') + bd)      LDS gathers
@@ -25,6 +28,7 @@
 #include <type_traits>
 
 #include "fused_tile.h"
+#include "tiles.h"
 
 #ifndef GCONV_BWD_WAVES
 #define GCONV_BWD_WAVES 2
@@ -121,10 +125,44 @@ __device__ __forceinline__ void stage_weights(f32x4* wl, const float* __restrict
   }
 }
 
-// Phase 1 of both directions: dst[local row][c] = row_scale * sval * (M_t Wt), tile rows
-// [ts, ts + nt). Returns this lane's partial of sum(acc * Pmat) (backward scalar gradient).
-// `rm` is the buffer descriptor of the tile's rows of M (nt * d floats): node blocks that run
-// past the tile and k-steps past the row end read zeros through its range check.
+// Offset that lies outside every buffer the tile kernels address through a descriptor (their
+// byte counts stay below it: tile_path_ok); what is added to it (a k-step inside a row) cannot
+// overflow 32 bits.
+constexpr int kRowOob = 0x7FFF0000;
+
+// One tile as the kernels see it (wave-uniform) + its halo slot. The kernels read the first 16
+// bytes of a gconv_tile_t only ({first, count, n1, n0}: a record prefetched for the next pass
+// sits in VGPRs for a whole tile — the forward kernel has none to spare) and pick up slot / e0 with
+// a second, short-lived request at the top of the pass; the edge counts come from the row
+// offsets the CSR staging requests anyway.
+struct TileView {
+  int ts, nt, n1, n0, e0;
+  const int32_t* hb;   // the tile's halo slot (tiles.h)
+};
+__device__ __forceinline__ i32x4 tile_rec_load(const gconv_tile_t* tiles, int idx) {
+  return *reinterpret_cast<const i32x4*>(tiles + idx);
+}
+__device__ __forceinline__ TileView tile_view(const gconv_tile_t* tiles, int idx, const i32x4& r0,
+                                              const int32_t* halo) {
+  TileView v;
+  const int2 r1 = *reinterpret_cast<const int2*>(&tiles[idx].slot);   // {slot, e0}
+  v.ts = uniform(r0[0]); v.nt = uniform(r0[1]); v.n1 = uniform(r0[2]); v.n0 = uniform(r0[3]);
+  v.e0 = uniform(r1.y);
+  v.hb = halo + static_cast<size_t>(uniform(r1.x)) * kHaloSlot;
+  return v;
+}
+
+// graph node of the tile's local row lr (< n0): own rows are contiguous, halo rows come from the slot
+__device__ __forceinline__ int tile_node(const TileView& tv, int lr) {
+  const int hid = tv.hb[min(max(lr - tv.nt, 0), kHaloNodes - 1)];   // (requested for every lr: no branch)
+  return lr < tv.nt ? tv.ts + lr : hid;
+}
+
+// Phase 1 of both directions: dst[local row][c] = row_scale * sval * (M Wt) for the tile's n0
+// rows (own rows, then its halo nodes). Returns this lane's partial of sum(acc * Pmat) over the
+// OWN rows (backward scalar gradient).
+// `rm` is a descriptor over ALL rows of M (n * d floats): a lane whose row lies past the tile's
+// n0 rows, and a k-step past the row end, is pushed out of its range and reads zeros.
 //
 // A wave owns the 16-row blocks wave, wave + nwaves, ...; the k-steps of a block sit in a
 // register ring: all of them are requested before the first MFMA, and while block b is
@@ -137,12 +175,14 @@ template <int FP, int NQ, bool HAS_DIS, bool WANT_P, class Mid>
 __device__ __forceinline__ float tile_rowsA(rsrc_t rm, const float* __restrict__ anyrow,
                                             const f32x4* wl, float* dst,
                                             const float* __restrict__ dis,
-                                            const float* __restrict__ Pmat, float sval, int ts,
-                                            int nt, int d, int rowb, int nwaves, int wave,
+                                            const float* __restrict__ Pmat, float sval,
+                                            const TileView& tv, int d, int rowb, int nwaves, int wave,
                                             int lane, Mid&& mid) {
   constexpr int NCB = FP >= 16 ? FP / 16 : 1;
   const int node = lane & 15, kq = lane >> 4;
-  const int nb = ceil_div(nt, 16);
+  const int ts = tv.ts, nt = tv.nt, n0 = tv.n0;
+  const int nb = ceil_div(n0, 16);
+  const float* hdis = reinterpret_cast<const float*>(tv.hb + kHaloDisOff);
   float ds_acc = 0.f;
   int b = wave;
   if (b >= nb) {  // wave-uniform: no block for this wave in this tile
@@ -159,10 +199,22 @@ __device__ __forceinline__ float tile_rowsA(rsrc_t rm, const float* __restrict__
   // recompute them: two VALU ops per 16-byte load.
   auto launder = [](int v) { asm volatile("" : "+v"(v)); return v; };
   auto koff = [&](int rowoff, int q, int kqv) {  // a k-step past the row end reads zeros
-    return 16 * q + 4 * kqv < d ? rowoff + 64 * q + 16 * kqv : kBufOob;
+    return 16 * q + 4 * kqv < d ? rowoff + 64 * q + 16 * kqv : kRowOob;
+  };
+  // byte offset of this lane's row of node block `blk` in M: own rows are contiguous from ts,
+  // halo rows come from the slot's node list (only a block that reaches past the own rows of a
+  // tile WITH a halo pays that look-up; wave-uniform branch)
+  auto rowoff = [&](int blk) {
+    const int lr = 16 * blk + node;
+    int g = ts + lr;
+    if (n0 > nt && 16 * blk + 16 > nt) {
+      const int hid = tv.hb[min(max(lr - nt, 0), kHaloNodes - 1)];
+      g = lr < nt ? g : hid;
+    }
+    return lr < n0 ? g * rowb : kRowOob;
   };
   {
-    const int ro = (16 * b + node) * rowb, kqv = launder(kq);
+    const int ro = rowoff(b), kqv = launder(kq);
 #pragma unroll
     for (int q = 0; q < R; ++q) x[q] = buf_ld4(rm, koff(ro, q, kqv));
   }
@@ -175,13 +227,16 @@ __device__ __forceinline__ float tile_rowsA(rsrc_t rm, const float* __restrict__
     float dv[4], pv[NCB][4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      const int lrc = min(16 * blk + 4 * kq + m, nt - 1);
-      dv[m] = HAS_DIS ? dis[ts + lrc] : 1.f;
+      const int lrc = min(16 * blk + 4 * kq + m, n0 - 1);
+      // own rows: dis of the graph; halo rows: the slot's copy (ONE request, from a selected address)
+      dv[m] = HAS_DIS ? *(lrc < nt ? dis + ts + lrc : hdis + (lrc - nt)) : 1.f;
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb)
-        pv[cb][m] = WANT_P ? pmat[static_cast<size_t>(ts + lrc) * FP + min(16 * cb + node, FP - 1)] : 0.f;
+        pv[cb][m] = WANT_P ? pmat[static_cast<size_t>(ts + min(lrc, nt - 1)) * FP + min(16 * cb + node, FP - 1)] : 0.f;
     }
-    const int rc = (16 * blk + node) * rowb, rn = (16 * (blk + nwaves) + node) * rowb;
+    const int rc = rowoff(blk);
+    int rn = 0;
+    if constexpr (REFILL) rn = rowoff(blk + nwaves);
     const int kqv = launder(kq);
     f32x4 acc[NCB][2];
 #pragma unroll
@@ -221,9 +276,9 @@ __device__ __forceinline__ float tile_rowsA(rsrc_t rm, const float* __restrict__
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int lr = 16 * blk + 4 * kq + m;
-        if (lr < nt && c < FP) {
+        if (lr < n0 && c < FP) {
           float v = res[m];
-          if (WANT_P && Pmat) ds_acc += v * pv[cb][m];
+          if (WANT_P && Pmat && lr < nt) ds_acc += v * pv[cb][m];
           v *= sval * dv[m];
           dst[lr * FP + c] = v;
         }
@@ -257,41 +312,55 @@ __device__ __forceinline__ f32x4 tile_row_sum(const float* src, const int32_t* r
   return acc;
 }
 
-// Split-phase staging of a tile's CSR slice and dis values into LDS: `request` (before the
-// phase-1 tile loads) asks for the row offsets and dis, `advance` (the phase-1 `mid` hook:
-// the big tile loads are in flight by then) asks for the column ids, which need the slice
-// start, and parks what has arrived; `finish` parks the column ids. The barrier that ends
-// phase 1 publishes everything. First blockDim elements in registers, the rest (tiles with
-// more rows / edges than threads) by plain loops in `finish`.
+// Split-phase staging of a tile's local CSR and dis values into LDS: `request` (before the
+// phase-1 tile loads) asks for the own rows' offsets, dis and the halo slot's small arrays,
+// `advance` (the phase-1 `mid` hook: the big tile loads are in flight by then) asks for the column
+// ids and parks what has arrived; `finish` parks the column ids. The barrier that ends phase 1
+// publishes everything. Local rows: own rows 0 .. nt - 1 (columns already tile-local in `lcol`),
+// then the halo1 rows nt .. n1 - 1 (rowptr and columns from the slot). First blockDim elements in
+// registers, the rest (own parts of tiles with more rows / edges than threads) by plain loops in
+// `finish`; the halo parts never exceed a workgroup (64 rows, 256 edges; blockDim >= 256).
 template <bool NORM>
 struct TileCsrStage {
   const int32_t* __restrict__ rowptr;
-  const int32_t* __restrict__ col;
+  const int32_t* __restrict__ lcol;
   const float* __restrict__ dis;
   int32_t *rp, *cl;
   float* dl;
-  int ts, nt, e0, e1, rpv, clv;
+  TileView tv;
+  int rpv, hrpv, clv, e1v, hev, ne, nhe;
   float dv;
   __device__ __forceinline__ void request() {
-    const int tid = threadIdx.x;
-    e0 = rowptr[ts];
-    e1 = rowptr[ts + nt];
-    rpv = rowptr[ts + min(tid, nt)];
-    dv = NORM ? dis[ts + min(tid, nt - 1)] : 1.f;
+    const int tid = threadIdx.x, nt = tv.nt;
+    rpv = rowptr[tv.ts + min(tid, nt)];
+    e1v = rowptr[tv.ts + nt];                                   // (same word in every lane)
+    hrpv = tv.hb[kHaloRpOff + min(tid, kHaloNodes)];
+    hev = tv.hb[kHaloRpOff + tv.n1 - nt];                       // stored edges of the halo1 rows
+    const float* hdis = reinterpret_cast<const float*>(tv.hb + kHaloDisOff);
+    dv = NORM ? *(tid < nt ? dis + tv.ts + tid : hdis + min(tid - nt, kHaloNodes - 1)) : 1.f;
+  }
+  // column id e of the tile's local edge list: own rows' edges first, then the halo1 rows'
+  __device__ __forceinline__ int col_at(int e) const {
+    const int ec = min(e, max(ne + nhe - 1, 0));
+    return *(ec < ne ? lcol + tv.e0 + ec : tv.hb + kHaloColOff + (ec - ne));
   }
   __device__ __forceinline__ void advance() {
-    const int tid = threadIdx.x;
-    clv = col[e0 + min(tid, max(e1 - e0 - 1, 0))];
-    if (tid <= nt) rp[tid] = rpv - e0;
-    if (NORM && tid < nt) dl[tid] = dv;
+    const int tid = threadIdx.x, nt = tv.nt;
+    ne = uniform(e1v) - tv.e0;
+    nhe = min(uniform(hev), kHaloEdges);
+    clv = col_at(tid);
+    if (tid <= nt) rp[tid] = rpv - tv.e0;
+    if (tid >= 1 && tid <= tv.n1 - nt) rp[nt + tid] = ne + hrpv;   // (rp[nt] = ne from the own side)
+    if (NORM && tid < tv.n0) dl[tid] = dv;
   }
   __device__ __forceinline__ void finish() {
-    const int tid = threadIdx.x, ne = e1 - e0;
-    if (tid < ne) cl[tid] = clv - ts;
-    for (int e = tid + blockDim.x; e < ne; e += blockDim.x) cl[e] = col[e0 + e] - ts;
-    for (int i = tid + blockDim.x; i <= nt; i += blockDim.x) {
-      rp[i] = rowptr[ts + i] - e0;
-      if (NORM && i < nt) dl[i] = dis[ts + i];
+    const int tid = threadIdx.x, nt = tv.nt;
+    if (tid < ne + nhe) cl[tid] = clv;
+    for (int e = tid + blockDim.x; e < ne + nhe; e += blockDim.x) cl[e] = col_at(e);
+    for (int i = tid + blockDim.x; i <= nt; i += blockDim.x) rp[i] = rowptr[tv.ts + i] - tv.e0;
+    if (NORM) {   // rows of a tile with more rows than threads
+      const float* hdis = reinterpret_cast<const float*>(tv.hb + kHaloDisOff);
+      for (int i = tid + blockDim.x; i < tv.n0; i += blockDim.x) dl[i] = i < nt ? dis[tv.ts + i] : hdis[i - nt];
     }
   }
 };
@@ -323,10 +392,10 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
 
   // Every first-touch load of a launch misses L2 (the previous kernel streamed 30+ MB through
   // it): the prologue requests ALL of them back to back — register fragments, scalar, the first
-  // tile's span — and only then stages the LDS weights, so it pays one cold round trip, not four.
+  // tile's record — and only then stages the LDS weights, so it pays one cold round trip, not four.
   TILE_STAMP(9);
   const float sraw = (a.scalar ? a.scalar : a.w_down)[0];
-  const int2 span0 = reinterpret_cast<const int2*>(a.tile_order)[blockIdx.x];   // grid <= n_tiles
+  i32x4 rec = tile_rec_load(a.tiles, blockIdx.x);   // grid <= n_tiles
 
   // phase-4 ownership: a wave owns ONE 64-column chunk (W_up fragments in registers) and
   // every nslots-th node block of a tile (nchunks <= nwaves is guaranteed by the launcher)
@@ -368,16 +437,16 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
   TILE_STAMP(0);
   // tiles are dealt from the size-sorted list boustrophedon: pass 0 gives workgroup w the
   // w-th largest tile, pass 1 the (2 G - 1 - w)-th, ... — the big tiles end up alone
-  int2 span = span0;
   for (int pass = 0;; ++pass) {
     const int G = gridDim.x;
     const int idx = (pass & 1) ? (pass + 1) * G - 1 - static_cast<int>(blockIdx.x) : pass * G + static_cast<int>(blockIdx.x);
     if (idx >= a.n_tiles) break;
-    const int ts = uniform(span.x), nt = uniform(span.y);   // (first node, count) of this pass
-    {   // the next pass's span is requested now (clamped index: always a valid entry)
+    const TileView tv = tile_view(a.tiles, idx, rec, a.halo);      // the tile of this pass
+    const int ts = tv.ts, nt = tv.nt;
+    {   // the next pass's record is requested now (clamped index: always a valid entry)
       const int nidx = ((pass + 1) & 1) ? (pass + 2) * G - 1 - static_cast<int>(blockIdx.x)
                                         : (pass + 1) * G + static_cast<int>(blockIdx.x);
-      span = reinterpret_cast<const int2*>(a.tile_order)[min(nidx, a.n_tiles - 1)];
+      rec = tile_rec_load(a.tiles, min(nidx, a.n_tiles - 1));
     }
     if (nt <= 0) continue;  // uniform
     TILE_STAMP_NT(nt);
@@ -390,14 +459,16 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
     // phase-4 byte offset of this lane inside a tile: row 4t of a node block, its 4 columns;
     // a lane past the last column is pushed out of the tile's range (loads 0, stores nothing)
     const int voff4 = 4 * t * rowb + (colvalid ? 4 * colbase : kBufOob);
-    // the tile's rows of X and of out as range-checked buffers
+    // the tile's own rows of X and of out as range-checked buffers (phase 4); all of X (phase 1
+    // also reads the halo nodes' rows)
     const rsrc_t rx = make_rsrc(a.x + static_cast<size_t>(ts) * a.d, static_cast<uint32_t>(nt) * rowb);
     const rsrc_t ro = make_rsrc(a.out + static_cast<size_t>(ts) * a.d, static_cast<uint32_t>(nt) * rowb);
+    const rsrc_t rxa = make_rsrc(a.x, static_cast<uint32_t>(a.n) * rowb);
 
-    // ---- phase 1: H0' -> bufA (the tile's CSR slice and dis land in LDS meanwhile)
-    TileCsrStage<NORM> csr{a.rowptr, a.col, a.dis, rp, cl, dl, ts, nt};
+    // ---- phase 1: H0' -> bufA, n0 rows (the tile's local CSR and dis land in LDS meanwhile)
+    TileCsrStage<NORM> csr{a.rowptr, a.lcol, a.dis, rp, cl, dl, tv};
     csr.request();
-    tile_rowsA<FP, NQ, NORM, false>(rx, a.x, wl, bufA, a.dis, nullptr, 1.f, ts, nt, a.d, rowb, nwaves, wave,
+    tile_rowsA<FP, NQ, NORM, false>(rxa, a.x, wl, bufA, a.dis, nullptr, 1.f, tv, a.d, rowb, nwaves, wave,
                                     lane, [&]() { csr.advance(); });
     csr.finish();
     lds_barrier();
@@ -415,16 +486,17 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
     load_x(slot, xa);
     load_x(slot + nslots, xb);
 
-    // ---- phase 2: H2' -> bufB (+ saved_h, saved_h1)
-    for (int lr = grp; lr < nt; lr += ngrp) {
+    // ---- phase 2: H2' -> bufB, n1 rows (own rows: + saved_h, saved_h1)
+    for (int lr = grp; lr < tv.n1; lr += ngrp) {
       f32x4 v = tile_row_sum<FP, NORM>(bufA, rp, cl, dl, lr, sub) + bdv;
       const size_t off = static_cast<size_t>(ts + lr) * FP + 4 * sub;
-      if (a.act == GCONV_ACT_SILU) stg4(a.saved_h1 + off, v);
+      const bool own = lr < nt;   // a halo row's value is stored by the tile that owns it
+      if (a.act == GCONV_ACT_SILU && own) stg4(a.saved_h1 + off, v);
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = act_fwd(a.act, v[k]);
       if (NORM) v *= dl[lr];
       *reinterpret_cast<f32x4*>(bufB + lr * FP + 4 * sub) = v;
-      stg4(a.saved_h + off, v);
+      if (own) stg4(a.saved_h + off, v);
     }
     lds_barrier();
 
@@ -504,7 +576,7 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
   const int pid = blockIdx.x;
   // (prologue: all first-touch requests back to back, LDS staging after them — see forward)
   const float sraw = (a.scalar ? a.scalar : a.w_down)[0];
-  const int2 span0 = reinterpret_cast<const int2*>(a.tile_order)[blockIdx.x];   // grid <= n_tiles
+  i32x4 rec = tile_rec_load(a.tiles, blockIdx.x);   // grid <= n_tiles
   const int nchunks = ceil_div(a.d, 64);
   const int jj = lane & 15, t = lane >> 4;
   const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR, ngrp = blockDim.x / LPR;
@@ -554,16 +626,16 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
   TILE_STAMP(0);
   // tiles are dealt from the size-sorted list boustrophedon: pass 0 gives workgroup w the
   // w-th largest tile, pass 1 the (2 G - 1 - w)-th, ... — the big tiles end up alone
-  int2 span = span0;
   for (int pass = 0;; ++pass) {
     const int G = gridDim.x;
     const int idx = (pass & 1) ? (pass + 1) * G - 1 - static_cast<int>(blockIdx.x) : pass * G + static_cast<int>(blockIdx.x);
     if (idx >= a.n_tiles) break;
-    const int ts = uniform(span.x), nt = uniform(span.y);   // (first node, count) of this pass
-    {   // the next pass's span is requested now (clamped index: always a valid entry)
+    const TileView tv = tile_view(a.tiles, idx, rec, a.halo);      // the tile of this pass
+    const int ts = tv.ts, nt = tv.nt;
+    {   // the next pass's record is requested now (clamped index: always a valid entry)
       const int nidx = ((pass + 1) & 1) ? (pass + 2) * G - 1 - static_cast<int>(blockIdx.x)
                                         : (pass + 1) * G + static_cast<int>(blockIdx.x);
-      span = reinterpret_cast<const int2*>(a.tile_order)[min(nidx, a.n_tiles - 1)];
+      rec = tile_rec_load(a.tiles, min(nidx, a.n_tiles - 1));
     }
     if (nt <= 0) continue;  // uniform
     TILE_STAMP_NT(nt);
@@ -577,24 +649,32 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
     // every lane of a wave that owns no chunk, is pushed out of the tile's range (loads 0
     // without traffic, stores nothing)
     const int voff1 = colvalid ? 4 * col1 : kBufOob;
-    // the tile's rows of G, X and dX as range-checked buffers
+    // the tile's own rows of G, X and dX as range-checked buffers (phase 4); all of G (phase 1
+    // also reads the halo nodes' rows)
     const uint32_t tbytes = static_cast<uint32_t>(nt) * rowb;
     const rsrc_t rg = make_rsrc(a.g + static_cast<size_t>(ts) * a.d, tbytes);
     const rsrc_t rx = make_rsrc(a.x + static_cast<size_t>(ts) * a.d, tbytes);
     const rsrc_t rdx = make_rsrc(NEED_DX ? a.dx + static_cast<size_t>(ts) * a.d : nullptr, NEED_DX ? tbytes : 0);
+    const rsrc_t rga = make_rsrc(a.g, static_cast<uint32_t>(a.n) * rowb);
 
-    // ---- phase 1: dP' = dis . s (G Wu) -> bufA ; ds1 += sum (G Wu) . P
-    // (the tile's CSR slice and its P rows land in LDS meanwhile)
-    TileCsrStage<NORM> csr{a.rowptr, a.col, a.dis, rp, cl, dl, ts, nt};
+    // ---- phase 1: dP' = dis . s (G Wu) -> bufA, n0 rows ; ds1 += sum over the own rows (G Wu) . P
+    // (the tile's local CSR and its P rows land in LDS meanwhile)
+    TileCsrStage<NORM> csr{a.rowptr, a.lcol, a.dis, rp, cl, dl, tv};
     csr.request();
-    // phase 2's saved activation of this lane group's first row, requested a phase early
+    // phase 2's saved activation of this lane group's first row, requested a phase early: the
+    // row's graph node now (a halo row's comes from the slot), the row itself once the phase-1
+    // tile requests are out (`mid`)
     const float* hsel = a.act == GCONV_ACT_SILU ? a.saved_h1 : a.saved_h;
-    const f32x4 hfirst = ldg4(hsel + static_cast<size_t>(ts + min(grp, nt - 1)) * FP + 4 * sub);
+    const int gfirst = tile_node(tv, min(grp, tv.n1 - 1));
+    f32x4 hfirst;
     const int np4 = nt * LPR;  // the P tile: np4 float4, the first blockDim of them via registers
     const f32x4 pfirst =
         ldg4(a.saved_p + static_cast<size_t>(ts) * FP + 4 * min(static_cast<int>(threadIdx.x), np4 - 1));
-    ds1 += tile_rowsA<FP, NQ, NORM, true>(rg, a.g, wl, bufA, a.dis, a.want_ds ? a.saved_p : nullptr, sval, ts,
-                                          nt, a.d, rowb, nwaves, wave, lane, [&]() { csr.advance(); });
+    ds1 += tile_rowsA<FP, NQ, NORM, true>(rga, a.g, wl, bufA, a.dis, a.want_ds ? a.saved_p : nullptr, sval, tv,
+                                          a.d, rowb, nwaves, wave, lane, [&]() {
+                                            csr.advance();
+                                            hfirst = ldg4(hsel + static_cast<size_t>(gfirst) * FP + 4 * sub);
+                                          });
     csr.finish();
     // P goes to LDS transposed (rank-major): phase 4 reads 4 consecutive nodes of one rank row
     // with one 16-byte LDS load; rows between nt and the end of the last node block are zeros
@@ -626,11 +706,12 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
     load_gx(slot, ga, xa);
     if constexpr (DEEP) load_gx(slot + nslots, gb, xb);
 
-    // ---- phase 2: dH1' = dis . (S^T dP . act') -> bufB ; bias gradient
-    for (int lr = grp; lr < nt; lr += ngrp) {
+    // ---- phase 2: dH1' = dis . (S^T dP . act') -> bufB, n1 rows ; bias gradient (own rows)
+    for (int lr = grp; lr < tv.n1; lr += ngrp) {
       f32x4 v = tile_row_sum<FP, NORM>(bufA, rp, cl, dl, lr, sub);
       f32x4 hv = hfirst;
-      if (lr != grp) hv = ldg4(hsel + static_cast<size_t>(ts + lr) * FP + 4 * sub);   // tiles > 256 rows
+      if (lr != grp)   // tiles with more rows than lane groups
+        hv = ldg4(hsel + static_cast<size_t>(tile_node(tv, lr)) * FP + 4 * sub);
       if (a.act == GCONV_ACT_RELU) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = hv[k] > 0.f ? v[k] : 0.f;
@@ -638,7 +719,7 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] *= silu_grad(hv[k]);
       }
-      bgrad += v;
+      if (lr < nt) bgrad += v;   // a halo row's share belongs to the tile that owns it
       if (NORM) v *= dl[lr];
       *reinterpret_cast<f32x4*>(bufB + lr * FP + 4 * sub) = v;
     }
@@ -849,7 +930,11 @@ size_t tile_lds_bytes(int d, int fp, int tile_nodes_max, int tile_edges_max) {
 }
 
 bool tile_path_ok(const gconv_graph_t* g, int d, int fp) {
-  if (g->n_tiles <= 0 || !g->tile_ptr || !g->tile_order) return false;
+  if (g->n_tiles <= 0 || !g->tiles_fwd.tiles || !g->tiles_fwd.lcol || !g->tiles_fwd.halo || !g->tiles_bwd.tiles ||
+      !g->tiles_bwd.lcol || !g->tiles_bwd.halo)
+    return false;
+  // phase 1 addresses ALL rows of X / G through one buffer descriptor with 32-bit byte offsets
+  if (static_cast<int64_t>(g->fwd.num_nodes) * d * 4 > 0x7FFF0000LL) return false;
   if (tile_nq(d) == 0 || fp > 32 || ceil_div(d, 64) > 8) return false;
   // wide rows at high rank do not fit the register budget of the fused kernels (they would
   // spill); the four-launch path is the better one there anyway

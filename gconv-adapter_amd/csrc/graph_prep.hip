@@ -6,24 +6,41 @@
 // batch that all adapters of a model forward share.
 //
 // Pipeline (all on `stream`, one host sync for symmetric edge lists):
-//   1. make_keys   : key = (row << b) | col, dropped / invalid edges -> row = N;
-//                    also marks, per node boundary, how many edges span it (+1/-1 diff)
+//   1. make_keys   : key = (row << b) | col, dropped / invalid edges -> row = N
 //   2. radix sort  : hipCUB, 32-bit keys when 2 bits(N) <= 32 (molecule batches), else 64-bit
 //   3. build_csr   : rowptr from key run boundaries, col = low key field
 //   4. row_stats   : dis = (deg + 1)^-1/2, long-row / segment lists, max degree
 //   5. sym_check   : exact multiset test S == S^T by ranked binary search in the CSR
-//   6. tiles       : inclusive scan of the span diff -> edge-free boundaries -> tile starts
-//   7. D2H of the counters, sync; S^T (second sort) only when the test failed
+//   6. tiles       : one wave per tile places its cuts, finds its halo, translates its columns
+//                    (tiles.h; round 2: span-diff atomics + scan + edge-free boundary search)
+//   7. D2H of the counters, sync; S^T (second sort + its tiles) only when the test failed;
+//      size sort of the tile records
 #include <hipcub/hipcub.hpp>
 
 #include <cstdlib>
 
 #include "common.h"
+#include "tiles.h"
 
 namespace gconv {
 
-// a tile holds at most kTileSpan = 512 nodes: 10-bit size keys
-constexpr int kTileSizeMax = 1023, kTileSizeBits = 10;
+int tile_nominal(int n) {
+  static const int forced = [] {
+    const char* v = std::getenv("GCONV_TILE_NODES_OVERRIDE");
+    return v ? std::atoi(v) : 0;
+  }();
+  if (forced > 0) return forced < 16 ? 16 : (forced > 1024 ? 1024 : forced);
+  static const int tmax = [] {
+    const char* v = std::getenv("GCONV_TILE_NODES_MAX");
+    const int k = v ? std::atoi(v) : 0;
+    return k >= GCONV_TILE_NODES ? k : GCONV_TILE_NODES_MAX;
+  }();
+  if (n <= 0) return GCONV_TILE_NODES;
+  const int per_wg = ceil_div(n, kNumCU);
+  const int k = ceil_div(per_wg, tmax);             // tiles per workgroup
+  const int t = ceil_div(n, kNumCU * k);
+  return t < GCONV_TILE_NODES ? GCONV_TILE_NODES : t;
+}
 
 enum {
   INFO_NNZ = 0, INFO_NLONG = 1, INFO_NSEG = 2, INFO_MAXDEG = 3, INFO_BAD = 4,
@@ -51,8 +68,7 @@ static int index_bits(int32_t n) {  // bits needed to represent the values 0 .. 
 template <typename K>
 __global__ void make_keys_kernel(const int64_t* __restrict__ ei, int64_t E, int32_t n,
                                  int normalize, int transpose, KeyOps<K> ko,
-                                 K* __restrict__ keys, int32_t* __restrict__ span,
-                                 int32_t* __restrict__ info) {
+                                 K* __restrict__ keys, int32_t* __restrict__ info) {
   int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (e >= E) return;
   const int64_t s = ei[e], d = ei[E + e];
@@ -65,17 +81,6 @@ __global__ void make_keys_kernel(const int64_t* __restrict__ ei, int64_t E, int3
   } else {
     key = transpose ? ko.make(static_cast<uint32_t>(s), static_cast<uint32_t>(d))
                     : ko.make(static_cast<uint32_t>(d), static_cast<uint32_t>(s));
-    if (span && s != d) {  // boundaries lo+1 .. hi are crossed by this edge
-      const int lo = static_cast<int>(s < d ? s : d), hi = static_cast<int>(s < d ? d : s);
-      if (hi - lo > kTileSpan) {
-        // wider than any tile: the graph is not tileable; skip the atomics (on power-law
-        // graphs thousands of them would pile up on the hub's counter)
-        if (info[INFO_NOTILE] == 0) atomicOr(&info[INFO_NOTILE], 1);
-      } else {
-        atomicAdd(&span[lo + 1], 1);
-        atomicAdd(&span[hi + 1], -1);
-      }
-    }
   }
   keys[e] = key;
 }
@@ -150,96 +155,34 @@ __global__ void sym_check_kernel(const int32_t* __restrict__ rowptr,
   if (q >= rowptr[j + 1] || col[q] != i) atomicOr(asym, 1);
 }
 
-// tile_ptr[t] = last boundary q <= t * B (B = tile_nodes(n)) that no edge spans (span_ps[q] == 0),
-// searched at most kTileSpan - B positions back. One wave per tile: 64 candidate boundaries per step
-// (coalesced load + ballot) instead of a serial walk of up to 480 dependent loads per thread.
-__global__ __launch_bounds__(256) void tile_start_kernel(const int32_t* __restrict__ span_ps, int32_t n,
-                                                         int ntiles, int32_t* __restrict__ tile_ptr,
-                                                         int32_t* __restrict__ info) {
-  const int lane = threadIdx.x & 63;
-  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (t > ntiles) return;
-  if (t == ntiles) {
-    if (lane == 0) tile_ptr[t] = n;
-    return;
-  }
-  const int q0 = t * tile_nodes(n), back = kTileSpan - tile_nodes(n);
-  int found = -1;
-  for (int base = 0; base <= back && found < 0; base += 64) {
-    const int q = q0 - base - lane;                       // lane 0 = the highest candidate
-    const bool cand = q >= 0 && base + lane <= back;
-    const bool ok = cand && (q == 0 || span_ps[q] == 0);
-    const unsigned long long m = __ballot(ok);
-    if (m) found = q0 - base - (__ffsll(static_cast<long long>(m)) - 1);
-    if (q0 - base - 63 <= 0) break;                       // reached the start of the graph
-  }
-  if (lane == 0) {
-    if (found < 0) {   // no edge-free boundary within reach: the graph is not tileable
-      atomicOr(&info[INFO_NOTILE], 1);
-      found = max(q0 - back, 0);
-    }
-    tile_ptr[t] = found;
-  }
-}
-
-// Largest tile (nodes, stored edges) for the LDS budget of the fused kernels, and the keys of
-// the size sort behind gconv_graph_t::tile_order (ascending key = descending node count).
-__global__ void tile_max_kernel(const int32_t* __restrict__ tile_ptr,
-                                const int32_t* __restrict__ rowptr, int ntiles,
-                                int32_t* __restrict__ info, uint32_t* __restrict__ size_key,
-                                uint64_t* __restrict__ tile_span) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  int sz = 0, ed = 0;
-  if (t < ntiles) {
-    sz = tile_ptr[t + 1] - tile_ptr[t];
-    ed = rowptr[tile_ptr[t + 1]] - rowptr[tile_ptr[t]];
-    size_key[t] = static_cast<uint32_t>(kTileSizeMax - min(sz, kTileSizeMax));
-    // (first node, node count) as one 64-bit sort value: low word = first node
-    tile_span[t] = static_cast<uint64_t>(static_cast<uint32_t>(tile_ptr[t])) |
-                   (static_cast<uint64_t>(static_cast<uint32_t>(sz)) << 32);
-  }
-  for (int off = 32; off > 0; off >>= 1) {
-    sz = max(sz, __shfl_xor(sz, off));
-    ed = max(ed, __shfl_xor(ed, off));
-  }
-  if ((threadIdx.x & 63) == 0) {
-    if (sz > 0) atomicMax(&info[INFO_TILEMAX], sz);
-    if (ed > 0) atomicMax(&info[INFO_TILEEDGES], ed);
-  }
-}
-
 // ---------------------------------------------------------------------------
 // arena layout
 // ---------------------------------------------------------------------------
 struct CsrSlots {
   size_t rowptr, col, long_rows, long_seg_base, seg_long, long_sync;
+  size_t recs, tiles, lcol, halo;   // tile data of this direction (unsorted records, sorted records, ...)
 };
 struct BuildLayout {
   CsrSlots f, b;
-  size_t dis, tile_ptr, tile_order, tile_key, tile_key_out, tile_id, span, span_ps, keys_a, keys_b, info, cub,
-      total, cub_bytes;
-  int ntiles;
+  size_t dis, tile_ptr, tile_key, tile_key_out, tile_id, tile_id_out, keys_a, keys_b, info, cub, total, cub_bytes;
+  int ntiles, T;
 };
 
 static int64_t max_long_rows(int64_t E) { return E / (GCONV_LONG_ROW + 1) + 1; }
 static int64_t max_segments(int64_t E) { return E / GCONV_SEG_EDGES + max_long_rows(E) + 1; }
 
-static size_t cub_bytes_for(int64_t E, int32_t n) {
+static size_t cub_bytes_for(int64_t E, int ntiles) {
   const int cnt = static_cast<int>(E > 0 ? E : 1);
-  size_t s64 = 0, s32 = 0, sc = 0;
+  size_t s64 = 0, s32 = 0;
   hipcub::DeviceRadixSort::SortKeys(nullptr, s64, static_cast<const uint64_t*>(nullptr),
                                     static_cast<uint64_t*>(nullptr), cnt, 0, 64, nullptr);
   hipcub::DeviceRadixSort::SortKeys(nullptr, s32, static_cast<const uint32_t*>(nullptr),
                                     static_cast<uint32_t*>(nullptr), cnt, 0, 32, nullptr);
-  hipcub::DeviceScan::InclusiveSum(nullptr, sc, static_cast<const int32_t*>(nullptr),
-                                   static_cast<int32_t*>(nullptr), n + 2, nullptr);
   size_t st = 0;
   hipcub::DeviceRadixSort::SortPairs(nullptr, st, static_cast<const uint32_t*>(nullptr),
-                                     static_cast<uint32_t*>(nullptr), static_cast<const uint64_t*>(nullptr),
-                                     static_cast<uint64_t*>(nullptr), ceil_div(n > 0 ? n : 1, GCONV_TILE_NODES),
-                                     0, kTileSizeBits, nullptr);
+                                     static_cast<uint32_t*>(nullptr), static_cast<const uint32_t*>(nullptr),
+                                     static_cast<uint32_t*>(nullptr), ntiles, 0, kTileSizeBits, nullptr);
   size_t m = s64 > s32 ? s64 : s32;
-  m = m > sc ? m : sc;
   return m > st ? m : st;
 }
 
@@ -248,6 +191,9 @@ static BuildLayout build_layout(int64_t E, int32_t n) {
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes + 16, 256); return o; };
   const size_t e1 = static_cast<size_t>(E > 0 ? E : 1);
+  L.T = tile_nominal(n);
+  L.ntiles = ceil_div(n > 0 ? n : 1, L.T);
+  const size_t nt = static_cast<size_t>(L.ntiles);
   auto csr = [&](CsrSlots& c) {
     c.rowptr = take((static_cast<size_t>(n) + 1) * 4);
     c.col = take(e1 * 4);
@@ -255,22 +201,23 @@ static BuildLayout build_layout(int64_t E, int32_t n) {
     c.long_seg_base = take(static_cast<size_t>(max_long_rows(E)) * 4);
     c.seg_long = take(static_cast<size_t>(max_segments(E)) * 4);
     c.long_sync = take(static_cast<size_t>(max_long_rows(E)) * 4);
+    c.recs = take(nt * sizeof(gconv_tile_t));
+    c.tiles = take(nt * sizeof(gconv_tile_t));
+    c.lcol = take(e1 * 4);
+    c.halo = take(nt * kHaloSlot * 4);
   };
   csr(L.f);
   csr(L.b);
-  L.ntiles = ceil_div(n > 0 ? n : 1, tile_nodes(n));
   L.dis = take((static_cast<size_t>(n) + 1) * 4);
-  L.tile_ptr = take((static_cast<size_t>(L.ntiles) + 1) * 4);
-  L.tile_order = take(static_cast<size_t>(L.ntiles) * 8);
-  L.tile_key = take(static_cast<size_t>(L.ntiles) * 4);
-  L.tile_key_out = take(static_cast<size_t>(L.ntiles) * 4);
-  L.tile_id = take(static_cast<size_t>(L.ntiles) * 8);
-  L.span = take((static_cast<size_t>(n) + 2) * 4);
-  L.span_ps = take((static_cast<size_t>(n) + 2) * 4);
+  L.tile_ptr = take((nt + 1) * 4);
+  L.tile_key = take(nt * 4);
+  L.tile_key_out = take(nt * 4);
+  L.tile_id = take(nt * 4);
+  L.tile_id_out = take(nt * 4);
   L.keys_a = take(e1 * 8);
   L.keys_b = take(e1 * 8);
   L.info = take(64 * 4);
-  L.cub_bytes = cub_bytes_for(E, n);
+  L.cub_bytes = cub_bytes_for(E, L.ntiles);
   L.cub = take(L.cub_bytes + 256);
   L.total = off;
   return L;
@@ -285,8 +232,8 @@ struct CsrOut {
 template <typename K>
 static gconv_status_t build_direction(const int64_t* ei, int64_t E, int32_t n, int normalize,
                                       int transpose, int shift, char* arena, const BuildLayout& L,
-                                      const CsrOut& o, float* dis, int32_t* span, int32_t* info,
-                                      int base, hipStream_t stream) {
+                                      const CsrOut& o, float* dis, int32_t* info, int base,
+                                      hipStream_t stream) {
   KeyOps<K> ko{shift};
   K* keys_a = reinterpret_cast<K*>(arena + L.keys_a);
   K* keys_b = reinterpret_cast<K*>(arena + L.keys_b);
@@ -294,7 +241,7 @@ static gconv_status_t build_direction(const int64_t* ei, int64_t E, int32_t n, i
   const K* sorted = keys_a;
   if (E > 0) {
     make_keys_kernel<K><<<static_cast<unsigned>((E + T - 1) / T), T, 0, stream>>>(
-        ei, E, n, normalize, transpose, ko, keys_a, span, info);
+        ei, E, n, normalize, transpose, ko, keys_a, info);
     GCONV_LAUNCH_CHECK();
     size_t cub_bytes = L.cub_bytes;
     GCONV_HIP(hipcub::DeviceRadixSort::SortKeys(arena + L.cub, cub_bytes, keys_a, keys_b,
@@ -421,17 +368,19 @@ __device__ __forceinline__ void small_bitonic_sort(uint32_t (&v)[NR], uint32_t* 
 }
 
 struct SmallBuildArgs {
-  const int64_t* ei; int32_t E, n, normalize, shift, nsort, ntiles;
+  const int64_t* ei; int32_t E, n, normalize, shift, nsort, ntiles, T, slack;
   // outputs (device): forward / transposed CSR slots, dis, tiles, info
   int32_t *rowptr_f, *col_f, *long_rows_f, *long_seg_base_f, *seg_long_f; uint32_t* long_sync_f;
   int32_t *rowptr_b, *col_b, *long_rows_b, *long_seg_base_b, *seg_long_b; uint32_t* long_sync_b;
-  float* dis; int32_t* tile_ptr; uint64_t* tile_order; int32_t* info;
+  float* dis; int32_t* tile_ptr; int32_t* info;
+  gconv_tile_t *recs_f, *recs_b, *tiles_f, *tiles_b;   // unsorted / size-sorted tile records
+  int32_t *lcol_f, *lcol_b, *halo_f, *halo_b;
 };
 
 // sort + CSR + row statistics of one direction out of LDS; counters -> sinfo[base .. base + 3]
 template <int NR, int T>
 __device__ __forceinline__ void small_direction(const SmallBuildArgs& a, int transpose, uint32_t* keys,
-                                                int32_t* rowptr, int32_t* span, int32_t* tmp, int32_t* flags,
+                                                int32_t* rowptr, int32_t* tmp, int32_t* flags,
                                                 int32_t* flags2, int32_t* out_rowptr, int32_t* out_col,
                                                 float* out_dis, int32_t* out_long_rows,
                                                 int32_t* out_long_seg_base, int32_t* out_seg_long,
@@ -454,11 +403,6 @@ __device__ __forceinline__ void small_direction(const SmallBuildArgs& a, int tra
       } else {
         key = transpose ? ko.make(static_cast<uint32_t>(s), static_cast<uint32_t>(d))
                         : ko.make(static_cast<uint32_t>(d), static_cast<uint32_t>(s));
-        if (span && s != d) {
-          const int lo = static_cast<int>(s < d ? s : d), hi = static_cast<int>(s < d ? d : s);
-          if (hi - lo > kTileSpan) sinfo[INFO_NOTILE] = 1;
-          else { atomicAdd(&span[lo + 1], 1); atomicAdd(&span[hi + 1], -1); }
-        }
       }
     }
     kv[r] = key;
@@ -515,21 +459,20 @@ __device__ __forceinline__ void small_direction(const SmallBuildArgs& a, int tra
 template <int NR, int T>
 __global__ __launch_bounds__(T) void small_graph_build_kernel(SmallBuildArgs a) {
   extern __shared__ int32_t sm[];
-  // layout: keys[nsort] | rowptr[n + 1] | span[n + 2] | flags[n] | flags2[n] | tmp[1024] | tptr[ntiles + 1] | sinfo[64]
+  // layout: keys[nsort] | rowptr[n + 1] | flags[n] | flags2[n] | tmp[1024] | tsize[ntiles] | sinfo[64]
   uint32_t* keys = reinterpret_cast<uint32_t*>(sm);
   int32_t* rowptr = sm + a.nsort;
-  int32_t* span = rowptr + a.n + 1;
-  int32_t* flags = span + a.n + 2;
+  int32_t* flags = rowptr + a.n + 1;
   int32_t* flags2 = flags + a.n;
   int32_t* tmp = flags2 + a.n;
-  int32_t* tptr = tmp + T;
-  int32_t* sinfo = tptr + a.ntiles + 1;   // the info words (enum above; forward counters at 16, transposed at 24)
+  int32_t* tsize = tmp + T;
+  int32_t* sinfo = tsize + a.ntiles;   // the info words (enum above; forward counters at 16, transposed at 24)
   const int tid = threadIdx.x, n = a.n;
-  for (int i = tid; i < n + 2; i += T) span[i] = 0;
+  const int lane = tid & 63, wave = tid >> 6;
   if (tid < 64) sinfo[tid] = 0;
   __syncthreads();
 
-  small_direction<NR, T>(a, 0, keys, rowptr, span, tmp, flags, flags2, a.rowptr_f, a.col_f, a.dis, a.long_rows_f,
+  small_direction<NR, T>(a, 0, keys, rowptr, tmp, flags, flags2, a.rowptr_f, a.col_f, a.dis, a.long_rows_f,
                   a.long_seg_base_f, a.seg_long_f, a.long_sync_f, 16, sinfo);
   const KeyOps<uint32_t> ko{a.shift};
   const int nnz = rowptr[n];
@@ -546,60 +489,44 @@ __global__ __launch_bounds__(T) void small_graph_build_kernel(SmallBuildArgs a) 
     const int q = rowptr[j] + small_lower_bound(keys + rowptr[j], rowptr[j + 1] - rowptr[j], ko.make(j, i)) + k;
     if (q >= rowptr[j + 1] || keys[q] != ko.make(j, i)) sinfo[INFO_ASYM] = 1;
   }
-  __syncthreads();
+  __syncthreads();   // (also: the CSR this workgroup wrote to global memory is complete)
 
-  // component tiles: inclusive scan of the span diff, tile starts (tile_start_kernel), tile maxima
-  {
-    const int total = small_exclusive_scan<T>(span, n + 2, tmp);   // exclusive; inclusive[q] = excl[q] + diff[q]
-    (void)total;
-    // span now holds the EXCLUSIVE prefix: inclusive value at q = span[q + 1] for q <= n
-    const int B = tile_nodes(n), back = kTileSpan - B;
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int t = wave; t <= a.ntiles; t += T / 64) {   // one wave per tile
-      if (t == a.ntiles) { if (lane == 0) tptr[t] = n; continue; }
-      const int q0 = t * B;
-      int found = -1;
-      for (int base = 0; base <= back && found < 0; base += 64) {
-        const int q = q0 - base - lane;
-        const bool cand = q >= 0 && base + lane <= back;
-        const bool ok = cand && (q == 0 || span[min(q, n) + 1] == 0);
-        const unsigned long long m = __ballot(ok);
-        if (m) found = q0 - base - (__ffsll(static_cast<long long>(m)) - 1);
-        if (q0 - base - 63 <= 0) break;
-      }
-      if (lane == 0) {
-        if (found < 0) { sinfo[INFO_NOTILE] = 1; found = max(q0 - back, 0); }
-        tptr[t] = found;
-      }
-    }
-    __syncthreads();
-    int sz = 0, ed = 0;
-    for (int t = tid; t < a.ntiles; t += T) {
-      sz = max(sz, tptr[t + 1] - tptr[t]);
-      ed = max(ed, rowptr[tptr[t + 1]] - rowptr[tptr[t]]);
-    }
-    for (int off = 32; off > 0; off >>= 1) { sz = max(sz, __shfl_xor(sz, off)); ed = max(ed, __shfl_xor(ed, off)); }
+  // tiles (tiles.h): one wave per tile places its cuts on the global CSR this workgroup has just
+  // written, finds its halo and translates its columns; same routine as the multi-launch build
+  const TileInfoSlots is{INFO_NOTILE, INFO_TILEMAX, INFO_TILEEDGES};
+  for (int t = wave; t < a.ntiles; t += T / 64) {
+    const int ts = tile_cut_wave(a.rowptr_f, a.col_f, n, t, a.ntiles, a.T, a.slack, lane);
+    const int te = tile_cut_wave(a.rowptr_f, a.col_f, n, t + 1, a.ntiles, a.T, a.slack, lane);
     if (lane == 0) {
-      if (sz > 0) atomicMax(&sinfo[INFO_TILEMAX], sz);
-      if (ed > 0) atomicMax(&sinfo[INFO_TILEEDGES], ed);
+      a.tile_ptr[t] = ts;
+      if (t == a.ntiles - 1) a.tile_ptr[a.ntiles] = n;
     }
-    for (int t = tid; t <= a.ntiles; t += T) a.tile_ptr[t] = tptr[t];
-    // size-sorted tile list: rank by (size descending, index ascending) == small_tile_sort_kernel
-    for (int t = tid; t < a.ntiles; t += T) {
-      const int s0 = tptr[t + 1] - tptr[t];
-      int rank = 0;
-      for (int u = 0; u < a.ntiles; ++u) {
-        const int su = tptr[u + 1] - tptr[u];
-        rank += (su > s0) || (su == s0 && u < t);
-      }
-      a.tile_order[rank] = static_cast<uint64_t>(static_cast<uint32_t>(tptr[t])) |
-                           (static_cast<uint64_t>(static_cast<uint32_t>(s0)) << 32);
-    }
+    tile_halo_wave(a.rowptr_f, a.col_f, a.dis, ts, te, t, a.lcol_f, a.halo_f, a.recs_f + t, sinfo, is, lane);
   }
   __syncthreads();
-  if (sinfo[INFO_ASYM])   // uniform: directed edge list -> S^T as well, in the same launch
-    small_direction<NR, T>(a, 1, keys, rowptr, nullptr, tmp, flags, flags2, a.rowptr_b, a.col_b, nullptr, a.long_rows_b,
+  const bool asym = sinfo[INFO_ASYM] != 0;   // uniform: directed edge list -> S^T as well, in the same launch
+  if (asym) {
+    small_direction<NR, T>(a, 1, keys, rowptr, tmp, flags, flags2, a.rowptr_b, a.col_b, nullptr, a.long_rows_b,
                     a.long_seg_base_b, a.seg_long_b, a.long_sync_b, 24, sinfo);
+    __syncthreads();
+    for (int t = wave; t < a.ntiles; t += T / 64)
+      tile_halo_wave(a.rowptr_b, a.col_b, a.dis, a.tile_ptr[t], a.tile_ptr[t + 1], t, a.lcol_b, a.halo_b, a.recs_b + t,
+                     sinfo, is, lane);
+    __syncthreads();
+  }
+  // size-sorted tile list: rank by (rows incl. halo descending, index ascending) == tile_sort_small_kernel
+  for (int t = tid; t < a.ntiles; t += T) tsize[t] = a.recs_f[t].n0;
+  __syncthreads();
+  for (int t = tid; t < a.ntiles; t += T) {
+    const int s0 = tsize[t];
+    int rank = 0;
+    for (int u = 0; u < a.ntiles; ++u) {
+      const int su = tsize[u];
+      rank += (su > s0) || (su == s0 && u < t);
+    }
+    a.tiles_f[rank] = a.recs_f[t];
+    if (asym) a.tiles_b[rank] = a.recs_b[t];
+  }
   __syncthreads();
   if (tid < 64) a.info[tid] = sinfo[tid];
 }
@@ -613,6 +540,8 @@ static bool small_build_ok(int64_t E, int32_t n) {   // (env read per call: the 
 }  // namespace gconv
 
 using namespace gconv;
+
+extern "C" int32_t gconv_tile_nodes(int32_t num_nodes) { return tile_nominal(num_nodes); }
 
 extern "C" size_t gconv_graph_build_bytes(int64_t num_edges, int32_t num_nodes) {
   if (num_edges < 0 || num_nodes < 0) return 0;
@@ -641,14 +570,20 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
                   reinterpret_cast<int32_t*>(arena + c.seg_long),
                   reinterpret_cast<uint32_t*>(arena + c.long_sync)};
   };
+  struct TileOut { gconv_tile_t *recs, *tiles; int32_t *lcol, *halo; };
+  auto tslots = [&](const CsrSlots& c) {
+    return TileOut{reinterpret_cast<gconv_tile_t*>(arena + c.recs), reinterpret_cast<gconv_tile_t*>(arena + c.tiles),
+                   reinterpret_cast<int32_t*>(arena + c.lcol), reinterpret_cast<int32_t*>(arena + c.halo)};
+  };
   const CsrOut of = slots(L.f), ob = slots(L.b);
+  const TileOut tf = tslots(L.f), tb = tslots(L.b);
   float* dis = normalize ? reinterpret_cast<float*>(arena + L.dis) : nullptr;
   int32_t* tile_ptr = reinterpret_cast<int32_t*>(arena + L.tile_ptr);
-  int32_t* span = reinterpret_cast<int32_t*>(arena + L.span);
-  int32_t* span_ps = reinterpret_cast<int32_t*>(arena + L.span_ps);
   int32_t* info = reinterpret_cast<int32_t*>(arena + L.info);
-  // info words: [0..7] flags (enum above); forward counters at 16.., transposed at 24..
+  // info words: [0..8] flags / maxima (enum above); forward counters at 16.., transposed at 24..
   const int FWD = 16, BWD = 24;
+  const TileInfoSlots is{INFO_NOTILE, INFO_TILEMAX, INFO_TILEEDGES};
+  const int slack = tile_slack(L.T);
 
   auto fill = [&](gconv_csr_t& c, const CsrOut& o, const int32_t* cnt) {
     c.num_nodes = n; c.nnz = cnt[0];
@@ -657,10 +592,18 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
     c.long_rows = o.long_rows; c.long_seg_base = o.long_seg_base; c.seg_long = o.seg_long;
     c.long_sync = o.long_sync;
   };
+  auto fill_tiles = [&](const int32_t* h, bool symmetric) {
+    g->tile_ptr = tile_ptr;
+    g->tiles_fwd = gconv_tiling_t{tf.tiles, tf.lcol, tf.halo};
+    g->tiles_bwd = symmetric ? g->tiles_fwd : gconv_tiling_t{tb.tiles, tb.lcol, tb.halo};
+    g->n_tiles = (h[INFO_NOTILE] || n == 0) ? 0 : L.ntiles;
+    g->tile_nodes_max = h[INFO_TILEMAX];
+    g->tile_edges_max = h[INFO_TILEEDGES];
+  };
   if (small_build_ok(E, n)) {   // ONE launch, ONE synchronisation (see small_graph_build_kernel)
     SmallBuildArgs a{};
     a.ei = edge_index; a.E = static_cast<int32_t>(E); a.n = n; a.normalize = normalize ? 1 : 0;
-    a.shift = index_bits(n); a.ntiles = L.ntiles;
+    a.shift = index_bits(n); a.ntiles = L.ntiles; a.T = L.T; a.slack = slack;
     const int threads = 1024;
     a.nsort = threads;
     while (a.nsort < E) a.nsort <<= 1;
@@ -668,10 +611,11 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
     a.seg_long_f = of.seg_long; a.long_sync_f = of.long_sync;
     a.rowptr_b = ob.rowptr; a.col_b = ob.col; a.long_rows_b = ob.long_rows; a.long_seg_base_b = ob.long_seg_base;
     a.seg_long_b = ob.seg_long; a.long_sync_b = ob.long_sync;
-    a.dis = dis; a.tile_ptr = tile_ptr; a.tile_order = reinterpret_cast<uint64_t*>(arena + L.tile_order);
-    a.info = info;
-    const size_t lds = (static_cast<size_t>(a.nsort) + (n + 1) + (n + 2) + 2 * static_cast<size_t>(n) + threads +
-                        (L.ntiles + 1) + 64) * sizeof(int32_t);
+    a.dis = dis; a.tile_ptr = tile_ptr; a.info = info;
+    a.recs_f = tf.recs; a.recs_b = tb.recs; a.tiles_f = tf.tiles; a.tiles_b = tb.tiles;
+    a.lcol_f = tf.lcol; a.lcol_b = tb.lcol; a.halo_f = tf.halo; a.halo_b = tb.halo;
+    const size_t lds = (static_cast<size_t>(a.nsort) + (n + 1) + 2 * static_cast<size_t>(n) + threads +
+                        L.ntiles + 64) * sizeof(int32_t);
 #define GCONV_SMALL_BUILD(NR_, T_)                                                                     \
   do {                                                                                                 \
     if (lds > 48 * 1024)                                                                               \
@@ -698,23 +642,18 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
     g->symmetric = h[INFO_ASYM] ? 0 : 1;
     if (g->symmetric) g->bwd = g->fwd; else fill(g->bwd, ob, h + 24);
     g->dis = dis;
-    g->tile_ptr = tile_ptr;
-    g->tile_order = reinterpret_cast<int32_t*>(arena + L.tile_order);
-    g->n_tiles = h[INFO_NOTILE] ? 0 : L.ntiles;
-    g->tile_nodes_max = h[INFO_TILEMAX];
-    g->tile_edges_max = h[INFO_TILEEDGES];
+    fill_tiles(h, g->symmetric != 0);
     g->normalize = normalize ? 1 : 0;
     g->bad_index = 0;
     return GCONV_OK;
   }
 
   GCONV_HIP(hipMemsetAsync(info, 0, 64 * sizeof(int32_t), stream));
-  GCONV_HIP(hipMemsetAsync(span, 0, (static_cast<size_t>(n) + 2) * sizeof(int32_t), stream));
   const int b = index_bits(n);
   const bool k32 = 2 * b <= 32;
   gconv_status_t st =
-      k32 ? build_direction<uint32_t>(edge_index, E, n, normalize, 0, b, arena, L, of, dis, span, info, FWD, stream)
-          : build_direction<uint64_t>(edge_index, E, n, normalize, 0, b, arena, L, of, dis, span, info, FWD, stream);
+      k32 ? build_direction<uint32_t>(edge_index, E, n, normalize, 0, b, arena, L, of, dis, info, FWD, stream)
+          : build_direction<uint64_t>(edge_index, E, n, normalize, 0, b, arena, L, of, dis, info, FWD, stream);
   if (st != GCONV_OK) return st;
 
   const int T = 256;
@@ -723,15 +662,9 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
         of.rowptr, of.col, n, info + FWD, info + INFO_ASYM);
     GCONV_LAUNCH_CHECK();
   }
-  // component tiles
-  {
-    size_t cub_bytes = L.cub_bytes;
-    GCONV_HIP(hipcub::DeviceScan::InclusiveSum(arena + L.cub, cub_bytes, span, span_ps, n + 2, stream));
-    tile_start_kernel<<<(L.ntiles + 1 + 3) / 4, 256, 0, stream>>>(span_ps, n, L.ntiles, tile_ptr, info);
-    GCONV_LAUNCH_CHECK();
-    tile_max_kernel<<<(L.ntiles + T - 1) / T, T, 0, stream>>>(
-        tile_ptr, of.rowptr, L.ntiles, info, reinterpret_cast<uint32_t*>(arena + L.tile_key),
-        reinterpret_cast<uint64_t*>(arena + L.tile_id));
+  if (n > 0) {   // tiles of the forward CSR: cuts, halos, local columns (one wave per tile)
+    tile_build_kernel<true><<<(L.ntiles + 3) / 4, 256, 0, stream>>>(of.rowptr, of.col, dis, n, L.ntiles, L.T, slack,
+                                                                    tile_ptr, tf.lcol, tf.halo, tf.recs, info, is);
     GCONV_LAUNCH_CHECK();
   }
   int32_t h[64];
@@ -747,31 +680,39 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
   g->symmetric = h[INFO_ASYM] ? 0 : 1;
   if (g->symmetric) {
     g->bwd = g->fwd;
-  } else {  // rare path (directed edge lists): second sort for S^T, second sync
-    st = k32 ? build_direction<uint32_t>(edge_index, E, n, normalize, 1, b, arena, L, ob, nullptr, nullptr, info, BWD, stream)
-             : build_direction<uint64_t>(edge_index, E, n, normalize, 1, b, arena, L, ob, nullptr, nullptr, info, BWD, stream);
+  } else {  // rare path (directed edge lists): second sort for S^T, its tiles on the same cuts, second sync
+    st = k32 ? build_direction<uint32_t>(edge_index, E, n, normalize, 1, b, arena, L, ob, nullptr, info, BWD, stream)
+             : build_direction<uint64_t>(edge_index, E, n, normalize, 1, b, arena, L, ob, nullptr, info, BWD, stream);
     if (st != GCONV_OK) return st;
+    if (n > 0) {
+      tile_build_kernel<false><<<(L.ntiles + 3) / 4, 256, 0, stream>>>(ob.rowptr, ob.col, dis, n, L.ntiles, L.T, slack,
+                                                                       tile_ptr, tb.lcol, tb.halo, tb.recs, info, is);
+      GCONV_LAUNCH_CHECK();
+    }
     GCONV_HIP(hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, stream));
     GCONV_HIP(hipStreamSynchronize(stream));
     fill(g->bwd, ob, h + BWD);
   }
   g->dis = dis;
-  g->tile_ptr = tile_ptr;
-  g->tile_order = reinterpret_cast<int32_t*>(arena + L.tile_order);
-  g->n_tiles = (h[INFO_NOTILE] || n == 0) ? 0 : L.ntiles;
+  fill_tiles(h, g->symmetric != 0);
+  gconv_tile_t* recs_b = g->symmetric ? nullptr : tb.recs;
   if (g->n_tiles > 0 && L.ntiles <= kSmallSortMax) {
-    small_tile_sort_kernel<<<1, 1024, 0, stream>>>(tile_ptr, L.ntiles,
-                                                   reinterpret_cast<uint64_t*>(arena + L.tile_order));
+    tile_sort_small_kernel<<<1, 1024, 0, stream>>>(tf.recs, recs_b, L.ntiles, tf.tiles, tb.tiles);
     GCONV_LAUNCH_CHECK();
   } else if (g->n_tiles > 0) {  // largest tile first; stable, so the order is a function of the graph alone
+    uint32_t* key = reinterpret_cast<uint32_t*>(arena + L.tile_key);
+    uint32_t* key_out = reinterpret_cast<uint32_t*>(arena + L.tile_key_out);
+    uint32_t* id = reinterpret_cast<uint32_t*>(arena + L.tile_id);
+    uint32_t* id_out = reinterpret_cast<uint32_t*>(arena + L.tile_id_out);
+    tile_sort_keys_kernel<<<(L.ntiles + T - 1) / T, T, 0, stream>>>(tf.recs, L.ntiles, key, id);
+    GCONV_LAUNCH_CHECK();
     size_t cub_bytes = L.cub_bytes;
-    GCONV_HIP(hipcub::DeviceRadixSort::SortPairs(
-        arena + L.cub, cub_bytes, reinterpret_cast<const uint32_t*>(arena + L.tile_key),
-        reinterpret_cast<uint32_t*>(arena + L.tile_key_out), reinterpret_cast<const uint64_t*>(arena + L.tile_id),
-        reinterpret_cast<uint64_t*>(arena + L.tile_order), L.ntiles, 0, kTileSizeBits, stream));
+    GCONV_HIP(hipcub::DeviceRadixSort::SortPairs(arena + L.cub, cub_bytes, key, key_out, id, id_out, L.ntiles, 0,
+                                                 kTileSizeBits, stream));
+    tile_sort_gather_kernel<<<(L.ntiles + T - 1) / T, T, 0, stream>>>(tf.recs, recs_b, id_out, L.ntiles, tf.tiles,
+                                                                      tb.tiles);
+    GCONV_LAUNCH_CHECK();
   }
-  g->tile_nodes_max = h[INFO_TILEMAX];
-  g->tile_edges_max = h[INFO_TILEEDGES];
   g->normalize = normalize ? 1 : 0;
   g->bad_index = 0;
   return GCONV_OK;

@@ -1,0 +1,276 @@
+// Tiles of the fused adapter kernels (fused_tile.hip): how a graph plan cuts the node range into
+// pieces that ONE workgroup each runs end to end, and what a piece needs besides its own rows.
+//
+// A tile owns a contiguous node range [first, first + count). Cuts are placed near the multiples
+// of the nominal tile size T (tile_nominal: about N / 256 nodes, so that each of the 256
+// persistent workgroups gets ONE tile of about the same size), preferably on a boundary that no
+// edge crosses — collated molecule batches have one between any two molecules — but a cut may go
+// THROUGH a component: the two-hop neighbourhood the adapter needs then comes along as a halo.
+//   phase 1 (down projection)  runs on own rows + halo1 + halo2   (n0 rows)
+//   phase 2 (first propagate)  runs on own rows + halo1           (n1 rows)
+//   phase 3 / 4                run on the own rows                (count rows)
+// halo1 = nodes outside the range that an own row gathers from, halo2 = nodes outside both that a
+// halo1 row gathers from. Halo rows are recomputed by every tile that needs them (a row's value
+// is a fixed-order sum: every copy has the same bits) and never stored, so tiles exchange
+// nothing and each output row has exactly one writer. Round 2 cut only at edge-free boundaries:
+// a batch's largest molecule (129 of 13104 nodes in the 512-molecule HIV shard) was one tile on
+// one CU and set the kernel's length.
+//
+// Per tile the plan stores a record (gconv_tile_t), the own rows' column ids translated to tile-
+// local row numbers (`lcol`, indexed like the CSR's `col`; local id = node - first for own nodes,
+// count + k for the k-th halo node) and a fixed-size halo slot: halo node ids (halo1 first, in
+// order of first appearance), the local rowptr of the halo1 rows and their local column ids.
+// A tile whose halo outgrows the slot (64 nodes, 256 edges) makes the graph "not tileable"
+// (n_tiles = 0: the general path runs) — molecules stay far below, expanders exceed it at once.
+#pragma once
+
+#include <climits>
+
+#include "common.h"
+
+namespace gconv {
+
+constexpr int kHaloNodes = GCONV_TILE_HALO_NODES;   // 64: one lane per halo node
+constexpr int kHaloEdges = GCONV_TILE_HALO_EDGES;   // 256
+constexpr int kHaloRpOff = kHaloNodes;                       // [kHaloNodes + 1] local rowptr of the halo1 rows
+constexpr int kHaloColOff = 2 * kHaloNodes + 4;              // [kHaloEdges] local column ids of the halo1 rows
+constexpr int kHaloDisOff = kHaloColOff + kHaloEdges;        // [kHaloNodes] dis of the halo nodes (float)
+constexpr int kHaloSlot = GCONV_TILE_HALO_SLOT;              // 4-byte words per tile
+static_assert(kHaloDisOff + kHaloNodes <= kHaloSlot && kHaloColOff % 4 == 0 && kHaloSlot % 4 == 0, "halo slot layout");
+static_assert(kHaloNodes == 64, "tile_halo_wave keeps one halo node per lane");
+
+// counters of a build that the tile kernels report into (indices into the build's info words)
+struct TileInfoSlots { int notile, nodes_max, edges_max; };
+
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+  return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
+  return v;
+}
+
+// Cut k of `ntiles` (0 < k < ntiles) at nominal position q0 = k * T: the candidate closest to q0
+// in (q0 - slack, q0] that no edge of the rows within reach crosses, q0 itself if there is none.
+// "Within reach" = 128 rows below and 64 rows above q0, through each row's smallest and largest
+// column (rows are sorted): exact for the tree-plus-chords layouts of molecules, a heuristic in
+// general — correctness never depends on it (tile_halo_wave finds every crossing edge).
+// One wave; all lanes return the cut.
+__device__ __forceinline__ int tile_cut_wave(const int32_t* __restrict__ rowptr,
+                                             const int32_t* __restrict__ col, int n, int k, int ntiles,
+                                             int T, int slack, int lane) {
+  if (k <= 0) return 0;
+  if (k >= ntiles) return n;
+  const int q0 = k * T;
+  auto reach = [&](int row, int& mx, int& mn) {
+    mx = -1; mn = INT_MAX;
+    if (row >= 0 && row < n) {
+      const int a = rowptr[row], b = rowptr[row + 1];
+      if (b > a) { mn = col[a]; mx = col[b - 1]; }
+    }
+  };
+  int mxA, mnA, mxB, mnB, mxC, mnC;
+  reach(q0 - 128 + lane, mxA, mnA);
+  reach(q0 - 64 + lane, mxB, mnB);    // lane b <-> row q0 - 64 + b
+  reach(q0 + lane, mxC, mnC);
+  (void)mnA; (void)mxC;
+  const int maxA = wave_max_i(mxA), minC = wave_min_i(mnC);
+  int pm = mxB;                        // inclusive prefix maximum over the lanes of B
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(pm, off);
+    if (lane >= off) pm = max(pm, v);
+  }
+  int sm = mnB;                        // inclusive suffix minimum over the lanes of B
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_down(sm, off);
+    if (lane + off < 64) sm = min(sm, v);
+  }
+  int sme = __shfl_down(sm, 1);        // exclusive: rows above this lane's
+  if (lane == 63) sme = INT_MAX;
+  // lane j <-> candidate q = q0 - 63 + j: rows below q are A and the lanes <= j of B
+  const int q = q0 - 63 + lane;
+  const bool crossed = max(maxA, pm) >= q || min(sme, minC) < q;
+  const bool cand = q >= 1 && q0 - q < slack;
+  const unsigned long long m = __ballot(cand && !crossed);
+  if (m == 0) return q0;
+  return q0 - 63 + (63 - __clzll(static_cast<long long>(m)));
+}
+
+// Halo, local column ids and record of tile t = rows [ts, te) of one CSR (forward or transposed).
+// One wave. `rec` receives the unsorted record (slot = t).
+__device__ __forceinline__ void tile_halo_wave(const int32_t* __restrict__ rowptr,
+                                               const int32_t* __restrict__ col,
+                                               const float* __restrict__ dis, int ts, int te, int t,
+                                               int32_t* __restrict__ lcol, int32_t* __restrict__ slots,
+                                               gconv_tile_t* __restrict__ rec, int32_t* info,
+                                               TileInfoSlots is, int lane) {
+  const int nt = te - ts;
+  int32_t* hnodes = slots + static_cast<size_t>(t) * kHaloSlot;
+  int32_t* hrp = hnodes + kHaloRpOff;
+  int32_t* hcol = hnodes + kHaloColOff;
+  const int e0 = rowptr[ts], e1 = rowptr[te];
+  int hval = -1;       // lane j: the j-th halo node
+  int hcount = 0;      // wave-uniform
+  bool overflow = false;
+  // appends the nodes c of the lanes in m that are not in the list yet, in lane order
+  auto append = [&](unsigned long long m, int c) {
+    while (m) {
+      const int b = __ffsll(static_cast<long long>(m)) - 1;
+      m &= m - 1;
+      const int v = __shfl(c, b);
+      if (__ballot(hval == v) == 0) {
+        if (hcount < kHaloNodes) {
+          if (lane == hcount) hval = v;
+          ++hcount;
+        } else {
+          overflow = true;
+        }
+      }
+    }
+  };
+  for (int base = e0; base < e1; base += 64) {           // halo1: outside columns of the own rows
+    const int e = base + lane;
+    const int c = e < e1 ? col[e] : ts;
+    append(__ballot(e < e1 && (c < ts || c >= te)), c);
+  }
+  const int nh1 = hcount;
+  int he = 0;
+  for (int h = 0; h < nh1; ++h) {                         // halo2: outside columns of the halo1 rows
+    const int row = __shfl(hval, h);
+    const int a = rowptr[row], b = rowptr[row + 1];
+    for (int base = a; base < b; base += 64) {
+      const int e = base + lane;
+      const int c = e < b ? col[e] : ts;
+      append(__ballot(e < b && (c < ts || c >= te)), c);
+    }
+    he += b - a;
+  }
+  if (he > kHaloEdges) overflow = true;
+  // tile-local id of column c (uniform control flow: every lane walks the list when any needs it)
+  auto local_id = [&](int c, bool outside) {
+    int id = c - ts;
+    if (__ballot(outside)) {
+      for (int j = 0; j < hcount; ++j) {
+        const int v = __shfl(hval, j);
+        if (outside && v == c) id = nt + j;
+      }
+    }
+    return id;
+  };
+  for (int base = e0; base < e1; base += 64) {
+    const int e = base + lane;
+    const bool ok = e < e1;
+    const int c = ok ? col[e] : ts;
+    const int id = local_id(c, ok && (c < ts || c >= te));
+    if (ok) lcol[e] = id;
+  }
+  int run = 0;
+  if (lane == 0) hrp[0] = 0;
+  for (int h = 0; h < nh1; ++h) {
+    const int row = __shfl(hval, h);
+    const int a = rowptr[row], b = rowptr[row + 1];
+    for (int base = a; base < b; base += 64) {
+      const int e = base + lane;
+      const bool ok = e < b;
+      const int c = ok ? col[e] : ts;
+      const int id = local_id(c, ok && (c < ts || c >= te));
+      const int pos = run + (e - a);
+      if (ok && pos < kHaloEdges) hcol[pos] = id;
+    }
+    run += b - a;
+    if (lane == 0) hrp[h + 1] = run;
+  }
+  if (lane < hcount) {
+    hnodes[lane] = hval;
+    if (dis) reinterpret_cast<float*>(hnodes + kHaloDisOff)[lane] = dis[hval];
+  }
+  if (lane == 0) {
+    gconv_tile_t r;
+    r.first = ts; r.count = nt; r.n1 = nt + nh1; r.n0 = nt + hcount; r.slot = t; r.e0 = e0;
+    r.ne_own = e1 - e0; r.ne_halo = he;
+    *rec = r;
+    if (overflow) atomicOr(&info[is.notile], 1);
+    atomicMax(&info[is.nodes_max], nt + hcount);
+    atomicMax(&info[is.edges_max], e1 - e0 + min(he, kHaloEdges));
+  }
+}
+
+// One wave per tile. CUTS: the wave places its own two cuts (and publishes the lower one in
+// tile_ptr); otherwise the cuts are read from tile_ptr (the transposed CSR of a directed edge list
+// is tiled on the cuts chosen for the forward one).
+template <bool CUTS>
+__global__ __launch_bounds__(256) void tile_build_kernel(const int32_t* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ col,
+                                                         const float* __restrict__ dis, int n, int ntiles,
+                                                         int T, int slack, int32_t* __restrict__ tile_ptr,
+                                                         int32_t* __restrict__ lcol, int32_t* __restrict__ slots,
+                                                         gconv_tile_t* __restrict__ recs, int32_t* info,
+                                                         TileInfoSlots is) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= ntiles) return;   // wave-uniform
+  int ts, te;
+  if (CUTS) {
+    ts = tile_cut_wave(rowptr, col, n, t, ntiles, T, slack, lane);
+    te = tile_cut_wave(rowptr, col, n, t + 1, ntiles, T, slack, lane);
+    if (lane == 0) {
+      tile_ptr[t] = ts;
+      if (t == ntiles - 1) tile_ptr[ntiles] = n;
+    }
+  } else {
+    ts = tile_ptr[t];
+    te = tile_ptr[t + 1];
+  }
+  tile_halo_wave(rowptr, col, dis, ts, te, t, lcol, slots, recs + t, info, is, lane);
+}
+
+// Size-sorted tile list for small tile counts (a molecule batch has a few hundred tiles): ONE
+// workgroup ranks every tile by (rows incl. halo descending, tile index ascending) — the order a
+// stable sort gives — and writes the records of both directions in that order. The persistent
+// workgroups deal themselves tiles from this list boustrophedon, so no workgroup gets two big ones.
+constexpr int kSmallSortMax = 2048;
+static __global__ __launch_bounds__(1024) void tile_sort_small_kernel(const gconv_tile_t* __restrict__ recs_f,
+                                                                      const gconv_tile_t* __restrict__ recs_b,
+                                                                      int ntiles, gconv_tile_t* __restrict__ out_f,
+                                                                      gconv_tile_t* __restrict__ out_b) {
+  __shared__ int32_t size[kSmallSortMax];
+  for (int t = threadIdx.x; t < ntiles; t += 1024) size[t] = recs_f[t].n0;
+  __syncthreads();
+  for (int t = threadIdx.x; t < ntiles; t += 1024) {
+    const int sz = size[t];
+    int rank = 0;
+    for (int u = 0; u < ntiles; ++u) {
+      const int su = size[u];
+      rank += (su > sz) || (su == sz && u < t);
+    }
+    out_f[rank] = recs_f[t];
+    if (recs_b) out_b[rank] = recs_b[t];
+  }
+}
+
+// large tile counts: stable radix sort of (key, tile id) pairs, then this gather
+constexpr int kTileSizeMax = 1023, kTileSizeBits = 10;
+static __global__ void tile_sort_keys_kernel(const gconv_tile_t* __restrict__ recs_f, int ntiles,
+                                             uint32_t* __restrict__ key, uint32_t* __restrict__ id) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntiles) return;
+  key[t] = static_cast<uint32_t>(kTileSizeMax - min(recs_f[t].n0, kTileSizeMax));
+  id[t] = static_cast<uint32_t>(t);
+}
+static __global__ void tile_sort_gather_kernel(const gconv_tile_t* __restrict__ recs_f,
+                                               const gconv_tile_t* __restrict__ recs_b,
+                                               const uint32_t* __restrict__ id_sorted, int ntiles,
+                                               gconv_tile_t* __restrict__ out_f, gconv_tile_t* __restrict__ out_b) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= ntiles) return;
+  const uint32_t t = id_sorted[p];
+  out_f[p] = recs_f[t];
+  if (recs_b) out_b[p] = recs_b[t];
+}
+
+}  // namespace gconv

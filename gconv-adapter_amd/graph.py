@@ -132,10 +132,30 @@ class GraphPlan:
     def tile_ptr(self) -> torch.Tensor:
         return self.arena_view(self.struct.tile_ptr, self.n_tiles + 1, torch.int32)
 
+    #: columns of a tile record (``gconv_tile_t``)
+    TILE_FIELDS = ("first", "count", "n1", "n0", "slot", "e0", "ne_own", "ne_halo")
+
+    def tiles(self, transposed: bool = False) -> torch.Tensor:
+        """``[n_tiles, 8]`` tile records (``gconv_tile_t``: first, count, n1, n0, slot, e0, ne_own,
+        ne_halo) of S (or of S^T), largest tile (rows incl. halo) first."""
+        t = self.struct.tiles_bwd if transposed else self.struct.tiles_fwd
+        return self.arena_view(t.tiles, 8 * self.n_tiles, torch.int32).view(-1, 8)
+
+    def tile_lcol(self, transposed: bool = False) -> torch.Tensor:
+        """The CSR's ``col`` in tile-local row numbers (``gconv_tiling_t.lcol``)."""
+        t, csr = (self.struct.tiles_bwd, self.bwd) if transposed else (self.struct.tiles_fwd, self.fwd)
+        return self.arena_view(t.lcol, csr.nnz, torch.int32)
+
+    def tile_halo(self, transposed: bool = False) -> torch.Tensor:
+        """``[n_tiles, TILE_HALO_SLOT]`` halo slots in tile order (``gconv_tiling_t.halo``; only a
+        slot's used prefixes are defined)."""
+        t = self.struct.tiles_bwd if transposed else self.struct.tiles_fwd
+        return self.arena_view(t.halo, _lib.TILE_HALO_SLOT * self.n_tiles, torch.int32).view(-1, _lib.TILE_HALO_SLOT)
+
     @property
     def tile_order(self) -> torch.Tensor:
-        """``[n_tiles, 2]`` (first node, node count), largest tile first."""
-        return self.arena_view(self.struct.tile_order, 2 * self.n_tiles, torch.int32).view(-1, 2)
+        """The size-sorted tile records of S (see ``tiles``)."""
+        return self.tiles(False)
 
     @property
     def dis_ptr(self) -> Optional[int]:

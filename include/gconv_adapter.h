@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GCONV_ABI_VERSION 5
+#define GCONV_ABI_VERSION 6
 
 typedef int32_t gconv_status_t;
 typedef void*   gconv_stream_t; /* hipStream_t */
@@ -68,7 +68,8 @@ enum { GCONV_ACT_NONE = 0, GCONV_ACT_RELU = 1, GCONV_ACT_SILU = 2 };
 /* ------------------------------------------------------------------------- */
 int32_t     gconv_abi_version(void);
 /* sizeof of the ABI's POD structs as compiled into the library, for bindings to check their
- * mirrors: 0 gconv_csr_t, 1 gconv_graph_t, 2 gconv_adapter_params_t, 3 gconv_pending_finalize_t */
+ * mirrors: 0 gconv_csr_t, 1 gconv_graph_t, 2 gconv_adapter_params_t, 3 gconv_pending_finalize_t,
+ * 4 gconv_tile_t, 5 gconv_tiling_t */
 int32_t     gconv_abi_struct_bytes(int32_t which);
 const char* gconv_status_string(gconv_status_t status);
 /* Fp for a bottleneck rank r (0 if r is unsupported: r < 1 or r > 64). */
@@ -102,19 +103,50 @@ typedef struct gconv_csr {
                                  * that share a CSR must therefore be stream-ordered.      */
 } gconv_csr_t;
 
-/* Component tiles: molecule batches are block-diagonal, so the node range splits into
- * contiguous tiles that no edge crosses. A tile is handled end-to-end by ONE workgroup
- * (rank-width intermediates never leave LDS). Tiles start at the last edge-free boundary
- * at or below every multiple of the batch's nominal tile size (GCONV_TILE_NODES, doubled for
- * batches of GCONV_TILE_WIDE_FROM nodes or more); a tile spans at most 512 nodes. */
+/* Tiles of the fused (one-launch) adapter kernels. The node range is cut into contiguous tiles
+ * of about gconv_tile_nodes(N) nodes — N / 256, so that each of the 256 persistent workgroups
+ * gets one tile of about the same size — that ONE workgroup each runs end to end (rank-width
+ * intermediates never leave LDS). A cut sits on a boundary that no edge crosses when there is
+ * one within a quarter tile below its nominal position (collated molecule batches: between two
+ * molecules); otherwise it goes through a component and the tile carries a HALO: the nodes
+ * outside its range that its rows gather from (halo1) and the nodes those gather from (halo2),
+ * whose rank-width rows the tile recomputes for itself — tiles exchange nothing.
+ * (Round 2 cut at edge-free boundaries only; a batch's largest molecule then was one tile.) */
 #ifndef GCONV_TILE_NODES
-#define GCONV_TILE_NODES 32
+#define GCONV_TILE_NODES 32       /* smallest nominal tile                                     */
 #endif
-/* batches of at least this many nodes (256 workgroups x 64 nodes: enough 64-node tiles to give
- * every persistent workgroup one) are cut at multiples of 2 * GCONV_TILE_NODES instead */
-#ifndef GCONV_TILE_WIDE_FROM
-#define GCONV_TILE_WIDE_FROM 16384
+#ifndef GCONV_TILE_NODES_MAX
+#define GCONV_TILE_NODES_MAX 64   /* largest: beyond 256 x this many nodes a workgroup walks several tiles */
 #endif
+#define GCONV_TILE_HALO_NODES 64  /* halo1 + halo2 nodes a tile may carry                      */
+#define GCONV_TILE_HALO_EDGES 256 /* stored edges of its halo1 rows                            */
+#define GCONV_TILE_HALO_SLOT  456 /* 4-byte words per tile in `halo`: [0,64) halo node ids (halo1
+                                   * first), [64,129) local rowptr of the halo1 rows, [132,388)
+                                   * their local column ids, [388,452) dis of the halo nodes
+                                   * (float; only when normalised)                              */
+/* nominal nodes per tile of an N-node graph (env GCONV_TILE_NODES_OVERRIDE=k forces k) */
+int32_t gconv_tile_nodes(int32_t num_nodes);
+
+typedef struct gconv_tile {       /* 32 bytes                                                  */
+  int32_t first;                  /* first own node                                            */
+  int32_t count;                  /* own nodes                                                 */
+  int32_t n1;                     /* count + |halo1|: rows of the first propagation            */
+  int32_t n0;                     /* n1 + |halo2|: rows of the down projection                 */
+  int32_t slot;                   /* index of the tile's slot in `halo` (= its position in tile_ptr) */
+  int32_t e0;                     /* rowptr[first]                                             */
+  int32_t ne_own;                 /* stored edges of the own rows                              */
+  int32_t ne_halo;                /* stored edges of the halo1 rows                            */
+} gconv_tile_t;
+
+/* tile data of ONE direction (S or S^T; the cuts are shared) */
+typedef struct gconv_tiling {
+  const gconv_tile_t* tiles;      /* [n_tiles] largest (n0) first, ties in node order (stable):
+                                   * the persistent workgroups deal themselves tiles from this
+                                   * list boustrophedon, so no workgroup gets two big ones      */
+  const int32_t*      lcol;       /* [nnz] the CSR's `col` in tile-local row numbers: node - first
+                                   * for an own node, count + k for the tile's k-th halo node   */
+  const int32_t*      halo;       /* [n_tiles][GCONV_TILE_HALO_SLOT]                            */
+} gconv_tiling_t;
 
 /* Everything the kernels need to apply S and S^T for one edge list. All pointers
  * point into the caller's arena (see gconv_graph_build). */
@@ -122,15 +154,12 @@ typedef struct gconv_graph {
   gconv_csr_t    fwd;            /* rows = targets: the forward operator S              */
   gconv_csr_t    bwd;            /* rows = sources: S^T (a copy of `fwd` if symmetric)  */
   const float*   dis;            /* [num_nodes] (in-degree + 1)^-1/2; NULL if !normalize */
-  const int32_t* tile_ptr;       /* [n_tiles + 1] node offsets of the component tiles   */
-  const int32_t* tile_order;     /* [n_tiles][2] (first node, node count) of every tile, largest
-                                  * tile first (stable sort; 8-byte aligned): the
-                                  * persistent workgroups deal themselves tiles from this
-                                  * list boustrophedon, big ones first, so that no
-                                  * workgroup ends up with two big tiles               */
-  int32_t        n_tiles;        /* 0: not tileable (an edge-free boundary was not found) */
-  int32_t        tile_nodes_max; /* nodes in the largest tile                           */
-  int32_t        tile_edges_max; /* stored edges (of fwd, == bwd count) in the largest tile */
+  const int32_t* tile_ptr;       /* [n_tiles + 1] first node of every tile, ascending   */
+  gconv_tiling_t tiles_fwd;      /* tiles of `fwd`                                      */
+  gconv_tiling_t tiles_bwd;      /* tiles of `bwd` (a copy of tiles_fwd if symmetric)   */
+  int32_t        n_tiles;        /* 0: not tileable (a tile's halo outgrew its slot)    */
+  int32_t        tile_nodes_max; /* largest n0 (rows incl. halo) of a tile, either direction */
+  int32_t        tile_edges_max; /* most stored edges (own + halo1 rows) of a tile       */
   int32_t        symmetric;      /* edge multiset equals its transpose                  */
   int32_t        normalize;
   int32_t        max_degree;     /* of `fwd`                                            */
@@ -142,11 +171,11 @@ size_t gconv_graph_build_bytes(int64_t num_edges, int32_t num_nodes);
 
 /* Builds the whole graph plan from a COO edge list in ONE call:
  *   key build -> radix sort -> CSR (+ deg^-1/2, long-row segments) -> exact symmetry
- *   test on device -> S^T only if the edge list is not symmetric -> component tiles.
+ *   test on device -> S^T only if the edge list is not symmetric -> tiles (cuts, halos).
  * `arena` (device, >= gconv_graph_build_bytes, 256-B aligned) receives every output
  * array; it must stay alive as long as `graph_host_out` is used.
  * Synchronises `stream` once (twice for asymmetric edge lists) to return the counters;
- * the LAST launch (the size sort that fills `tile_order`) is queued on `stream` AFTER that
+ * the LAST launch (the size sort that fills `tiles_fwd.tiles`) is queued on `stream` AFTER that
  * synchronisation and may still be pending when the call returns: consumers on `stream` are
  * ordered behind it by the stream itself, a consumer on ANOTHER stream must first wait for an
  * event recorded on `stream` after this call.

@@ -86,17 +86,23 @@ def grad_atol(want: torch.Tensor, base: float = ATOL) -> float:
     return base * max(1.0, float(want.abs().max())) if want.numel() else base
 
 
-def assert_close(got: torch.Tensor, want: torch.Tensor, what: str, rtol=RTOL, atol=ATOL):
+def assert_close(got: torch.Tensor, want: torch.Tensor, what: str, rtol=RTOL, atol=ATOL, row_scaled=False):
+    """|got - want| <= atol + rtol |want| element-wise. `row_scaled`: the absolute term of a row is
+    atol * max(1, max |want| over that row) — for UNNORMALISED sums over hub neighbourhoods, where an
+    output row is a rank-r dot product of terms thousands of times larger than some of its entries
+    (cancellation): fp32 rounding of the terms, in any summation order (the reference's own fp32
+    path included), is then of the order 1e-7 x the row's scale, not of the entry."""
     want = want.double()
     err = (got - want).abs()
-    tol = atol + rtol * want.abs()
+    scale = want.abs().amax(dim=-1, keepdim=True).clamp(min=1.0) if row_scaled and want.dim() >= 2 else 1.0
+    tol = atol * scale + rtol * want.abs()
     assert got.shape == want.shape, f"{what}: shape {tuple(got.shape)} != {tuple(want.shape)}"
     bad = err > tol
     assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.numel()} elements out of tolerance, "
                            f"max abs err {err.max().item():.3e}, max |want| {want.abs().max().item():.3e}")
 
 
-def check_workload(ga, dev, batch, d, r, flags, seed=0, need_dx=True, rtol=RTOL, atol=ATOL):
+def check_workload(ga, dev, batch, d, r, flags, seed=0, need_dx=True, rtol=RTOL, atol=ATOL, row_scaled=False):
     """Module forward + backward on `dev` against the fp64 oracle (PyG op order, torch autograd) on
     the same seeded inputs: `out`, dX element-wise at (rtol, atol); parameter gradients with the
     scale-relative absolute term of `grad_atol`."""
@@ -106,6 +112,7 @@ def check_workload(ga, dev, batch, d, r, flags, seed=0, need_dx=True, rtol=RTOL,
                                                            flags, g.double(), need_dx=need_dx)
     mod = build_module(ga, d, r, flags, params, dev)
     got = run_module(mod, batch.x, batch.edge_index, g, dev, need_dx=need_dx)
-    assert_close(got["out"], want_out, "out", rtol, atol)
+    assert_close(got["out"], want_out, "out", rtol, atol, row_scaled)
     for k, want in want_grads.items():
-        assert_close(got[k], want, f"grad {k}", rtol, atol if k == "x" else grad_atol(want, atol))
+        assert_close(got[k], want, f"grad {k}", rtol, atol if k == "x" else grad_atol(want, atol),
+                     row_scaled and k == "x")

@@ -50,6 +50,9 @@ def test_arxiv_config_forward_and_backward(dev, normalize):
     batch, cfg = ga.synth.make_workload("arxiv")
     assert batch.num_nodes == 170_000 and (cfg["d"], cfg["r"]) == (128, 32)
     flags = oracle.AdapterFlags(learnable_scalar=True, normalize=normalize)
-    check_workload(ga, dev, batch, cfg["d"], cfg["r"], flags)
+    # normalize=False sums thousands of unweighted neighbours twice: |out| reaches 1.6e4 and single
+    # entries of such a row cancel to ~0 — element-wise 1e-5 relative, the absolute term scaled by the
+    # row's magnitude (helpers.assert_close); the normalised operator keeps the plain 1e-5
+    check_workload(ga, dev, batch, cfg["d"], cfg["r"], flags, row_scaled=not normalize)
     plan = ga.get_plan(batch.edge_index.to(dev), batch.num_nodes, normalize)
     assert plan.fwd.n_long > 0       # hub rows: long-row segments completed in-kernel

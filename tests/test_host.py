@@ -139,7 +139,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_library_host_only_entry_points():
     lib = ga._lib.load()
-    assert lib.gconv_abi_version() == 5
+    assert lib.gconv_abi_version() == 6
     assert [lib.gconv_padded_rank(r) for r in (0, 1, 4, 5, 8, 16, 17, 33, 64, 65)] == \
         [0, 4, 4, 8, 8, 16, 32, 64, 64, 0]
     assert b"workspace" in lib.gconv_status_string(-3)
@@ -152,7 +152,19 @@ def test_header_constants_match_binding():
     text = open(os.path.join(ROOT, "include", "gconv_adapter.h")).read()
     assert int(re.search(r"#define GCONV_LONG_ROW\s+(\d+)", text).group(1)) == ga._lib.LONG_ROW
     assert int(re.search(r"#define GCONV_SEG_EDGES\s+(\d+)", text).group(1)) == ga._lib.SEG_EDGES
-    assert int(re.search(r"#define GCONV_TILE_NODES\s+(\d+)", text).group(1)) == ga._lib.TILE_NODES
+    for name in ("TILE_NODES", "TILE_NODES_MAX", "TILE_HALO_NODES", "TILE_HALO_EDGES", "TILE_HALO_SLOT"):
+        assert int(re.search(r"#define GCONV_%s\s+(\d+)" % name, text).group(1)) == getattr(ga._lib, name), name
+
+
+def test_nominal_tile_size_rule():
+    """`gconv_tile_nodes` (the library) == `_lib.tile_nodes` (the binding's restatement): about
+    N / 256 nodes, one tile per persistent workgroup, k equal tiles each beyond 256 x 64 nodes."""
+    lib = ga._lib.load()
+    for n in (0, 1, 31, 431, 8191, 8193, 13104, 16384, 16385, 20000, 102952, 170000, 1 << 20):
+        assert lib.gconv_tile_nodes(n) == ga._lib.tile_nodes(n), n
+    assert ga._lib.tile_nodes(431) == 32 and ga._lib.tile_nodes(13104) == 52
+    assert ga._lib.tile_nodes(16385) == 33 and ga._lib.tile_nodes(102952) == 58
+    assert all(1 <= ga._lib.tile_slack(t) <= t for t in (1, 16, 32, 52, 64))
 
 
 # ---- synthetic workloads ---------------------------------------------------------------
@@ -227,6 +239,7 @@ def test_ctypes_structs_match_the_header():
         return [m.group(1) for m in re.finditer(r"\b(\w+)(?:\[\d+\])?\s*;", body)]
 
     for cname, ctype in (("gconv_csr_t", ga._lib.CsrStruct), ("gconv_graph_t", ga._lib.GraphStruct),
+                         ("gconv_tiling_t", ga._lib.TilingStruct),
                          ("gconv_adapter_params_t", ga._lib.AdapterParams),
                          ("gconv_pending_finalize_t", ga._lib.PendingFinalize)):
         assert fields(cname) == [f[0] for f in ctype._fields_], cname
@@ -236,6 +249,8 @@ def test_ctypes_structs_match_the_header():
     for i, ctype in enumerate((ga._lib.CsrStruct, ga._lib.GraphStruct, ga._lib.AdapterParams,
                                ga._lib.PendingFinalize)):
         assert lib.gconv_abi_struct_bytes(i) == ctypes.sizeof(ctype)
+    assert lib.gconv_abi_struct_bytes(4) == 32 == 4 * len(ga.GraphPlan.TILE_FIELDS)
+    assert lib.gconv_abi_struct_bytes(5) == ctypes.sizeof(ga._lib.TilingStruct)
 
 
 def test_batch_norm_module_is_a_drop_in_on_any_input():
