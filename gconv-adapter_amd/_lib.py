@@ -19,8 +19,8 @@ SPMM_IN_PRESCALED = 1
 SPMM_OUT_PRESCALE = 2
 LONG_ROW = 64
 SEG_EDGES = 128
-TILE_NODES = 32            # GCONV_TILE_NODES: smallest nominal tile
-TILE_NODES_MAX = 64        # GCONV_TILE_NODES_MAX
+TILE_NODES = 16            # GCONV_TILE_NODES: smallest nominal tile
+TILE_NODES_MAX = 128       # GCONV_TILE_NODES_MAX
 TILE_HALO_NODES = 64       # GCONV_TILE_HALO_NODES
 TILE_HALO_EDGES = 256      # GCONV_TILE_HALO_EDGES
 TILE_HALO_SLOT = 456       # GCONV_TILE_HALO_SLOT (4-byte words per tile)
@@ -39,9 +39,11 @@ def tile_nodes(num_nodes: int) -> int:
     return max(TILE_NODES, -(-num_nodes // (NUM_CU * k)))
 
 
-def tile_slack(tile: int) -> int:
-    """How far below its nominal position a cut may sit (``tile_slack`` in ``csrc/common.h``)."""
-    return max(tile // 4, 1)
+def tile_slack(tile: int, num_nodes: int) -> int:
+    """How far below its nominal position a cut may sit (``tile_slack`` in ``csrc/graph_prep.hip``):
+    a quarter tile with one tile per workgroup, a whole tile (at most 64 nodes) with several."""
+    one_per_workgroup = -(-max(num_nodes, 1) // tile) <= NUM_CU
+    return min(max(tile // 4 if one_per_workgroup else tile, 1), 64)
 
 _i32p = C.POINTER(C.c_int32)
 

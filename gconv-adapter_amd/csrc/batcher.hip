@@ -201,7 +201,9 @@ extern "C" gconv_status_t gconv_graph_from_store(const gconv_graph_t* dataset, c
   tile_build_kernel<false><<<(L.ntiles + 3) / 4, 256, 0, stream>>>(rowptr, col, dis, num_nodes, L.ntiles, L.T, 0, tile_ptr,
                                                                    lcol, halo, recs, info, TileInfoSlots{0, 1, 2});
   GCONV_LAUNCH_CHECK();
-  if (L.ntiles <= kSmallSortMax) {
+  if (L.ntiles <= kNumCU) {   // one tile per persistent workgroup: node order, no sort (see gconv_graph_build)
+    tiles = recs;
+  } else if (L.ntiles <= kSmallSortMax) {
     tile_sort_small_kernel<<<1, 1024, 0, stream>>>(recs, nullptr, L.ntiles, tiles, nullptr);
     GCONV_LAUNCH_CHECK();
   } else {

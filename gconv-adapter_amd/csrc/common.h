@@ -24,16 +24,24 @@ constexpr int kNumCU = 256;
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // Nominal nodes per tile of an n-node graph (include/gconv_adapter.h, "Tiles"): about n / 256, so
-// that every one of the 256 persistent workgroups gets ONE tile; never below GCONV_TILE_NODES (the
-// per-tile chain of latencies does not shrink with the tile) and, beyond 256 x
-// GCONV_TILE_NODES_MAX nodes, n / (256 k) for the smallest k that keeps it under that maximum
-// (k tiles of equal size per workgroup). Round 2 used 32 (64 from 16384 nodes on) and cut only at
+// that every one of the 256 persistent workgroups gets ONE tile; never below GCONV_TILE_NODES (one
+// MFMA block of rows) and, beyond 256 x GCONV_TILE_NODES_MAX nodes, n / (256 k) for the smallest k
+// that keeps it under that maximum (k tiles of equal size per workgroup). With one tile per
+// workgroup the largest tile IS the kernel's length, so cuts stay within T / 4 of their nominal
+// position (and go through a molecule if there is no boundary that close); with several, the
+// workgroups even out by dealing themselves tiles largest first, and a cut takes the nearest
+// edge-free boundary up to a whole tile (at most 64 nodes) below — halos are then rare. Round 2 used 32 (64 from 16384 nodes on) and cut only at
 // edge-free boundaries; libraries built at 32 / 48 / 64 / 96 / 128 were compared then: with the
 // largest molecule as one tile the 512-molecule shard did not care (46.7 .. 47.6 us), larger
 // batches gained from fewer chains per workgroup (4096 molecules: 181 -> 162 us at 64).
 // A cut may lie up to tile_slack(T) nodes below its nominal position (on an edge-free boundary).
-int tile_nominal(int n);                       // graph_prep.hip (reads GCONV_TILE_NODES_OVERRIDE)
-inline int tile_slack(int T) { return T / 4 > 0 ? T / 4 : 1; }
+// Measured this round (tools/lab/tile_sweep.sh, 5 adapters' worth of one forward + backward):
+// 512 molecules (one tile per workgroup) 47.0 us with round 2's tiles -> 39.9 at T = N / 256, slack
+// T / 4 (T / 2 .. T / 6: 39.2 .. 40.1); 4096 molecules 156.3 -> 154.7 at T = 101 (4 tiles per workgroup,
+// slack T) against 170.7 at T = 58 / slack T / 4 (7 per workgroup, a third of them with a halo);
+// 32 molecules 24.6 -> 23.6 at T = 16.
+int tile_nominal(int n);                       // graph_prep.hip (reads GCONV_TILE_NODES_OVERRIDE / _MAX)
+int tile_slack(int T, int n);                  // how far below its nominal position a cut may sit
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

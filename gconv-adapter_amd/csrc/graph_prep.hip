@@ -47,6 +47,16 @@ enum {
   INFO_ASYM = 5, INFO_NOTILE = 6, INFO_TILEMAX = 7, INFO_TILEEDGES = 8, INFO_WORDS = 9
 };
 
+int tile_slack(int T, int n) {
+  static const int div = [] {
+    const char* v = std::getenv("GCONV_TILE_SLACK_DIV");
+    return v ? std::atoi(v) : 0;
+  }();
+  const bool one_per_workgroup = ceil_div(n > 0 ? n : 1, T) <= kNumCU;
+  const int s = div > 0 ? T / div : (one_per_workgroup ? T / 4 : T);
+  return s < 1 ? 1 : (s > 64 ? 64 : s);
+}
+
 template <typename K>
 struct KeyOps {
   int shift;
@@ -514,13 +524,15 @@ __global__ __launch_bounds__(T) void small_graph_build_kernel(SmallBuildArgs a) 
                      sinfo, is, lane);
     __syncthreads();
   }
-  // size-sorted tile list: rank by (rows incl. halo descending, index ascending) == tile_sort_small_kernel
+  // size-sorted tile list: rank by (rows incl. halo descending, index ascending) == tile_sort_small_kernel;
+  // node order when every persistent workgroup gets ONE tile anyway (the kernels then know a tile's
+  // halo slot from the workgroup index, before its record has arrived)
   for (int t = tid; t < a.ntiles; t += T) tsize[t] = a.recs_f[t].n0;
   __syncthreads();
   for (int t = tid; t < a.ntiles; t += T) {
     const int s0 = tsize[t];
-    int rank = 0;
-    for (int u = 0; u < a.ntiles; ++u) {
+    int rank = a.ntiles <= kNumCU ? t : 0;
+    for (int u = 0; u < a.ntiles && a.ntiles > kNumCU; ++u) {
       const int su = tsize[u];
       rank += (su > s0) || (su == s0 && u < t);
     }
@@ -583,7 +595,7 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
   // info words: [0..8] flags / maxima (enum above); forward counters at 16.., transposed at 24..
   const int FWD = 16, BWD = 24;
   const TileInfoSlots is{INFO_NOTILE, INFO_TILEMAX, INFO_TILEEDGES};
-  const int slack = tile_slack(L.T);
+  const int slack = tile_slack(L.T, n);
 
   auto fill = [&](gconv_csr_t& c, const CsrOut& o, const int32_t* cnt) {
     c.num_nodes = n; c.nnz = cnt[0];
@@ -696,7 +708,12 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
   g->dis = dis;
   fill_tiles(h, g->symmetric != 0);
   gconv_tile_t* recs_b = g->symmetric ? nullptr : tb.recs;
-  if (g->n_tiles > 0 && L.ntiles <= kSmallSortMax) {
+  if (g->n_tiles > 0 && L.ntiles <= kNumCU) {
+    // one tile per persistent workgroup: node order (no sort launch; the kernels know a tile's halo
+    // slot from the workgroup index, before its record has arrived)
+    g->tiles_fwd.tiles = tf.recs;
+    g->tiles_bwd.tiles = g->symmetric ? tf.recs : tb.recs;
+  } else if (g->n_tiles > 0 && L.ntiles <= kSmallSortMax) {
     tile_sort_small_kernel<<<1, 1024, 0, stream>>>(tf.recs, recs_b, L.ntiles, tf.tiles, tb.tiles);
     GCONV_LAUNCH_CHECK();
   } else if (g->n_tiles > 0) {  // largest tile first; stable, so the order is a function of the graph alone

@@ -201,6 +201,17 @@ struct AdapterFn : public torch::autograd::Function<AdapterFn> {
 // ---------------------------------------------------------------------------------------
 struct ParamPack {
   at::Tensor w_down, b_down, w_up, b_up, scalar;
+  // The parameters' grad accumulators, kept alive from the forward on: `backward(inputs=params)`
+  // identifies a named leaf by its accumulator node (a leaf without one counts as unreachable and
+  // cannot be told apart later), and the backward node below decides per parameter by looking that
+  // node up in the task's exec_info.
+  std::shared_ptr<torch::autograd::Node> acc[5];
+  void ensure_accumulators() {
+    const at::Tensor* ps[5] = {&w_down, &b_down, &w_up, &b_up, &scalar};
+    for (int i = 0; i < 5; ++i)
+      if (!acc[i] && ps[i]->defined() && ps[i]->requires_grad() && !ps[i]->grad_fn())
+        acc[i] = torch::autograd::impl::grad_accumulator(*ps[i]);
+  }
 };
 std::mutex g_pack_mu;
 std::unordered_map<int64_t, std::shared_ptr<ParamPack>> g_packs;
@@ -471,6 +482,7 @@ at::Tensor adapter_apply_direct(at::Tensor x, c10::optional<at::Tensor> anchor, 
                               graph_addr, fp, ws_fwd, ws_bwd, act, skip, stream);
     }
   }
+  pack_get(pack_id)->ensure_accumulators();
   return AdapterFnDirect::apply(x, anchor, pack_id, arena, graph_addr, fp, ws_fwd, ws_bwd, act, skip, stream);
 }
 

@@ -108,15 +108,17 @@ typedef struct gconv_csr {
  * gets one tile of about the same size — that ONE workgroup each runs end to end (rank-width
  * intermediates never leave LDS). A cut sits on a boundary that no edge crosses when there is
  * one within a quarter tile below its nominal position (collated molecule batches: between two
- * molecules); otherwise it goes through a component and the tile carries a HALO: the nodes
+ * molecules; with several tiles per workgroup — more than 256 x GCONV_TILE_NODES_MAX nodes — the
+ * workgroups balance themselves by dealing tiles largest first, and a cut may sit up to a whole
+ * tile, at most 64 nodes, below); otherwise it goes through a component and the tile carries a HALO: the nodes
  * outside its range that its rows gather from (halo1) and the nodes those gather from (halo2),
  * whose rank-width rows the tile recomputes for itself — tiles exchange nothing.
  * (Round 2 cut at edge-free boundaries only; a batch's largest molecule then was one tile.) */
 #ifndef GCONV_TILE_NODES
-#define GCONV_TILE_NODES 32       /* smallest nominal tile                                     */
+#define GCONV_TILE_NODES 16       /* smallest nominal tile (one 16-row MFMA block)             */
 #endif
 #ifndef GCONV_TILE_NODES_MAX
-#define GCONV_TILE_NODES_MAX 64   /* largest: beyond 256 x this many nodes a workgroup walks several tiles */
+#define GCONV_TILE_NODES_MAX 128  /* largest: beyond 256 x this many nodes a workgroup walks several tiles */
 #endif
 #define GCONV_TILE_HALO_NODES 64  /* halo1 + halo2 nodes a tile may carry                      */
 #define GCONV_TILE_HALO_EDGES 256 /* stored edges of its halo1 rows                            */
@@ -142,7 +144,8 @@ typedef struct gconv_tile {       /* 32 bytes                                   
 typedef struct gconv_tiling {
   const gconv_tile_t* tiles;      /* [n_tiles] largest (n0) first, ties in node order (stable):
                                    * the persistent workgroups deal themselves tiles from this
-                                   * list boustrophedon, so no workgroup gets two big ones      */
+                                   * list boustrophedon, so no workgroup gets two big ones. With
+                                   * at most 256 tiles (one per workgroup): node order, slot == index */
   const int32_t*      lcol;       /* [nnz] the CSR's `col` in tile-local row numbers: node - first
                                    * for an own node, count + k for the tile's k-th halo node   */
   const int32_t*      halo;       /* [n_tiles][GCONV_TILE_HALO_SLOT]                            */

@@ -162,9 +162,10 @@ def test_nominal_tile_size_rule():
     lib = ga._lib.load()
     for n in (0, 1, 31, 431, 8191, 8193, 13104, 16384, 16385, 20000, 102952, 170000, 1 << 20):
         assert lib.gconv_tile_nodes(n) == ga._lib.tile_nodes(n), n
-    assert ga._lib.tile_nodes(431) == 32 and ga._lib.tile_nodes(13104) == 52
-    assert ga._lib.tile_nodes(16385) == 33 and ga._lib.tile_nodes(102952) == 58
-    assert all(1 <= ga._lib.tile_slack(t) <= t for t in (1, 16, 32, 52, 64))
+    assert ga._lib.tile_nodes(431) == 16 and ga._lib.tile_nodes(13104) == 52
+    assert ga._lib.tile_nodes(16385) == 65 and ga._lib.tile_nodes(102952) == 101
+    assert ga._lib.tile_slack(52, 13104) == 13 and ga._lib.tile_slack(101, 102952) == 64
+    assert ga._lib.tile_slack(16, 431) == 4
 
 
 # ---- synthetic workloads ---------------------------------------------------------------

@@ -111,7 +111,10 @@ def check_plan(plan, rowptr, col, n, T, slack, transposed=False, dis=None, order
     if any_overflow:
         return want
     key = order_by if order_by is not None else want
-    order = sorted(range(len(want)), key=lambda t: (-key[t]["n0"], t))      # largest first, stable
+    if len(want) <= 256:       # one tile per persistent workgroup: node order, not sorted
+        order = list(range(len(want)))
+    else:
+        order = sorted(range(len(want)), key=lambda t: (-key[t]["n0"], t))  # largest first, stable
     fields = ("first", "count", "n1", "n0", "slot", "e0", "ne_own", "ne_halo")
     np.testing.assert_array_equal(recs, np.asarray([[want[t][f] for f in fields] for t in order]))
     return want

@@ -10,7 +10,7 @@ import numpy as np, torch
 import gconv_adapter_amd as ga
 from gconv_adapter_amd import _lib
 alt = os.environ.get("GCONV_STAMPS_LIB") or _lib.LIB_PATH.replace("libgconv_adapter.so", "libgconv_adapter_stamps.so")
-if not os.path.exists(alt):   # (build it here, where hipcc cross-compiles: python tools/tilestamps.py --build-only)
+if "--build-only" in sys.argv or not os.path.exists(alt):   # (build where hipcc cross-compiles: --build-only; incremental)
     import __graft_entry__ as ge
     ge.build_library(alt, defines=("-DGCONV_TILE_STAMPS",), tag="_stamps")
 if "--build-only" in sys.argv:
