@@ -17,8 +17,12 @@ C ABI -> HIP kernels). Inputs are resident in HBM before the timed region.
 
 Default workload: the per-GPU unit of BASELINE.json configs[2] — a 512-molecule
 HIV-like shard (d=300, r=8, 5 pre-adapters); N ranks process N shards (weak
-scaling; N=8 is the 4096-molecule batch of configs[2]). `--workload esol` is
-configs[1]; both are reported at N=1 (the other one under "extra").
+scaling; N=8 is the 4096-molecule batch of configs[2] split 8 ways). The same
+batch on ONE GPU (fresh plan per step, through the module) is reported at N=1 as
+extra.hiv4096_graphs_per_s: strong-scaling speed-up at 8 GPUs = value(N=8) divided
+by it. `--scaling strong` runs that mode for any N directly (every rank takes
+4096 / N graphs of the SAME batches). `--workload esol` is configs[1]; both
+molecule workloads are reported at N=1 (the other one under "extra").
 
 Timing: an untimed pre-roll (`settle`, reported as config.settle_steps) runs the step until
 its rate is steady — a fresh process on the GPU box needs 0.1–0.7 s of activity before the
@@ -50,18 +54,11 @@ import torch.distributed as dist  # noqa: E402
 # addmm path blocks the host at every call until the GPU has caught up (the step ran at GPU time +
 # host time, 3.3 ms); with rocBLAS the host runs ahead again (2.4 ms). Read at the first addmm.
 os.environ.setdefault("DISABLE_ADDMM_HIP_LT", "1")
-# ... and PyTorch's TunableOp picks the library GEMM kernel per shape: at [13104, 300] x [300, 600] the
-# default rocBLAS choice runs at 60-69 TFLOP/s fp32, the tuned one at 82-92 (tools/lab/mlp_gemm.py).
-# Only the fine-tune step of the extras contains torch GEMMs; the tuning result goes to /tmp.
-os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
-os.environ.setdefault("PYTORCH_TUNABLEOP_VERBOSE", "0")
-os.environ.setdefault("PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS", "100")
-os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", os.path.join(os.environ.get("TMPDIR", "/tmp"),
-                                                                 "gconv_bench_tunableop_%d.csv"))
 import gconv_adapter_amd as ga  # noqa: E402
 
 RESIDENT = 0
 PARTITION = "graphs"
+STRONG_WORKLOAD = "hiv4096"   # --scaling strong: the whole batch of BASELINE configs[2], split over the ranks
 _FULL_AFFINITY = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
 _PINNED = []
 
@@ -106,13 +103,18 @@ class BatchStream:
     started before the current step's adapters run, so it overlaps them — the role the
     DataLoader's prefetching workers play for collation in the reference."""
 
-    def __init__(self, name: str, rank: int, device, k: int, fresh: bool, prefetch: bool = True):
+    def __init__(self, name: str, rank: int, device, k: int, fresh: bool, prefetch: bool = True,
+                 shard=None):
         self.fresh = fresh
         self.prefetch = prefetch   # False: the plan is built in-stream by the step's first adapter
         self.items = []
         cfg = None
         for i in range(k if fresh else 1):
-            batch, cfg = ga.synth.make_workload(name, seed=rank * 1000 + i)
+            if shard is None:
+                batch, cfg = ga.synth.make_workload(name, seed=rank * 1000 + i)
+            else:                  # strong scaling: every rank cuts ITS graphs out of the same batch
+                whole, cfg = ga.synth.make_workload(name, seed=i)
+                batch = ga.synth.shard_graphs(whole, *shard)
             x = batch.x.to(device)
             ei = batch.edge_index.to(device)
             gout = torch.randn(x.shape, generator=torch.Generator().manual_seed(2 + i)).to(device)
@@ -164,6 +166,8 @@ class StoreStream:
 def adapter_step(mods, params, stream: BatchStream, normalize: bool, bucket=None):
     """fwd + bwd of the adapter chain on the next batch (+ gradient all-reduce)."""
     batch, x, ei, gout = stream.next(normalize)
+    if bucket is not None:
+        bucket.wait()         # the previous step's all-reduce, before its buffer is written again
     for p in params:          # optimizer.zero_grad(set_to_none=True)
         p.grad = None
     h = x
@@ -171,7 +175,9 @@ def adapter_step(mods, params, stream: BatchStream, normalize: bool, bucket=None
         h = m(h, ei)
     h.backward(gout)
     if bucket is not None:
-        bucket.all_reduce_grads()   # one cat + ONE flat all-reduce + one multi-tensor copy
+        # the backward pass has written every gradient into the flat bucket (gradient sinks):
+        # ONE collective, launched behind the backward, waited for at the top of the next step
+        bucket.all_reduce_grads(async_op=True)
     if stream.fresh or isinstance(stream, StoreStream):
         ga.PLAN_CACHE.discard(ei, x.shape[-2], normalize)   # a training batch is seen once
     return batch.num_graphs
@@ -296,9 +302,8 @@ def measure_arxiv(device, iters: int = 50, banded_control: bool = False) -> dict
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "frac_of_measured_copy_peak": round(achieved / HBM_MEASURED_GBS, 4),
             "algorithmic_bytes": b, "avg_launch_us": round(ms * 1e3, 2), "traffic": None}
-    pmc = os.path.join(ROOT, "profiles", "r02_spmm_arxiv_pmc.json")
-    if not os.path.exists(pmc):
-        pmc = os.path.join(ROOT, "profiles", "r01_spmm_arxiv_pmc.json")
+    pmc = next((q for q in (os.path.join(ROOT, "profiles", f"r0{k}_spmm_arxiv_pmc.json") for k in (3, 2, 1))
+                if os.path.exists(q)), "")
     if os.path.exists(pmc):   # PMC passes cannot run inside the timed bench: committed rocprofv3 result
         with open(pmc) as fh:
             dv = json.load(fh)["derived"]
@@ -306,7 +311,8 @@ def measure_arxiv(device, iters: int = 50, banded_control: bool = False) -> dict
         # the bytes that actually crossed L2 <-> memory per launch, at the live launch time
         roof["traffic_GBs"] = round(dv["traffic_bytes_per_launch"] / (ms * 1e-3) / 1e9, 1)
         roof["traffic_frac_of_measured_copy_peak"] = round(roof["traffic_GBs"] / HBM_MEASURED_GBS, 3)
-        roof["traffic_source"] = (f"profiles/{os.path.basename(pmc)}: 2 x FETCH_SIZE + WRITE_SIZE per launch "
+        roof["traffic_source"] = (f"profiles/{os.path.basename(pmc)} (collected at commit "
+                                  f"{dv.get('commit', 'n/a')}): 2 x FETCH_SIZE + WRITE_SIZE per launch "
                                   "(separate rocprofv3 --pmc passes, gfx950 x2 fetch correction); L2 hit rate "
                                   f"{dv['l2_hit_rate']:.2f}")
 
@@ -578,9 +584,26 @@ def measure_finetune_step(device, normalize: bool, name: str = "hiv", steps: int
         opt.step()
 
     ms = event_time_ms(step, steps, warmup=20)
+    res = {f"{name}_finetune_step_ms": round(ms, 4),
+           f"{name}_finetune_step_graphs_per_s": round(batch.num_graphs / (ms * 1e-3), 1)}
+    # The frozen layers' MLP GEMMs are library calls (rocBLAS): PyTorch's TunableOp picks their kernel
+    # per shape (60-69 -> 82-92 TFLOP/s fp32 at [13104, 300] x [300, 600]). Scoped to THIS measurement
+    # (round 2 switched it on for the whole process), tuned during a longer warm-up, reported beside
+    # the default — the gain depends on the box (round 2: 1.90 ms on one, no gain on the driver's).
+    try:
+        import torch.cuda.tunable as tunable
+        tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "gconv_bench_tunableop.csv"))
+        tunable.set_max_tuning_duration(100)
+        tunable.enable(True)
+        tunable.tuning_enable(True)
+        tms = event_time_ms(step, steps, warmup=40)
+        tunable.tuning_enable(False)
+        tunable.enable(False)
+        res[f"{name}_finetune_step_tunableop_ms"] = round(tms, 4)
+    except Exception as exc:   # pragma: no cover - API differences between torch builds
+        res[f"{name}_finetune_step_tunableop_ms"] = f"unavailable: {type(exc).__name__}"
     ga.PLAN_CACHE.clear()
-    return {f"{name}_finetune_step_ms": round(ms, 4),
-            f"{name}_finetune_step_graphs_per_s": round(batch.num_graphs / (ms * 1e-3), 1)}
+    return res
 
 
 def measure_banded(device, r: int, flags: int, lib) -> dict:
@@ -618,8 +641,10 @@ def host_cores() -> int:
 
 def cpu_baseline(batch, cfg: dict, normalize: bool, budget_s: float = 20.0) -> dict:
     """The oracle (PyG op order: linear -> gather -> scale -> index_add -> bias, gcn_norm
-    recomputed per conv, autograd backward) on the host cores. Checker code timed as the
-    baseline only — it is never on the product path."""
+    recomputed per conv, autograd backward) on the host cores — SURVEY.md 8(d): 3 warm-up steps,
+    median of 10 (fewer if 10 do not fit `budget_s`). Also timed: the REASSOCIATED order (both
+    propagations at rank width), so that the GPU / CPU ratio can be read without the reference's
+    d-wide propagate in it. Checker code timed as the baseline only — it is never on the product path."""
     from oracle import pyg_restated as oracle
     unpin_host_threads()
     threads = host_cores()
@@ -638,47 +663,52 @@ def cpu_baseline(batch, cfg: dict, normalize: bool, budget_s: float = 20.0) -> d
     x, ei = batch.x, batch.edge_index
     gout = torch.randn(x.shape, generator=g)
 
-    def step():
-        h = x
-        for p in params:
-            h = oracle.adapter_forward(h, ei, p, flags)
-        for p in params:
-            for v in p.values():
-                v.grad = None
-        h.backward(gout)
+    def make_step(forward):
+        def step():
+            h = x
+            for p in params:
+                h = forward(h, ei, p, flags)
+            for p in params:
+                for v in p.values():
+                    v.grad = None
+            h.backward(gout)
+        return step
 
-    step()
-    t0 = time.perf_counter()
-    step()
-    one = time.perf_counter() - t0
-    iters = int(max(3, min(200, budget_s / max(one, 1e-6))))
-    # three equal chunks, the FASTEST one is reported (the host is shared: a chunk can run 2x
-    # slower than its neighbour; the baseline gets the benefit of the doubt)
-    chunk = max(1, iters // 3)
-    best = None
-    for _ in range(3):
-        t0 = time.perf_counter()
-        for _ in range(chunk):
+    def median_time(step, budget):
+        for _ in range(3):
+            t0 = time.perf_counter()
             step()
-        t = (time.perf_counter() - t0) / chunk
-        best = t if best is None else min(best, t)
-    dt = best
+            one = time.perf_counter() - t0
+        k = int(max(3, min(10, budget / max(one, 1e-6))))
+        ts = []
+        for _ in range(k):
+            t0 = time.perf_counter()
+            step()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return ts[len(ts) // 2], k
+
+    dt, k = median_time(make_step(oracle.adapter_forward), budget_s * 0.6)
+    rdt, rk = median_time(make_step(oracle.adapter_forward_reassociated), budget_s * 0.4)
     pin_host_threads()
     return {"value": round(batch.num_graphs / dt, 1), "unit": "graphs/s", "cores": threads,
             "kind": "port", "ms_per_step": round(dt * 1e3, 3),
-            "sample": f"best of 3 x {chunk} steps of the same batch ({batch.num_graphs} graphs, "
+            "sample": f"3 warm-up steps, median of {k} steps of the same batch ({batch.num_graphs} graphs, "
                       f"{cfg['adapters']} adapters fwd+bwd, PyG op order, fp32, torch CPU, threads on "
-                      f"{threads} physical cores of one NUMA node)"}
+                      f"{threads} physical cores of one NUMA node)",
+            "reassociated_value": round(batch.num_graphs / rdt, 1),
+            "reassociated_ms_per_step": round(rdt * 1e3, 3),
+            "reassociated_sample": f"same, both propagations at rank width (median of {rk})"}
 
 
 # --------------------------------------------------------------------------- main
 def run_workload(name: str, normalize: bool, steps: int, warmup: int, rank: int, world: int,
-                 device, with_cpu: bool) -> dict:
+                 device, with_cpu: bool, strong: bool = False) -> dict:
     fresh = ga.synth.WORKLOADS[name]["kind"] == "molecule"   # transductive graphs are static
-    if RESIDENT and fresh:
+    if RESIDENT and fresh and not strong:
         stream = StoreStream(name, rank, device, RESIDENT)
     else:
-        stream = BatchStream(name, rank, device, k=4, fresh=fresh)
+        stream = BatchStream(name, rank, device, k=4, fresh=fresh, shard=(rank, world) if strong else None)
     cfg = stream.cfg
     by_rows = PARTITION == "rows" and not fresh and world > 1
     mods = build_adapters(cfg, normalize, device, ga.RowSlabGConvAdapter if by_rows else None)
@@ -709,8 +739,9 @@ def run_workload(name: str, normalize: bool, steps: int, warmup: int, rank: int,
         batch0 = stream.items[0][0]
         edges = round(sum(b.edge_index.shape[1] for b, *_ in stream.items) / len(stream.items))
     graphs_per_step = stream.avg("num_graphs")
-    res = {"value": graphs_per_step * (1 if by_rows else world) * steps / dt, "ms_per_step": dt / steps * 1e3,
-           "cfg": cfg, "by_rows": by_rows,
+    total_graphs = cfg["graphs"] if strong else graphs_per_step * (1 if by_rows else world)
+    res = {"value": total_graphs * steps / dt, "ms_per_step": dt / steps * 1e3,
+           "cfg": cfg, "by_rows": by_rows, "strong": strong,
            "nodes_per_rank": round(stream.avg("num_nodes")),
            "edges_per_rank": edges,
            "graphs_per_rank": round(graphs_per_step), "settle_steps": settled}
@@ -733,6 +764,10 @@ def main() -> None:
     ap.add_argument("--resident", type=int, default=0, metavar="G",
                     help="keep a G-molecule dataset in HBM and draw a fresh random batch every step "
                          "(device-side collation + plan assembly) instead of rotating 4 fixed batches")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every rank runs its own 512-molecule shard, N = 8 is the 4096-molecule "
+                         "batch of configs[2] split 8 ways; strong: the SAME 4096-molecule batches for any N, "
+                         "every rank takes 4096 / N graphs (N = 1: the whole batch on one GPU)")
     ap.add_argument("--partition", default="graphs", choices=["graphs", "rows"],
                     help="N > 1 on a single-graph workload (cora / pubmed / arxiv): 'graphs' runs one replica "
                          "of the graph per GPU, 'rows' splits the ONE graph by rows over the GPUs "
@@ -764,8 +799,11 @@ def main() -> None:
     ga._lib.load()
 
     solo = world == 1 and rank == 0
+    strong = args.scaling == "strong" and ga.synth.WORKLOADS[args.workload]["kind"] == "molecule"
+    if strong:
+        args.workload = STRONG_WORKLOAD
     main_res = run_workload(args.workload, normalize, args.steps, args.warmup, rank, world, device,
-                            with_cpu=solo and not args.no_cpu_baseline)
+                            with_cpu=solo and not args.no_cpu_baseline, strong=strong)
     line = {
         "metric": "adapter fwd+bwd graphs/sec (molecule batches)",
         "value": round(main_res["value"], 1),
@@ -775,7 +813,7 @@ def main() -> None:
         "warmup": args.warmup,
         "ms_per_step": round(main_res["ms_per_step"], 4),
         "higher_is_better": True,
-        "scaling": "strong" if main_res["by_rows"] else "weak",
+        "scaling": "strong" if (main_res["by_rows"] or strong) else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
@@ -785,11 +823,16 @@ def main() -> None:
                                f"{main_res['cfg']['adapters']} adapters fwd+bwd, "
                                + ("fresh graph plan per step (built on a side stream while the previous step runs)"
                                   if main_res["cfg"]["kind"] == "molecule" else "static graph (plan built once)")
-                               + (" + flat RCCL grad all-reduce" if world > 1 else ""),
+                               + (" + ONE flat RCCL grad all-reduce per step (gradients deposited in the bucket "
+                                  "by the backward kernels, collective asynchronous)" if world > 1 else ""),
                    "normalize": normalize,
                    "sharding": (f"ONE graph by rows over {world} rank(s): 4 all-gathers of [N, Fp] per adapter "
                                 f"and step + flat grad all-reduce" if main_res["by_rows"]
-                                else f"by graph, {world} rank(s)"),
+                                else (f"by graph: the same {main_res['cfg']['graphs']}-molecule batches cut "
+                                      f"into {world} shard(s) (strong scaling)" if strong
+                                      else f"by graph, {world} rank(s), one {main_res['graphs_per_rank']}-molecule "
+                                           f"shard each (weak scaling; strong-scaling reference at N = 1: "
+                                           f"extra.{STRONG_WORKLOAD}_graphs_per_s)")),
                    "settle_steps": main_res["settle_steps"],
                    "host_threads": (f"pinned to cores {_PINNED[0]}-{_PINNED[-1]} (GPU's NUMA node)"
                                     if _PINNED else "not pinned"),
@@ -800,7 +843,25 @@ def main() -> None:
         if "cpu" in main_res:
             line["cpu_baseline"] = main_res["cpu"]
             extra["speedup_vs_cpu"] = round(main_res["value"] / main_res["cpu"]["value"], 1)
+            #  the same ratio against the CPU running the REASSOCIATED order: without the
+            # reference's d-wide second propagation in the denominator
+            extra["speedup_vs_cpu_reassociated"] = round(main_res["value"] / main_res["cpu"]["reassociated_value"], 1)
         if not args.no_extra:
+            # the YAML default of the reference (configs/finetune/gconv_adapter.yaml:8, normalize: false)
+            # / the north-star subject (normalize: true): whichever the headline did not run
+            o = run_workload(args.workload, not normalize, max(20, args.steps // 2), args.warmup, rank, world,
+                             device, with_cpu=False, strong=strong)
+            key = "normalize_true" if not normalize else "normalize_false_yaml_default"
+            extra[f"{key}_graphs_per_s"] = round(o["value"], 1)
+            extra[f"{key}_ms_per_step"] = round(o["ms_per_step"], 4)
+            if not strong:
+                # strong-scaling reference: the whole 4096-molecule batch of configs[2] on this ONE GPU
+                # (fresh plan per step, through the module). value(N = 8, weak) / this = speed-up at 8 GPUs
+                o = run_workload(STRONG_WORKLOAD, normalize, max(20, args.steps // 4), args.warmup, rank, world,
+                                 device, with_cpu=False, strong=True)
+                extra[f"{STRONG_WORKLOAD}_graphs_per_s"] = round(o["value"], 1)
+                extra[f"{STRONG_WORKLOAD}_ms_per_step"] = round(o["ms_per_step"], 4)
+                pin_host_threads()
             ax = measure_arxiv(device, banded_control=args.banded)
             line["roofline"] = ax["roofline"]
             extra.update(ax["extra"])
@@ -823,6 +884,8 @@ def main() -> None:
             ga.PLAN_CACHE.clear()
             torch.cuda.empty_cache()   # the S-arxiv phases leave ~1 GB of cached blocks of odd sizes behind
             extra.update(measure_finetune_step(device, normalize))   # last: torch layers, allocator churn
+            extra["best_of_3_averages"] = ["arxiv_proj_*", "cora_*", "pubmed_*", "*_graph_build_wall_us",
+                                           "*_no_prefetch_*"]   # launch-bound extras: see best_event_time_ms
         line["extra"] = extra
     if rank == 0:
         print(json.dumps(line))

@@ -15,6 +15,8 @@
 #include <torch/csrc/autograd/engine.h>
 #include <torch/extension.h>
 
+#include <algorithm>
+
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -206,6 +208,14 @@ struct ParamPack {
   // cannot be told apart later), and the backward node below decides per parameter by looking that
   // node up in the task's exec_info.
   std::shared_ptr<torch::autograd::Node> acc[5];
+  // Gradient sinks (set_grad_sink): a caller-owned buffer per parameter — a view of a flat
+  // all-reduce bucket or of FusedAdam's flat gradient buffer. When a parameter's .grad is undefined at
+  // backward time, the reduction writes its gradient THERE and .grad becomes that view: no pack / copy
+  // before the collective or the optimizer. Undefined = none.
+  at::Tensor sink[5];
+  const at::Tensor& param(int i) const {
+    return i == 0 ? w_down : i == 1 ? b_down : i == 2 ? w_up : i == 3 ? b_up : scalar;
+  }
   void ensure_accumulators() {
     const at::Tensor* ps[5] = {&w_down, &b_down, &w_up, &b_up, &scalar};
     for (int i = 0; i < 5; ++i)
@@ -216,6 +226,27 @@ struct ParamPack {
 std::mutex g_pack_mu;
 std::unordered_map<int64_t, std::shared_ptr<ParamPack>> g_packs;
 int64_t g_next_pack = 1;
+std::unordered_map<c10::TensorImpl*, at::Tensor> g_sinks;   // parameter -> its gradient sink (guarded by g_pack_mu)
+
+// Registers (or, with no destination, removes) the gradient sink of a parameter: a float tensor of
+// the parameter's shape, 16-byte aligned, that the caller keeps alive and does not write during a
+// backward pass. Used by dist.FlatGradBucket / FusedAdam.
+void set_grad_sink(at::Tensor param, c10::optional<at::Tensor> dest) {
+  TORCH_CHECK(param.defined(), "set_grad_sink: undefined parameter");
+  at::Tensor d = dest.value_or(at::Tensor());
+  if (d.defined()) {
+    TORCH_CHECK(d.is_cuda() && d.scalar_type() == at::kFloat && d.is_contiguous() && d.sizes() == param.sizes() &&
+                    d.device() == param.device() && reinterpret_cast<uintptr_t>(d.data_ptr()) % 16 == 0,
+                "set_grad_sink: the sink must be a contiguous, 16-byte aligned fp32 HIP tensor of the parameter's shape");
+  }
+  std::lock_guard<std::mutex> lk(g_pack_mu);
+  if (d.defined()) g_sinks[param.unsafeGetTensorImpl()] = d;
+  else g_sinks.erase(param.unsafeGetTensorImpl());
+  for (auto& kv : g_packs)
+    for (int i = 0; i < 5; ++i)
+      if (kv.second->param(i).defined() && kv.second->param(i).unsafeGetTensorImpl() == param.unsafeGetTensorImpl())
+        kv.second->sink[i] = d;
+}
 
 int64_t pack_create(at::Tensor w_down, c10::optional<at::Tensor> b_down, at::Tensor w_up,
                     c10::optional<at::Tensor> b_up, c10::optional<at::Tensor> scalar) {
@@ -226,6 +257,11 @@ int64_t pack_create(at::Tensor w_down, c10::optional<at::Tensor> b_down, at::Ten
   pk->b_up = b_up.value_or(at::Tensor());
   pk->scalar = scalar.value_or(at::Tensor());
   std::lock_guard<std::mutex> lk(g_pack_mu);
+  for (int i = 0; i < 5; ++i) {
+    if (!pk->param(i).defined()) continue;
+    const auto it = g_sinks.find(pk->param(i).unsafeGetTensorImpl());
+    if (it != g_sinks.end()) pk->sink[i] = it->second;
+  }
   g_packs[g_next_pack] = pk;
   return g_next_pack++;
 }
@@ -261,6 +297,7 @@ struct TaskState {
   std::vector<gconv_pending_finalize_t> pending;
   std::vector<at::Tensor> keep;      // workspaces of the pending entries
   std::vector<PendingGrad> grads;    // reduced by `pending`, stored in p.grad by flush()
+  std::vector<c10::TensorImpl*> sunk; // parameters whose sink this pass has already handed out
   int64_t stream = 0;
   int device = 0;                    // the stream's device (the callback may run elsewhere)
 };
@@ -287,6 +324,7 @@ void flush_locked(TaskState& st) {
   pending.swap(st.pending);
   grads.swap(st.grads);
   keep.swap(st.keep);
+  st.sunk.clear();
   on_device(st.device, [&] {
     check(g_lib.bwd_finalize(pending.data(), static_cast<int32_t>(pending.size()),
                              reinterpret_cast<void*>(st.stream)),
@@ -407,31 +445,6 @@ struct AdapterFnDirect : public torch::autograd::Function<AdapterFnDirect> {
     const int64_t n = x.size(0), d = x.size(1), r = pk->w_down.size(0);
     at::NoGradGuard no_grad;
     at::Tensor gx = ctx->needs_input_grad(0) ? at::empty_like(x) : at::Tensor();
-    // the five parameter gradients are views of ONE allocation (what FlatGradBucket.bind() does
-    // for a whole model): one allocator round trip instead of five per backward node; every view
-    // starts on a 16-byte boundary
-    auto pad4 = [](int64_t v) { return (v + 3) / 4 * 4; };
-    const int64_t n_wd = r * d, n_bd = pk->b_down.defined() ? r : 0, n_bu = pk->b_up.defined() ? d : 0,
-                  n_sc = pk->scalar.defined() ? 1 : 0;
-    const int64_t o_bd = pad4(n_wd), o_wu = o_bd + pad4(n_bd), o_bu = o_wu + pad4(n_wd), o_sc = o_bu + pad4(n_bu);
-    at::Tensor flat = at::empty({o_sc + pad4(n_sc)}, x.options());
-    auto view = [&](int64_t off, int64_t cnt, const at::Tensor& like) {
-      return cnt ? flat.narrow(0, off, cnt).view(like.sizes()) : at::Tensor();
-    };
-    at::Tensor gwd = view(0, n_wd, pk->w_down), gwu = view(o_wu, n_wd, pk->w_up);
-    at::Tensor gbd = view(o_bd, n_bd, pk->b_down), gbu = view(o_bu, n_bu, pk->b_up), gsc = view(o_sc, n_sc, pk->scalar);
-    at::Tensor ws = at::empty({ws_bwd}, x.options().dtype(at::kByte));
-    const float* svp = saved.data_ptr<float>();
-    gconv_adapter_params_t p{fptr(pk->w_down), fptr(pk->b_down), fptr(pk->w_up), fptr(pk->b_up),
-                             fptr(pk->scalar), static_cast<int32_t>(d), static_cast<int32_t>(r),
-                             static_cast<int32_t>(act), skip ? 1 : 0};
-    gconv_pending_finalize_t pend;
-    check(g_lib.bwd_partial(&g, &p, x.data_ptr<float>(), go.data_ptr<float>(), svp,
-                            act == GCONV_ACT_SILU ? svp + 2 * n * fp : nullptr, svp + n * fp,
-                            fptr_mut(gx), gwd.data_ptr<float>(), fptr_mut(gbd), gwu.data_ptr<float>(),
-                            fptr_mut(gbu), fptr_mut(gsc), ws.data_ptr(), static_cast<size_t>(ws_bwd),
-                            &pend, reinterpret_cast<void*>(stream)),
-          "adapter_bwd");
     // A graph task that names its inputs (torch.autograd.grad(out, x), backward(inputs=[...])):
     // a parameter receives its gradient only if it is one of them — its grad accumulator is then
     // in the task's exec_info, marked for execution. AccumulateGrad would run for exactly those.
@@ -448,10 +461,54 @@ struct AdapterFnDirect : public torch::autograd::Function<AdapterFnDirect> {
     };
     const bool want[5] = {wanted(pk->w_down), wanted(pk->b_down), wanted(pk->w_up), wanted(pk->b_up),
                           wanted(pk->scalar)};
-    if (named && !(want[0] || want[1] || want[2] || want[3] || want[4]))
+    const bool any_wanted = want[0] || want[1] || want[2] || want[3] || want[4];
+    // Where the five parameter gradients go. A parameter with a registered sink (a view of a flat
+    // all-reduce / optimizer buffer) and no gradient yet gets its gradient written there, once per
+    // pass; everything else goes to views of ONE fresh allocation (one allocator round trip instead
+    // of five per backward node; every view starts on a 16-byte boundary).
+    const std::shared_ptr<TaskState> st = (!named || any_wanted) ? current_task_state() : nullptr;
+    at::Tensor gout[5];
+    bool to_sink[5] = {false, false, false, false, false};
+    if (st) {
+      std::lock_guard<std::mutex> lk(st->mu);
+      for (int i = 0; i < 5; ++i) {
+        const at::Tensor& prm = pk->param(i);
+        if (!want[i] || !pk->sink[i].defined() || prm.grad().defined()) continue;
+        auto* impl = prm.unsafeGetTensorImpl();
+        if (std::find(st->sunk.begin(), st->sunk.end(), impl) != st->sunk.end()) continue;   // second use this pass
+        st->sunk.push_back(impl);
+        gout[i] = pk->sink[i];
+        to_sink[i] = true;
+      }
+    }
+    auto pad4 = [](int64_t v) { return (v + 3) / 4 * 4; };
+    int64_t need = 0, off5[5];
+    for (int i = 0; i < 5; ++i) {
+      off5[i] = need;
+      if (pk->param(i).defined() && !to_sink[i]) need += pad4(pk->param(i).numel());
+    }
+    if (need > 0) {
+      at::Tensor flat = at::empty({need}, x.options());
+      for (int i = 0; i < 5; ++i)
+        if (pk->param(i).defined() && !to_sink[i])
+          gout[i] = flat.narrow(0, off5[i], pk->param(i).numel()).view(pk->param(i).sizes());
+    }
+    at::Tensor &gwd = gout[0], &gbd = gout[1], &gwu = gout[2], &gbu = gout[3], &gsc = gout[4];
+    at::Tensor ws = at::empty({ws_bwd}, x.options().dtype(at::kByte));
+    const float* svp = saved.data_ptr<float>();
+    gconv_adapter_params_t p{fptr(pk->w_down), fptr(pk->b_down), fptr(pk->w_up), fptr(pk->b_up),
+                             fptr(pk->scalar), static_cast<int32_t>(d), static_cast<int32_t>(r),
+                             static_cast<int32_t>(act), skip ? 1 : 0};
+    gconv_pending_finalize_t pend;
+    check(g_lib.bwd_partial(&g, &p, x.data_ptr<float>(), go.data_ptr<float>(), svp,
+                            act == GCONV_ACT_SILU ? svp + 2 * n * fp : nullptr, svp + n * fp,
+                            fptr_mut(gx), gwd.data_ptr<float>(), fptr_mut(gbd), gwu.data_ptr<float>(),
+                            fptr_mut(gbu), fptr_mut(gsc), ws.data_ptr(), static_cast<size_t>(ws_bwd),
+                            &pend, reinterpret_cast<void*>(stream)),
+          "adapter_bwd");
+    if (named && !any_wanted)
       return {gx, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
               at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
-    const std::shared_ptr<TaskState> st = current_task_state();
     {
       std::lock_guard<std::mutex> lk(st->mu);
       if (!st->pending.empty() && st->stream != stream) flush_locked(*st);   // another stream: do not mix
@@ -697,6 +754,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("adapter_apply_direct", &adapter_apply_direct);
   m.def("pack_create", &pack_create);
   m.def("pack_release", &pack_release);
+  m.def("set_grad_sink", &set_grad_sink);
   m.def("plan_submit", &plan_submit);
   m.def("plan_take", &plan_take);
   m.def("layer_norm_scale", &layer_norm_scale);

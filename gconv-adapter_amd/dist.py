@@ -48,13 +48,27 @@ def adapter_trainable_parameters(model: torch.nn.Module) -> List[torch.nn.Parame
 
 
 class FlatGradBucket:
-    """One contiguous gradient buffer for a parameter list.
+    """One contiguous gradient buffer for a parameter list; every parameter starts on a 16-byte
+    boundary (padding floats are zero and stay zero).
 
-    ``p.grad`` of every parameter is a view into ``self.flat``; autograd
-    accumulates into the views in place, so after ``backward()`` the bucket is
-    ready for a single ``all_reduce``."""
+    Three ways to get the gradients into it, cheapest first:
 
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
+    * ``attach_sinks()`` (the default on a HIP device with the C++ binding): every view is registered
+      as the parameter's *gradient sink*. The adapter's backward node then lets its last kernel (the
+      fixed-order reduction of the per-workgroup partials) write ``dW / db / ds`` STRAIGHT into the
+      bucket and sets ``p.grad`` to the view — no ``cat`` before the collective, no copy back after
+      it. Needs the step to start from ``p.grad = None`` (``zero_grad(set_to_none=True)``); a
+      parameter that still holds a gradient is accumulated into the ordinary way.
+    * parameters that autograd fills itself (prediction head, norm layers: fresh tensors per step)
+      are packed by ``all_reduce_grads`` with ONE multi-tensor copy and re-bound to their views.
+    * ``bind()``: every ``p.grad`` a view up front, autograd accumulates in place (``zero_()`` per step).
+
+    ``all_reduce_grads(async_op=True)`` launches the ONE collective of the step behind the current
+    stream's work and returns; ``wait()`` — before the optimizer, or before the next backward writes
+    the sinks again — makes the current stream wait for it. RCCL runs it on its own stream, so it is
+    off the critical path of whatever the host queues in between (the next batch's graph build)."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], sinks: bool = True):
         self.params = [p for p in params]
         if not self.params:
             raise ValueError("FlatGradBucket needs at least one parameter")
@@ -66,11 +80,36 @@ class FlatGradBucket:
         total = 0
         for p in self.params:
             self.offsets.append(total)
-            total += p.numel()
+            total += -(-p.numel() // 4) * 4
         self.flat = torch.zeros(total, dtype=dt, device=dev)
         self.views = [self.flat[off:off + p.numel()].view_as(p)
                       for p, off in zip(self.params, self.offsets)]
-        self.bind()
+        self._work = None
+        self.sinks = False
+        if sinks and dev.type == "cuda" and dt == torch.float32:
+            self.attach_sinks()
+        else:
+            self.bind()
+
+    def attach_sinks(self) -> bool:
+        """Registers the views as gradient sinks with the C++ binding (see the class docstring).
+        False when the binding is absent (ctypes path): use ``bind()`` or plain ``all_reduce_grads``."""
+        from . import _torch_ext
+        ext = _torch_ext.get()
+        if ext is None or not hasattr(ext, "set_grad_sink"):
+            return False
+        for p, v in zip(self.params, self.views):
+            ext.set_grad_sink(p, v)
+        self.sinks = True
+        return True
+
+    def detach_sinks(self) -> None:
+        from . import _torch_ext
+        ext = _torch_ext.get()
+        if self.sinks and ext is not None:
+            for p in self.params:
+                ext.set_grad_sink(p, None)
+        self.sinks = False
 
     def bind(self) -> None:
         """Makes every ``p.grad`` a view into the flat buffer (autograd then accumulates in
@@ -83,8 +122,14 @@ class FlatGradBucket:
         return self.flat.numel() * self.flat.element_size()
 
     def zero_(self) -> None:
-        """Replaces ``optimizer.zero_grad()``: keeps the views, zeroes in one op."""
+        """Replaces ``optimizer.zero_grad()`` in ``bind()`` mode: keeps the views, zeroes in one op."""
         self.flat.zero_()
+
+    def wait(self) -> None:
+        """Orders the current stream behind the collective launched by an ``async_op`` call."""
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
 
     def all_reduce(self, average: bool = False, async_op: bool = False):
         """Sum (or mean) of the bucket over all ranks: one collective per step.
@@ -95,24 +140,37 @@ class FlatGradBucket:
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return None
         work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
-        if average and not async_op:
+        if async_op:
+            self._work = work
+        elif average:
             self.flat.div_(dist.get_world_size())
         return work
 
-    def all_reduce_grads(self, average: bool = False) -> None:
-        """Launch-lean variant for steps that start from ``p.grad = None``: autograd hands
-        back fresh gradient tensors (no accumulate kernels); they are packed with ONE ``cat``
-        into the flat buffer, reduced with ONE collective, and copied back with ONE
-        multi-tensor copy. Three launches per step instead of one add per parameter."""
-        grads = [p.grad for p in self.params]
-        if any(g is None for g in grads):
-            raise RuntimeError("all_reduce_grads: every bucketed parameter needs a gradient")
-        torch.cat([g.reshape(-1) for g in grads], out=self.flat)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            if average:
-                self.flat.div_(dist.get_world_size())
-            torch._foreach_copy_(grads, self.views)
+    def gather_stragglers(self) -> int:
+        """Gradients that are not in the bucket yet (autograd's own fresh tensors: parameters without
+        a sink, or a step that accumulated) are copied in with ONE multi-tensor copy and ``p.grad`` is
+        re-bound to the view. Returns how many there were (0 for an adapter-only parameter list with
+        sinks: nothing is launched)."""
+        src, dst = [], []
+        for p, v in zip(self.params, self.views):
+            g = p.grad
+            if g is None:
+                raise RuntimeError("FlatGradBucket: every bucketed parameter needs a gradient")
+            if g.data_ptr() != v.data_ptr():
+                src.append(g)
+                dst.append(v)
+                p.grad = v
+        if src:
+            torch._foreach_copy_(dst, src)
+        return len(src)
+
+    def all_reduce_grads(self, average: bool = False, async_op: bool = False):
+        """The step's gradient exchange for loops that start from ``p.grad = None``: stragglers in
+        (see ``gather_stragglers``), ONE collective on the flat buffer, ``p.grad`` = views of it —
+        nothing is copied back. ``async_op``: returns at once, ``wait()`` later."""
+        self.gather_stragglers()
+        work = self.all_reduce(average=average and not async_op, async_op=async_op)
+        return work
 
 
 # ---------------------------------------------------------------------------------------

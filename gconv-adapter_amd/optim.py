@@ -63,8 +63,36 @@ class FusedAdam(torch.optim.Optimizer):
                 off += -(-n // 4) * 4
         grad = torch.zeros_like(flat)
         grad_views = [grad[o:o + p.numel()].view_as(p) for p, o in zip(ps, offsets)]
+        # the gradient views double as the parameters' gradient SINKS: the adapter's backward node
+        # writes dW / db / ds straight into `grad` (csrc/torch_binding.cpp, set_grad_sink) and step()
+        # finds them in place — no copy at all for the adapters, one multi-tensor copy for the rest
+        from . import _torch_ext
+        ext = _torch_ext.get()
+        if ext is not None and hasattr(ext, "set_grad_sink"):
+            for p, gv in zip(ps, grad_views):
+                ext.set_grad_sink(p, gv)
         return dict(params=ps, offsets=offsets, total=total, flat=flat, grad=grad, grad_views=grad_views,
                     exp_avg=m, exp_avg_sq=v, steps=[0] * len(ps))
+
+    def flat_grads(self) -> List[torch.Tensor]:
+        """The flat gradient buffer of every parameter group (what a data-parallel loop all-reduces,
+        after ``gather_grads()``): padding floats are zero."""
+        return [fl["grad"] for fl in self._flat if fl.get("params")]
+
+    @torch.no_grad()
+    def gather_grads(self) -> None:
+        """Brings every gradient that is not in its group's flat buffer yet into it (one multi-tensor
+        copy per group) and re-binds ``p.grad`` to the buffer's view."""
+        for fl in self._flat:
+            src, dst = [], []
+            for p, gv in zip(fl.get("params", []), fl.get("grad_views", [])):
+                g = p.grad
+                if g is not None and g.data_ptr() != gv.data_ptr():
+                    src.append(g)
+                    dst.append(gv)
+                    p.grad = gv
+            if src:
+                torch._foreach_copy_(dst, src)
 
     # ------------------------------------------------------------------ step
     @torch.no_grad()
@@ -89,8 +117,10 @@ class FusedAdam(torch.optim.Optimizer):
                     steps[i] += 1
             beta1, beta2 = group["betas"]
             dev = fl["flat"].device
-            if all(has) and min(steps) == max(steps):   # the normal case: one multi-tensor copy, one launch
-                torch._foreach_copy_(fl["grad_views"], grads)
+            if all(has) and min(steps) == max(steps):   # the normal case: (one multi-tensor copy,) one launch
+                pend = [(gv, g) for gv, g in zip(fl["grad_views"], grads) if g.data_ptr() != gv.data_ptr()]
+                if pend:   # gradients the backward pass has not already deposited in the flat buffer
+                    torch._foreach_copy_([a for a, _ in pend], [b for _, b in pend])
                 st = self._lib.gconv_adam_step_f32(
                     fl["flat"].data_ptr(), fl["grad"].data_ptr(), fl["exp_avg"].data_ptr(),
                     fl["exp_avg_sq"].data_ptr(), fl["total"], float(group["lr"]), float(beta1), float(beta2),
@@ -109,7 +139,9 @@ class FusedAdam(torch.optim.Optimizer):
                     j += 1
                 lo = fl["offsets"][i]
                 hi = fl["offsets"][j - 1] + ps[j - 1].numel()
-                torch._foreach_copy_(fl["grad_views"][i:j], grads[i:j])
+                pend = [(gv, g) for gv, g in zip(fl["grad_views"][i:j], grads[i:j]) if g.data_ptr() != gv.data_ptr()]
+                if pend:
+                    torch._foreach_copy_([a for a, _ in pend], [b for _, b in pend])
                 st = self._lib.gconv_adam_step_f32(
                     fl["flat"].data_ptr() + 4 * lo, fl["grad"].data_ptr() + 4 * lo,
                     fl["exp_avg"].data_ptr() + 4 * lo, fl["exp_avg_sq"].data_ptr() + 4 * lo, hi - lo,

@@ -54,16 +54,19 @@ def _worker(rank, world, port, out_path):
     loss.backward()
     assert [p.grad.data_ptr() for p in bucket.params] == views, "autograd must accumulate in place"
     bucket.all_reduce()
-    flat_views = bucket.flat.clone()
-    # launch-lean variant: fresh grads -> cat -> one all-reduce -> multi-tensor copy back
+    flat_views = torch.cat([v.flatten() for v in bucket.views]).clone()
+    # steps that start from p.grad = None: autograd's fresh tensors are packed with one multi-tensor
+    # copy, ONE all-reduce (asynchronous here), p.grad = views of the flat buffer (nothing copied back)
     for p in bucket.params:
         p.grad = None
     loss = ((model(shard.x) - target) ** 2).sum() / count
     loss.backward()
-    bucket.all_reduce_grads()
+    assert bucket.all_reduce_grads(async_op=True) is not None
+    bucket.wait()
+    assert [p.grad.data_ptr() for p in bucket.params] == views
     packed = torch.cat([p.grad.flatten() for p in bucket.params])
     assert torch.allclose(packed, flat_views, rtol=1e-6, atol=1e-7)
-    assert torch.equal(packed, bucket.flat)
+    assert bucket.gather_stragglers() == 0
     if rank == 0:
         torch.save({"flat": flat_views, "count": count}, out_path)
     dist.barrier()
@@ -87,9 +90,11 @@ def test_sharded_flat_allreduce_matches_single_process(tmp_path):
 def test_bucket_layout_single_process():
     m = ga.GConvAdapter(8, 2, learnable_scalar=True)
     b = ga.dist.FlatGradBucket(m.parameters())
-    assert b.flat.numel() == sum(p.numel() for p in m.parameters()) and b.nbytes == 4 * b.flat.numel()
+    # every parameter on a 16-byte boundary (the adapter kernels read / write them 4 floats at a time)
+    assert b.flat.numel() == sum(-(-p.numel() // 4) * 4 for p in m.parameters()) and b.nbytes == 4 * b.flat.numel()
+    assert not b.sinks                       # CPU tensors: bind() mode
     for p, off in zip(b.params, b.offsets):
-        assert p.grad.data_ptr() == b.flat.data_ptr() + 4 * off
+        assert p.grad.data_ptr() == b.flat.data_ptr() + 4 * off and off % 4 == 0
     b.flat.fill_(3.0)
     b.zero_()
     assert all(torch.count_nonzero(p.grad) == 0 for p in m.parameters())

@@ -244,3 +244,69 @@ def test_two_ranks_on_one_gpu_match_the_single_device_module(dev, tmp_path, redu
     for k, p in ref.named_parameters():
         want = p.grad.cpu().double()
         assert_close(got["grads"][k].double(), want, f"grad {k}", 2e-5, grad_atol(want, 2e-5))
+
+
+# ---------------------------------------------------------------------------
+# molecule batches, sharded BY GRAPH: gradient sinks + ONE asynchronous flat all-reduce
+# ---------------------------------------------------------------------------
+def _shard_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    batch = ga.synth.molecule_batch("hiv", 48, hidden=64, seed=3)
+    shard = ga.synth.shard_graphs(batch, rank, world)
+    torch.manual_seed(0)
+    mods = torch.nn.ModuleList([ga.GConvAdapter(64, 8, learnable_scalar=True, normalize=True) for _ in range(3)]).to(dev)
+    with torch.no_grad():
+        for p in mods.parameters():
+            p.normal_(0, 0.1)
+    params = list(mods.parameters())
+    bucket = ga.dist.FlatGradBucket(params)
+    assert bucket.sinks, "the C++ binding registers the bucket's views as gradient sinks"
+    g_all = torch.randn(batch.num_nodes, 64, generator=torch.Generator().manual_seed(1))
+    n0 = int(batch.graph_ptr[(batch.num_graphs * rank) // world])
+    g = g_all[n0:n0 + shard.num_nodes].to(dev)
+    x, ei = shard.x.to(dev), shard.edge_index.to(dev)
+    for step in range(2):                      # the second step overwrites the sinks
+        bucket.wait()
+        for p in params:
+            p.grad = None
+        h = x
+        for m in mods:
+            h = m(h, ei)
+        h.backward(g)
+        # the backward pass has put every gradient in the bucket: nothing to pack
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, bucket.views))
+        assert bucket.gather_stragglers() == 0
+        bucket.all_reduce_grads(async_op=True)
+    bucket.wait()
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save({k: p.grad.cpu() for k, p in mods.named_parameters()}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_by_graph_with_gradient_sinks(dev, tmp_path):
+    """Two processes, one shard of the batch each: the adapters' backward deposits dW /
+    db / ds straight into the flat bucket (no cat, no copy back), ONE asynchronous all-reduce per step
+    — the summed gradients equal the single-process gradients of the whole batch."""
+    out_path = str(tmp_path / "r0.pt")
+    mp.start_processes(_shard_worker, args=(2, _free_port(), out_path), nprocs=2, join=True, start_method="spawn")
+    got = torch.load(out_path)
+    batch = ga.synth.molecule_batch("hiv", 48, hidden=64, seed=3)
+    torch.manual_seed(0)
+    mods = torch.nn.ModuleList([ga.GConvAdapter(64, 8, learnable_scalar=True, normalize=True) for _ in range(3)]).to(dev)
+    with torch.no_grad():
+        for p in mods.parameters():
+            p.normal_(0, 0.1)
+    g = torch.randn(batch.num_nodes, 64, generator=torch.Generator().manual_seed(1)).to(dev)
+    h = batch.x.to(dev)
+    for m in mods:
+        h = m(h, batch.edge_index.to(dev))
+    h.backward(g)
+    for k, p in mods.named_parameters():
+        want = p.grad.cpu().double()
+        assert_close(got[k].double(), want, f"grad {k}", 1e-5, grad_atol(want))

@@ -320,3 +320,45 @@ def test_replaced_parameter_is_picked_up(dev):
     out.backward(g.to(dev))
     assert not torch.allclose(out.detach(), before)
     _check_against_oracle(mod, batch, flags, params2, g, xg, out)
+
+
+def test_gradient_sinks_single_process(dev):
+    """`FlatGradBucket` / `FusedAdam` register their flat views as gradient sinks: the backward
+    deposits there when p.grad is None, accumulates the ordinary way when it is not, hands a sink
+    out once per pass (a module used twice in one graph), and the numbers do not change."""
+    batch, flags, params, mod, g = _setup(dev, seed=9)
+    ei, x, gd = batch.edge_index.to(dev), batch.x.to(dev), g.to(dev)
+    mod(x, ei).backward(gd)
+    want = {k: p.grad.clone() for k, p in mod.named_parameters()}
+    mod.zero_grad(set_to_none=True)
+    bucket = ga.dist.FlatGradBucket(list(mod.parameters()))
+    assert bucket.sinks
+    mod(x, ei).backward(gd)
+    for (k, p), v in zip(mod.named_parameters(), bucket.views):
+        assert p.grad.data_ptr() == v.data_ptr() and torch.equal(p.grad, want[k]), k
+    mod(x, ei).backward(gd)                                  # p.grad defined: accumulated, still in the bucket
+    for (k, p), v in zip(mod.named_parameters(), bucket.views):
+        assert p.grad.data_ptr() == v.data_ptr() and torch.allclose(p.grad, 2 * want[k], rtol=1e-6), k
+    mod.zero_grad(set_to_none=True)
+    (mod(x, ei) + mod(x, ei)).backward(gd)                   # the module twice in one graph
+    for k, p in mod.named_parameters():
+        assert torch.allclose(p.grad, 2 * want[k], rtol=1e-6, atol=1e-7), k
+    bucket.detach_sinks()
+    mod.zero_grad(set_to_none=True)
+    mod(x, ei).backward(gd)
+    assert all(p.grad.data_ptr() != v.data_ptr() for p, v in zip(mod.parameters(), bucket.views))
+    # FusedAdam: the gradients land in its flat buffer, step() copies nothing, same update as torch
+    ref = [p.detach().clone().requires_grad_(True) for p in mod.parameters()]
+    topt = torch.optim.Adam(ref, lr=1e-2)
+    opt = ga.FusedAdam(mod.parameters(), lr=1e-2)
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        mod(x, ei).backward(gd)
+        flat = opt.flat_grads()[0]
+        assert all(flat.data_ptr() <= p.grad.data_ptr() < flat.data_ptr() + 4 * flat.numel() for p in mod.parameters())
+        for q, p in zip(ref, mod.parameters()):
+            q.grad = p.grad.detach().clone()
+        opt.step()
+        topt.step()
+    for q, p in zip(ref, mod.parameters()):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-6)

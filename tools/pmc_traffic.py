@@ -20,7 +20,7 @@ res = {"workload": "S-arxiv N=170000 nnz=1199998 F=32 normalized, production fla
        "command": "bash tools/pmc_traffic.sh  (rocprofv3 --pmc <group> --output-format csv -- python3 tools/spmm_only.py; "
                   "one pass per group: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum)",
        "kernels": {"spmm_rows_kernel<32,norm,GENERIC>": avg},
-       "derived": {"fetch_bytes_raw": fetch_raw, "fetch_bytes_x2_gfx950": 2 * fetch_raw, "write_bytes": write,
+       "derived": {"commit": os.environ.get("GCONV_COMMIT", "n/a"), "fetch_bytes_raw": fetch_raw, "fetch_bytes_x2_gfx950": 2 * fetch_raw, "write_bytes": write,
                    "traffic_bytes_per_launch": 2 * fetch_raw + write, "l2_hit_rate": hit / (hit + miss),
                    "tcc_miss_x128B": miss * 128,
                    "note": "FETCH_SIZE/WRITE_SIZE are in KiB; gfx950 tallies a 128-B read request as 64 B "
