@@ -377,6 +377,14 @@ __device__ __forceinline__ void small_bitonic_sort(uint32_t (&v)[NR], uint32_t* 
   }
 }
 
+struct CsrLds {   // the single-workgroup build's CSR as it sits in LDS (tiles.h: tile_cut_wave / tile_halo_wave)
+  const int32_t* rowptr_;
+  const uint32_t* keys_;
+  KeyOps<uint32_t> ko_;
+  __device__ __forceinline__ int rowptr(int i) const { return rowptr_[i]; }
+  __device__ __forceinline__ int col(int e) const { return static_cast<int>(ko_.col(keys_[e])); }
+};
+
 struct SmallBuildArgs {
   const int64_t* ei; int32_t E, n, normalize, shift, nsort, ntiles, T, slack;
   // outputs (device): forward / transposed CSR slots, dis, tiles, info
@@ -469,14 +477,15 @@ __device__ __forceinline__ void small_direction(const SmallBuildArgs& a, int tra
 template <int NR, int T>
 __global__ __launch_bounds__(T) void small_graph_build_kernel(SmallBuildArgs a) {
   extern __shared__ int32_t sm[];
-  // layout: keys[nsort] | rowptr[n + 1] | flags[n] | flags2[n] | tmp[1024] | tsize[ntiles] | sinfo[64]
+  // layout: keys[nsort] | rowptr[n + 1] | flags[n] | flags2[n] | tmp[1024] | tsize[ntiles] | tptr[ntiles + 1] | sinfo[64]
   uint32_t* keys = reinterpret_cast<uint32_t*>(sm);
   int32_t* rowptr = sm + a.nsort;
   int32_t* flags = rowptr + a.n + 1;
   int32_t* flags2 = flags + a.n;
   int32_t* tmp = flags2 + a.n;
   int32_t* tsize = tmp + T;
-  int32_t* sinfo = tsize + a.ntiles;   // the info words (enum above; forward counters at 16, transposed at 24)
+  int32_t* tptr = tsize + a.ntiles;
+  int32_t* sinfo = tptr + a.ntiles + 1;   // the info words (enum above; forward counters at 16, transposed at 24)
   const int tid = threadIdx.x, n = a.n;
   const int lane = tid & 63, wave = tid >> 6;
   if (tid < 64) sinfo[tid] = 0;
@@ -501,17 +510,20 @@ __global__ __launch_bounds__(T) void small_graph_build_kernel(SmallBuildArgs a) 
   }
   __syncthreads();   // (also: the CSR this workgroup wrote to global memory is complete)
 
-  // tiles (tiles.h): one wave per tile places its cuts on the global CSR this workgroup has just
-  // written, finds its halo and translates its columns; same routine as the multi-launch build
+  // tiles (tiles.h): one wave per tile places its cuts, finds its halo and translates its columns —
+  // the routine of the multi-launch build, reading the CSR out of LDS (rowptr as it stands, a column
+  // = the low field of a sorted key)
   const TileInfoSlots is{INFO_NOTILE, INFO_TILEMAX, INFO_TILEEDGES};
+  const CsrLds csr_lds{rowptr, keys, ko};
   for (int t = wave; t < a.ntiles; t += T / 64) {
-    const int ts = tile_cut_wave(a.rowptr_f, a.col_f, n, t, a.ntiles, a.T, a.slack, lane);
-    const int te = tile_cut_wave(a.rowptr_f, a.col_f, n, t + 1, a.ntiles, a.T, a.slack, lane);
+    const int ts = tile_cut_wave(csr_lds, n, t, a.ntiles, a.T, a.slack, lane);
+    const int te = tile_cut_wave(csr_lds, n, t + 1, a.ntiles, a.T, a.slack, lane);
     if (lane == 0) {
       a.tile_ptr[t] = ts;
-      if (t == a.ntiles - 1) a.tile_ptr[a.ntiles] = n;
+      tptr[t] = ts;
+      if (t == a.ntiles - 1) { a.tile_ptr[a.ntiles] = n; tptr[a.ntiles] = n; }
     }
-    tile_halo_wave(a.rowptr_f, a.col_f, a.dis, ts, te, t, a.lcol_f, a.halo_f, a.recs_f + t, sinfo, is, lane);
+    tile_halo_wave(csr_lds, a.dis, ts, te, t, a.lcol_f, a.halo_f, a.recs_f + t, sinfo, is, lane);
   }
   __syncthreads();
   const bool asym = sinfo[INFO_ASYM] != 0;   // uniform: directed edge list -> S^T as well, in the same launch
@@ -519,9 +531,8 @@ __global__ __launch_bounds__(T) void small_graph_build_kernel(SmallBuildArgs a) 
     small_direction<NR, T>(a, 1, keys, rowptr, tmp, flags, flags2, a.rowptr_b, a.col_b, nullptr, a.long_rows_b,
                     a.long_seg_base_b, a.seg_long_b, a.long_sync_b, 24, sinfo);
     __syncthreads();
-    for (int t = wave; t < a.ntiles; t += T / 64)
-      tile_halo_wave(a.rowptr_b, a.col_b, a.dis, a.tile_ptr[t], a.tile_ptr[t + 1], t, a.lcol_b, a.halo_b, a.recs_b + t,
-                     sinfo, is, lane);
+    for (int t = wave; t < a.ntiles; t += T / 64)   // (keys / rowptr now hold the transposed CSR)
+      tile_halo_wave(csr_lds, a.dis, tptr[t], tptr[t + 1], t, a.lcol_b, a.halo_b, a.recs_b + t, sinfo, is, lane);
     __syncthreads();
   }
   // size-sorted tile list: rank by (rows incl. halo descending, index ascending) == tile_sort_small_kernel;
@@ -627,7 +638,7 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
     a.recs_f = tf.recs; a.recs_b = tb.recs; a.tiles_f = tf.tiles; a.tiles_b = tb.tiles;
     a.lcol_f = tf.lcol; a.lcol_b = tb.lcol; a.halo_f = tf.halo; a.halo_b = tb.halo;
     const size_t lds = (static_cast<size_t>(a.nsort) + (n + 1) + 2 * static_cast<size_t>(n) + threads +
-                        L.ntiles + 64) * sizeof(int32_t);
+                        2 * L.ntiles + 1 + 64) * sizeof(int32_t);
 #define GCONV_SMALL_BUILD(NR_, T_)                                                                     \
   do {                                                                                                 \
     if (lds > 48 * 1024)                                                                               \

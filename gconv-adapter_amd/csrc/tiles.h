@@ -42,6 +42,16 @@ static_assert(kHaloNodes == 64, "tile_halo_wave keeps one halo node per lane");
 // counters of a build that the tile kernels report into (indices into the build's info words)
 struct TileInfoSlots { int notile, nodes_max, edges_max; };
 
+// How the tile routines read the CSR: from global memory (the multi-launch build, the plan assembled
+// from a resident dataset) or — the single-workgroup build — from the LDS copy the workgroup has just
+// produced (row offsets as they are, columns as the low field of the sorted keys).
+struct CsrGlobal {
+  const int32_t* __restrict__ rowptr_;
+  const int32_t* __restrict__ col_;
+  __device__ __forceinline__ int rowptr(int i) const { return rowptr_[i]; }
+  __device__ __forceinline__ int col(int e) const { return col_[e]; }
+};
+
 __device__ __forceinline__ int wave_max_i(int v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
@@ -59,17 +69,16 @@ __device__ __forceinline__ int wave_min_i(int v) {
 // column (rows are sorted): exact for the tree-plus-chords layouts of molecules, a heuristic in
 // general — correctness never depends on it (tile_halo_wave finds every crossing edge).
 // One wave; all lanes return the cut.
-__device__ __forceinline__ int tile_cut_wave(const int32_t* __restrict__ rowptr,
-                                             const int32_t* __restrict__ col, int n, int k, int ntiles,
-                                             int T, int slack, int lane) {
+template <class Csr>
+__device__ __forceinline__ int tile_cut_wave(const Csr& csr, int n, int k, int ntiles, int T, int slack, int lane) {
   if (k <= 0) return 0;
   if (k >= ntiles) return n;
   const int q0 = k * T;
   auto reach = [&](int row, int& mx, int& mn) {
     mx = -1; mn = INT_MAX;
     if (row >= 0 && row < n) {
-      const int a = rowptr[row], b = rowptr[row + 1];
-      if (b > a) { mn = col[a]; mx = col[b - 1]; }
+      const int a = csr.rowptr(row), b = csr.rowptr(row + 1);
+      if (b > a) { mn = csr.col(a); mx = csr.col(b - 1); }
     }
   };
   int mxA, mnA, mxB, mnB, mxC, mnC;
@@ -103,9 +112,25 @@ __device__ __forceinline__ int tile_cut_wave(const int32_t* __restrict__ rowptr,
 
 // Halo, local column ids and record of tile t = rows [ts, te) of one CSR (forward or transposed).
 // One wave. `rec` receives the unsorted record (slot = t).
-__device__ __forceinline__ void tile_halo_wave(const int32_t* __restrict__ rowptr,
-                                               const int32_t* __restrict__ col,
-                                               const float* __restrict__ dis, int ts, int te, int t,
+//
+// The halo is collected in two sweeps: the own rows' edges, 64 per step (halo1: outside columns in
+// edge order), then the halo1 rows' edges with ONE LANE PER HALO ROW, all lanes stepping through
+// their rows together (halo2: outside columns in (edge position, halo row) order) — a handful of
+// memory round trips per tile whatever the halo's size (a row-by-row walk of the halo cost two
+// dependent round trips per halo node: 25 us per tile, most of the graph build). A tile that cannot
+// be a tile — more own edges than kTileMaxOwnEdges, a halo beyond its slot — is given up at once
+// (hub rows of a power-law graph would otherwise be walked edge by edge), and once one tile has
+// been given up the graph is not tileable and the other waves stop as well.
+constexpr int kTileMaxOwnEdges = 1 << 14;
+
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+template <class Csr>
+__device__ __forceinline__ void tile_halo_wave(const Csr& csr, const float* __restrict__ dis, int ts, int te, int t,
                                                int32_t* __restrict__ lcol, int32_t* __restrict__ slots,
                                                gconv_tile_t* __restrict__ rec, int32_t* info,
                                                TileInfoSlots is, int lane) {
@@ -113,13 +138,24 @@ __device__ __forceinline__ void tile_halo_wave(const int32_t* __restrict__ rowpt
   int32_t* hnodes = slots + static_cast<size_t>(t) * kHaloSlot;
   int32_t* hrp = hnodes + kHaloRpOff;
   int32_t* hcol = hnodes + kHaloColOff;
-  const int e0 = rowptr[ts], e1 = rowptr[te];
+  const int e0 = csr.rowptr(ts), e1 = csr.rowptr(te);
+  auto give_up = [&]() {
+    if (lane == 0) {
+      atomicOr(&info[is.notile], 1);
+      *rec = gconv_tile_t{ts, nt, nt, nt, t, e0, e1 - e0, 0};
+    }
+  };
+  if (__hip_atomic_load(&info[is.notile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+      e1 - e0 > kTileMaxOwnEdges) {
+    give_up();
+    return;
+  }
   int hval = -1;       // lane j: the j-th halo node
   int hcount = 0;      // wave-uniform
   bool overflow = false;
   // appends the nodes c of the lanes in m that are not in the list yet, in lane order
   auto append = [&](unsigned long long m, int c) {
-    while (m) {
+    while (m && !overflow) {
       const int b = __ffsll(static_cast<long long>(m)) - 1;
       m &= m - 1;
       const int v = __shfl(c, b);
@@ -133,24 +169,32 @@ __device__ __forceinline__ void tile_halo_wave(const int32_t* __restrict__ rowpt
       }
     }
   };
-  for (int base = e0; base < e1; base += 64) {           // halo1: outside columns of the own rows
+  for (int base = e0; base < e1 && !overflow; base += 64) {   // halo1: outside columns of the own rows
     const int e = base + lane;
-    const int c = e < e1 ? col[e] : ts;
+    const int c = e < e1 ? csr.col(e) : ts;
     append(__ballot(e < e1 && (c < ts || c >= te)), c);
   }
+  if (overflow) { give_up(); return; }
   const int nh1 = hcount;
-  int he = 0;
-  for (int h = 0; h < nh1; ++h) {                         // halo2: outside columns of the halo1 rows
-    const int row = __shfl(hval, h);
-    const int a = rowptr[row], b = rowptr[row + 1];
-    for (int base = a; base < b; base += 64) {
-      const int e = base + lane;
-      const int c = e < b ? col[e] : ts;
-      append(__ballot(e < b && (c < ts || c >= te)), c);
-    }
-    he += b - a;
+  // the halo1 rows, one per lane: offsets, degrees, exclusive prefix of the degrees
+  const int ha = lane < nh1 ? csr.rowptr(hval) : 0;
+  const int hdeg = lane < nh1 ? csr.rowptr(hval + 1) - ha : 0;
+  const int he = wave_sum_i(hdeg);
+  const int dmax = wave_max_i(hdeg);
+  if (he > kHaloEdges) { give_up(); return; }
+  int hoff = hdeg;                                            // inclusive scan over the lanes
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(hoff, off);
+    if (lane >= off) hoff += v;
   }
-  if (he > kHaloEdges) overflow = true;
+  hoff -= hdeg;                                               // exclusive: first edge slot of this lane's row
+  for (int k = 0; k < dmax && !overflow; ++k) {               // halo2: outside columns of the halo1 rows
+    const bool ok = k < hdeg;
+    const int c = ok ? csr.col(ha + k) : ts;
+    append(__ballot(ok && (c < ts || c >= te)), c);
+  }
+  if (overflow) { give_up(); return; }
   // tile-local id of column c (uniform control flow: every lane walks the list when any needs it)
   auto local_id = [&](int c, bool outside) {
     int id = c - ts;
@@ -165,26 +209,18 @@ __device__ __forceinline__ void tile_halo_wave(const int32_t* __restrict__ rowpt
   for (int base = e0; base < e1; base += 64) {
     const int e = base + lane;
     const bool ok = e < e1;
-    const int c = ok ? col[e] : ts;
+    const int c = ok ? csr.col(e) : ts;
     const int id = local_id(c, ok && (c < ts || c >= te));
     if (ok) lcol[e] = id;
   }
-  int run = 0;
-  if (lane == 0) hrp[0] = 0;
-  for (int h = 0; h < nh1; ++h) {
-    const int row = __shfl(hval, h);
-    const int a = rowptr[row], b = rowptr[row + 1];
-    for (int base = a; base < b; base += 64) {
-      const int e = base + lane;
-      const bool ok = e < b;
-      const int c = ok ? col[e] : ts;
-      const int id = local_id(c, ok && (c < ts || c >= te));
-      const int pos = run + (e - a);
-      if (ok && pos < kHaloEdges) hcol[pos] = id;
-    }
-    run += b - a;
-    if (lane == 0) hrp[h + 1] = run;
+  for (int k = 0; k < dmax; ++k) {
+    const bool ok = k < hdeg;
+    const int c = ok ? csr.col(ha + k) : ts;
+    const int id = local_id(c, ok && (c < ts || c >= te));
+    if (ok) hcol[hoff + k] = id;
   }
+  if (lane == 0) hrp[0] = 0;
+  if (lane < nh1) hrp[lane + 1] = hoff + hdeg;
   if (lane < hcount) {
     hnodes[lane] = hval;
     if (dis) reinterpret_cast<float*>(hnodes + kHaloDisOff)[lane] = dis[hval];
@@ -194,9 +230,8 @@ __device__ __forceinline__ void tile_halo_wave(const int32_t* __restrict__ rowpt
     r.first = ts; r.count = nt; r.n1 = nt + nh1; r.n0 = nt + hcount; r.slot = t; r.e0 = e0;
     r.ne_own = e1 - e0; r.ne_halo = he;
     *rec = r;
-    if (overflow) atomicOr(&info[is.notile], 1);
     atomicMax(&info[is.nodes_max], nt + hcount);
-    atomicMax(&info[is.edges_max], e1 - e0 + min(he, kHaloEdges));
+    atomicMax(&info[is.edges_max], e1 - e0 + he);
   }
 }
 
@@ -215,9 +250,10 @@ __global__ __launch_bounds__(256) void tile_build_kernel(const int32_t* __restri
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= ntiles) return;   // wave-uniform
   int ts, te;
+  const CsrGlobal csr{rowptr, col};
   if (CUTS) {
-    ts = tile_cut_wave(rowptr, col, n, t, ntiles, T, slack, lane);
-    te = tile_cut_wave(rowptr, col, n, t + 1, ntiles, T, slack, lane);
+    ts = tile_cut_wave(csr, n, t, ntiles, T, slack, lane);
+    te = tile_cut_wave(csr, n, t + 1, ntiles, T, slack, lane);
     if (lane == 0) {
       tile_ptr[t] = ts;
       if (t == ntiles - 1) tile_ptr[ntiles] = n;
@@ -226,7 +262,7 @@ __global__ __launch_bounds__(256) void tile_build_kernel(const int32_t* __restri
     ts = tile_ptr[t];
     te = tile_ptr[t + 1];
   }
-  tile_halo_wave(rowptr, col, dis, ts, te, t, lcol, slots, recs + t, info, is, lane);
+  tile_halo_wave(csr, dis, ts, te, t, lcol, slots, recs + t, info, is, lane);
 }
 
 // Size-sorted tile list for small tile counts (a molecule batch has a few hundred tiles): ONE

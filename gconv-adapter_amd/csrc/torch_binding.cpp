@@ -226,12 +226,23 @@ struct ParamPack {
 std::mutex g_pack_mu;
 std::unordered_map<int64_t, std::shared_ptr<ParamPack>> g_packs;
 int64_t g_next_pack = 1;
-std::unordered_map<c10::TensorImpl*, at::Tensor> g_sinks;   // parameter -> its gradient sink (guarded by g_pack_mu)
+// parameter -> its gradient sink (guarded by g_pack_mu). The key is the parameter's TensorImpl; the
+// entry holds a WEAK reference to it: while the entry lives the address cannot be recycled for
+// another tensor, and an entry whose parameter has died is dropped the next time the table is touched.
+struct SinkEntry {
+  c10::weak_intrusive_ptr<c10::TensorImpl> owner;
+  at::Tensor dest;
+};
+std::unordered_map<c10::TensorImpl*, SinkEntry> g_sinks;
+void prune_sinks_locked() {
+  for (auto it = g_sinks.begin(); it != g_sinks.end();)
+    it = it->second.owner.expired() ? g_sinks.erase(it) : std::next(it);
+}
 
 // Registers (or, with no destination, removes) the gradient sink of a parameter: a float tensor of
 // the parameter's shape, 16-byte aligned, that the caller keeps alive and does not write during a
 // backward pass. Used by dist.FlatGradBucket / FusedAdam.
-void set_grad_sink(at::Tensor param, c10::optional<at::Tensor> dest) {
+void set_grad_sink(at::Tensor param, c10::optional<at::Tensor> dest, c10::optional<at::Tensor> only_if) {
   TORCH_CHECK(param.defined(), "set_grad_sink: undefined parameter");
   at::Tensor d = dest.value_or(at::Tensor());
   if (d.defined()) {
@@ -240,8 +251,15 @@ void set_grad_sink(at::Tensor param, c10::optional<at::Tensor> dest) {
                 "set_grad_sink: the sink must be a contiguous, 16-byte aligned fp32 HIP tensor of the parameter's shape");
   }
   std::lock_guard<std::mutex> lk(g_pack_mu);
-  if (d.defined()) g_sinks[param.unsafeGetTensorImpl()] = d;
-  else g_sinks.erase(param.unsafeGetTensorImpl());
+  prune_sinks_locked();
+  if (!d.defined() && only_if.has_value()) {   // remove only the registration of this owner
+    const auto it = g_sinks.find(param.unsafeGetTensorImpl());
+    if (it == g_sinks.end() || it->second.dest.data_ptr() != only_if->data_ptr()) return;
+  }
+  g_sinks.erase(param.unsafeGetTensorImpl());
+  if (d.defined())
+    g_sinks.emplace(param.unsafeGetTensorImpl(),
+                    SinkEntry{c10::weak_intrusive_ptr<c10::TensorImpl>(param.getIntrusivePtr()), d});
   for (auto& kv : g_packs)
     for (int i = 0; i < 5; ++i)
       if (kv.second->param(i).defined() && kv.second->param(i).unsafeGetTensorImpl() == param.unsafeGetTensorImpl())
@@ -257,10 +275,11 @@ int64_t pack_create(at::Tensor w_down, c10::optional<at::Tensor> b_down, at::Ten
   pk->b_up = b_up.value_or(at::Tensor());
   pk->scalar = scalar.value_or(at::Tensor());
   std::lock_guard<std::mutex> lk(g_pack_mu);
+  prune_sinks_locked();
   for (int i = 0; i < 5; ++i) {
     if (!pk->param(i).defined()) continue;
     const auto it = g_sinks.find(pk->param(i).unsafeGetTensorImpl());
-    if (it != g_sinks.end()) pk->sink[i] = it->second;
+    if (it != g_sinks.end()) pk->sink[i] = it->second.dest;
   }
   g_packs[g_next_pack] = pk;
   return g_next_pack++;
@@ -473,7 +492,7 @@ struct AdapterFnDirect : public torch::autograd::Function<AdapterFnDirect> {
       std::lock_guard<std::mutex> lk(st->mu);
       for (int i = 0; i < 5; ++i) {
         const at::Tensor& prm = pk->param(i);
-        if (!want[i] || !pk->sink[i].defined() || prm.grad().defined()) continue;
+        if (!want[i] || !pk->sink[i].defined() || prm.grad().defined() || pk->sink[i].sizes() != prm.sizes()) continue;
         auto* impl = prm.unsafeGetTensorImpl();
         if (std::find(st->sunk.begin(), st->sunk.end(), impl) != st->sunk.end()) continue;   // second use this pass
         st->sunk.push_back(impl);
@@ -754,7 +773,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("adapter_apply_direct", &adapter_apply_direct);
   m.def("pack_create", &pack_create);
   m.def("pack_release", &pack_release);
-  m.def("set_grad_sink", &set_grad_sink);
+  m.def("set_grad_sink", &set_grad_sink, pybind11::arg("param"), pybind11::arg("dest"),
+        pybind11::arg("only_if") = c10::optional<at::Tensor>());
   m.def("plan_submit", &plan_submit);
   m.def("plan_take", &plan_take);
   m.def("layer_norm_scale", &layer_norm_scale);

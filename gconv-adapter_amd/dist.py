@@ -107,9 +107,15 @@ class FlatGradBucket:
         from . import _torch_ext
         ext = _torch_ext.get()
         if self.sinks and ext is not None:
-            for p in self.params:
-                ext.set_grad_sink(p, None)
+            for p, v in zip(self.params, self.views):
+                ext.set_grad_sink(p, None, v)      # (only if the registered sink is still this bucket's)
         self.sinks = False
+
+    def __del__(self):
+        try:
+            self.detach_sinks()
+        except Exception:   # interpreter shutdown
+            pass
 
     def bind(self) -> None:
         """Makes every ``p.grad`` a view into the flat buffer (autograd then accumulates in

@@ -21,6 +21,7 @@ The MLP (two dense GEMMs) stays ``nn.Linear``: plain library GEMMs belong to roc
 """
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 from typing import Optional
 
@@ -122,6 +123,73 @@ class GinAggregateFunction(torch.autograd.Function):
         return gx, gt, gd, None, None
 
 
+#: A/B knob: ``GCONV_TORCH_MLP=1`` keeps the layer's MLP on ``nn.Linear`` (library fp32 GEMMs)
+TORCH_MLP = bool(os.environ.get("GCONV_TORCH_MLP"))
+
+
+class _SplitWeights:
+    """The three bf16 images of a frozen weight (``gconv_mlp_split_weights_bf16x3``), rebuilt when the
+    parameter's storage or version changes (``load_state_dict``, ``.to()``, an optimizer step on an
+    unfrozen backbone)."""
+
+    def __init__(self):
+        self.key, self.buf, self.shape = None, None, None
+
+    def get(self, w: torch.Tensor, transpose: bool) -> torch.Tensor:
+        key = (w.data_ptr(), w._version, w.device, tuple(w.shape), transpose)
+        if key != self.key:
+            lib = _lib.load()
+            rows, cols = w.shape
+            m, k = (cols, rows) if transpose else (rows, cols)
+            buf = torch.empty(int(lib.gconv_mlp_split_bytes(m, k)), dtype=torch.uint8, device=w.device)
+            wc = w.detach().contiguous()
+            _lib.check(lib.gconv_mlp_split_weights_bf16x3(wc.data_ptr(), rows, cols, int(transpose),
+                                                          buf.data_ptr(), _stream(w.device.index)), "mlp_split_weights")
+            self.key, self.buf, self.shape = key, buf, (m, k)
+        return self.buf
+
+
+def _mlp_gemm(a: torch.Tensor, w_split: torch.Tensor, bias, mask, m: int, epilogue: int) -> torch.Tensor:
+    lib = _lib.load()
+    n, k = a.shape
+    out = torch.empty(n, m, dtype=torch.float32, device=a.device)
+    _lib.check(lib.gconv_mlp_gemm_bf16x3_f32(a.data_ptr(), w_split.data_ptr(),
+                                             None if bias is None else bias.data_ptr(),
+                                             None if mask is None else mask.data_ptr(), out.data_ptr(),
+                                             n, k, m, epilogue, _stream(a.device.index)), "mlp_gemm")
+    return out
+
+
+class GinMlpFunction(torch.autograd.Function):
+    """``mlp(agg)`` of the frozen layer (``gin_conv.py:24-28,85``) on the bf16x3 MFMA kernel
+    (``csrc/mlp.hip``): forward = two launches (the ReLU in the first one's epilogue), input
+    gradient = two launches (the ReLU mask in the first one's epilogue). No weight gradients:
+    the function is only used while the MLP's parameters are frozen."""
+
+    @staticmethod
+    def forward(ctx, agg, mod):
+        _require_hip_f32(agg, "agg")
+        agg = agg.contiguous()
+        l1, l2 = mod.mlp[0], mod.mlp[2]
+        sp = mod._mlp_split
+        h = _mlp_gemm(agg, sp[0].get(l1.weight, False), l1.bias, None, l1.out_features, 1)
+        y = _mlp_gemm(h, sp[1].get(l2.weight, False), l2.bias, None, l2.out_features, 0)
+        ctx.mod = mod
+        ctx.save_for_backward(h)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (h,) = ctx.saved_tensors
+        mod = ctx.mod
+        l1, l2 = mod.mlp[0], mod.mlp[2]
+        sp = mod._mlp_split
+        gy = gy.contiguous()
+        gh = _mlp_gemm(gy, sp[2].get(l2.weight, True), None, h, l2.in_features, 2)    # (dY W2) . [H > 0]
+        ga = _mlp_gemm(gh, sp[3].get(l1.weight, True), None, None, l1.in_features, 0)  # dZ1 W1
+        return ga, None
+
+
 class MolecularGINConv(nn.Module):
     """Drop-in for the reference's ``MolecularGINConv`` (module docstring)."""
 
@@ -141,6 +209,16 @@ class MolecularGINConv(nn.Module):
         #: read the skipped-edge counter back after building a batch's code counts (one host
         #: synchronisation per batch) and raise on out-of-range bond attributes
         self.validate_edge_attr = False
+        # the frozen MLP's weights as bf16 triples: W1, W2 (forward), W2^T, W1^T (input gradient)
+        self.__dict__["_mlp_split"] = [_SplitWeights() for _ in range(4)]
+
+    def __getstate__(self):   # (device buffers keyed on the original's parameters: not part of a copy)
+        state = self.__dict__.copy()
+        state["_mlp_split"] = [_SplitWeights() for _ in range(4)]
+        return state
+
+    def _mlp_is_frozen(self) -> bool:
+        return not any(p.requires_grad for p in self.mlp.parameters())
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_attr: torch.Tensor) -> torch.Tensor:
         if not x.is_cuda:
@@ -150,4 +228,8 @@ class MolecularGINConv(nn.Module):
         counts = edge_code_counts(edge_index, edge_attr, n, self.validate_edge_attr)
         agg = GinAggregateFunction.apply(x, self.edge_embedding_type.weight, self.edge_embedding_direction.weight,
                                          plan, counts)
+        # frozen MLP (the adapter recipe, gnn.py:230-241): the bf16x3 MFMA kernel, input gradient only;
+        # a backbone that trains its MLP keeps nn.Linear (weight gradients are torch's business)
+        if self._mlp_is_frozen() and not TORCH_MLP and agg.dtype == torch.float32 and agg.shape[1] % 4 == 0:
+            return GinMlpFunction.apply(agg, self)
         return self.mlp(agg)

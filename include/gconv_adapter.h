@@ -479,6 +479,25 @@ gconv_status_t gconv_batch_norm_bwd_f32(const float* grad_y, const float* x, con
                                         void* workspace, size_t workspace_bytes,
                                         gconv_stream_t stream);
 
+/* ---- next to the path: the frozen GIN layer's MLP -------------------------------
+ * replaces: `self.mlp` = Linear(d, 2d) -> ReLU -> Linear(2d, d) of `MolecularGINConv`
+ * (`src/layers/inductive/gin_conv.py:24-28`, applied in `update`, `:85`), forward and INPUT gradient
+ * (the layer is frozen under the adapter recipe, `src/models/inductive/gnn.py:230-241`).
+ * fp32 operands as sums of three bf16 values, six bf16 MFMA products per fp32 product, fp32
+ * accumulation: fp32-ACCURATE (relative error of a product <= 2^-23), not bit-equal to an fp32 GEMM.
+ *   gconv_mlp_split_weights_bf16x3: W [rows, cols] fp32 (or, `transpose`, its transpose) -> the three
+ *     bf16 images the GEMM reads ([3][roundup(M, 64)][roundup(K, 32)], zero padded; `out` holds
+ *     gconv_mlp_split_bytes(M, K) bytes, 16-byte aligned). Once per frozen weight.
+ *   gconv_mlp_gemm_bf16x3_f32: C [N, M] = epi(A [N, K] . W^T + bias); K a multiple of 4;
+ *     epilogue 0: none, 1: ReLU, 2: multiply by [mask > 0] (mask [N, M]: the ReLU's output). */
+size_t gconv_mlp_split_bytes(int32_t out_features, int32_t in_features);
+gconv_status_t gconv_mlp_split_weights_bf16x3(const float* w, int32_t rows, int32_t cols, int32_t transpose,
+                                              void* out, gconv_stream_t stream);
+gconv_status_t gconv_mlp_gemm_bf16x3_f32(const float* a, const void* w_split, const float* bias,
+                                         const float* mask, float* c, int32_t num_rows,
+                                         int32_t in_features, int32_t out_features, int32_t epilogue,
+                                         gconv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -143,6 +143,43 @@ def test_gin_layer_directed_graphs_with_duplicates_and_loops(dev, n, e, d):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,d", [(1, 8), (130, 64), (777, 300), (13104, 300), (2000, 1024)])
+def test_gin_mlp_bf16x3_is_fp32_accurate(dev, n, d):
+    """The frozen layer's MLP on the bf16x3 MFMA kernel (csrc/mlp.hip: every fp32 operand as three
+    bf16 values, six products per fp32 product, fp32 accumulation) against the fp64 MLP: forward and
+    input gradient within rtol = atol = 1e-5 (atol relative to the tensor's scale, as for every sum
+    of hundreds of O(1) terms here), and no worse than twice the error of torch's fp32 GEMMs on the
+    same data — fp32-accurate, which is the gate for using it (GCONV_TORCH_MLP=1 is the A/B knob)."""
+    gen = torch.Generator().manual_seed(n + d)
+    layer = ga.MolecularGINConv(d).to(dev)
+    for p in layer.parameters():
+        p.requires_grad_(False)
+    a = torch.randn(n, d, generator=gen)
+    g = torch.randn(n, d, generator=gen)
+    w1, b1, w2, b2 = (layer.mlp[0].weight, layer.mlp[0].bias, layer.mlp[2].weight, layer.mlp[2].bias)
+    a64 = a.double().requires_grad_(True)
+    h64 = torch.relu(torch.nn.functional.linear(a64, w1.cpu().double(), b1.cpu().double()))
+    y64 = torch.nn.functional.linear(h64, w2.cpu().double(), b2.cpu().double())
+    y64.backward(g.double())
+    ad = a.to(dev).requires_grad_(True)
+    y = ga.gin.GinMlpFunction.apply(ad, layer)
+    y.backward(g.to(dev))
+    at = a.to(dev).requires_grad_(True)
+    yt = layer.mlp(at)                                   # torch's fp32 GEMMs on the same data
+    yt.backward(g.to(dev))
+    # a hidden unit within 3e-5 of the ReLU kink may switch sides in any fp32 evaluation: leave the
+    # input-gradient rows of such nodes out (see _check)
+    pre = torch.nn.functional.linear(a.double(), w1.cpu().double(), b1.cpu().double())
+    safe = ~(pre.abs() < 3e-5).any(1)
+    for got, ref, want, what in ((y, yt, y64.detach(), "out"), (ad.grad[safe.to(dev)], at.grad[safe.to(dev)],
+                                                                 a64.grad[safe], "d agg")):
+        got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+        assert_close(got, want, what, 1e-5, grad_atol(want))
+        assert (got - want).abs().max() <= 2.0 * (ref - want).abs().max() + 1e-7, what
+    assert torch.equal(ga.gin.GinMlpFunction.apply(ad, layer), y)     # bitwise repeatable
+
+
+@pytest.mark.gpu
 def test_gin_aggregate_alone_is_tight_and_deterministic(dev):
     """Without the MLP the HIP kernel is compared at the adapter's tolerance (1e-5) and bit-for-bit
     against itself; the code counts are exact integers."""

@@ -58,21 +58,23 @@ def tile(rowptr, col, ts, te, dis=None):
         if c < ts or c >= te:
             add(int(c))
     nh1 = len(halo)
-    he = 0
-    for h in range(nh1):
-        a, b = int(rowptr[halo[h]]), int(rowptr[halo[h] + 1])
-        for c in col[a:b]:
-            if c < ts or c >= te:
-                add(int(c))
-        he += b - a
-    if he > HALO_EDGES:
+    rows = [(int(rowptr[h]), int(rowptr[h + 1])) for h in halo[:nh1]]
+    he = sum(b - a for a, b in rows)
+    if he > HALO_EDGES or e1 - e0 > (1 << 14):
         overflow = True
+    else:    # halo2 in (edge position, halo row) order: the halo1 rows are walked side by side
+        for k in range(max([b - a for a, b in rows], default=0)):
+            for a, b in rows:
+                if a + k < b:
+                    c = int(col[a + k])
+                    if c < ts or c >= te:
+                        add(c)
 
     def local(c):
         return c - ts if ts <= c < te else (nt + halo.index(c) if c in halo else -1)
     lcol = np.asarray([local(int(c)) for c in col[e0:e1]], dtype=np.int64)
     hrp, hcol = [0], []
-    for h in range(nh1):
+    for h in range(nh1 if not overflow else 0):
         a, b = int(rowptr[halo[h]]), int(rowptr[halo[h] + 1])
         hcol += [local(int(c)) for c in col[a:b]]
         hrp.append(len(hcol))
@@ -91,14 +93,17 @@ def check_plan(plan, rowptr, col, n, T, slack, transposed=False, dis=None, order
     recs = plan.tiles(transposed).cpu().numpy()
     lcol = plan.tile_lcol(transposed).cpu().numpy()
     halo = plan.tile_halo(transposed).cpu().numpy()
-    want, any_overflow = [], False
+    want, refs, any_overflow = [], [], False
     for t in range(len(tp) - 1):
         rec, wl, wh, whrp, whcol, whdis, ov = tile(rowptr, col, int(tp[t]), int(tp[t + 1]), dis)
         any_overflow |= ov
         rec["slot"] = t
         want.append(rec)
-        if ov:
-            continue
+        refs.append((wl, wh, whrp, whcol, whdis))
+    assert (plan.n_tiles == 0) == any_overflow or n == 0
+    if any_overflow:      # (one tile given up: the builder stops, nothing else is defined)
+        return want
+    for t, (rec, (wl, wh, whrp, whcol, whdis)) in enumerate(zip(want, refs)):
         np.testing.assert_array_equal(lcol[rec["e0"]:rec["e0"] + rec["ne_own"]], wl, err_msg=f"lcol of tile {t}")
         slot = halo[t]
         np.testing.assert_array_equal(slot[:len(wh)], wh, err_msg=f"halo nodes of tile {t}")
@@ -107,9 +112,6 @@ def check_plan(plan, rowptr, col, n, T, slack, transposed=False, dis=None, order
             np.testing.assert_array_equal(slot[HALO_COL:HALO_COL + len(whcol)], whcol, err_msg=f"halo cols of tile {t}")
         if whdis is not None and len(wh):
             np.testing.assert_array_equal(slot[HALO_DIS:HALO_DIS + len(wh)].view(np.float32), whdis)
-    assert (plan.n_tiles == 0) == any_overflow or n == 0
-    if any_overflow:
-        return want
     key = order_by if order_by is not None else want
     if len(want) <= 256:       # one tile per persistent workgroup: node order, not sorted
         order = list(range(len(want)))
