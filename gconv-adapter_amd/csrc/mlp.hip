@@ -10,24 +10,32 @@
 // rounding) and the product as the six cross terms that matter,
 //     a b ~= ah bh + ah bm + am bh + ah bl + al bh + am bm          (dropped: <= 2^-23 |a b|)
 // on v_mfma_f32_16x16x32_bf16 — 16x the fp32 MFMA rate per product, so 6 products cost 3/8 of one
-// fp32 product — accumulated in fp32. The weights are frozen: they are split ONCE
-// (gconv_mlp_split_weights_bf16x3); the activations are split on the fly while a tile goes from
-// global memory to LDS (eight VALU operations per element, amortised over the 64 output columns of
-// the tile). fp32-accurate, not fp32-exact: the layer's parity bar (1e-5 against the fp64
-// restatement, tests/test_gin.py) is the gate, `GCONV_TORCH_MLP=1` the A/B knob.
+// fp32 product — accumulated in fp32. fp32-accurate, not fp32-exact: the layer's parity bar
+// (1e-5 against the fp64 restatement, tests/test_gin.py) is the gate, `GCONV_TORCH_MLP=1` the knob.
 //
-// One kernel, four uses per layer:
-//   forward   H  = relu(A W1^T + b1)         A [N, d],  W1 [2d, d]
-//             Y  = H W2^T + b2               H [N, 2d], W2 [d, 2d]
-//   backward  dH = (dY W2) . [H > 0]         "weights" = W2^T, mask = H
-//             dA = dH W1                     "weights" = W1^T
+// Splitting is done ONCE per value, never inside a GEMM's inner loop (the first version split the
+// activation tile while staging it — ten VALU operations per element and k-step, repeated by every
+// column tile):
+//   weights  gconv_mlp_split_weights_bf16x3, once per frozen weight
+//   inputs   gconv_mlp_split_rows_bf16x3: one pass over agg (forward) / dY (backward)
+//   hidden   the first GEMM of each direction WRITES its output as a bf16 triple (epilogue: bias +
+//            ReLU, resp. the ReLU mask read off the saved triple's hi image) — the hidden
+//            activation never exists in fp32.
+//   forward   H3 = split(relu(A3 W1^T + b1)) ;  Y  = H3 W2^T + b2
+//   backward  G3 = split((dY3 W2) . [H > 0]) ;  dA = G3 W1
 //
-// Tiling: a workgroup (4 waves) computes 128 rows x 64 columns; a wave owns 32 rows x 64 columns
-// (2 x 4 accumulator tiles of 16 x 16). Per k-step of 32: the A tile (128 x 32 fp32) is split and
-// parked in LDS as three bf16 images, the three weight images (64 x 32 bf16 each) are copied;
-// rows are padded to 80 bytes so that the 16-byte fragment reads of 16 consecutive rows hit 16
-// different bank groups. The next k-step's global loads are in flight while the current one is
-// multiplied.
+// One GEMM kernel: a workgroup (4 waves) computes 128 nodes x 80 features; a wave owns 32 nodes x
+// 80 features (2 x 5 accumulator tiles). The MFMA's row operand is the WEIGHT fragment, its column
+// operand the activation fragment: a lane then holds 4 consecutive features of one node — one
+// 16-byte fp32 store, or one 8-byte store per bf16 image. Per k-step of 32 the six images (3 x 128
+// x 32 and 3 x 80 x 32 bf16) go from global memory to LDS through registers, the next k-step's
+// requests in flight under the MFMAs (barriers wait for LDS traffic only); rows are padded to 80
+// bytes so that the 16-byte fragment reads of 16 consecutive rows hit 16 different bank groups.
+// Measured on a 512-molecule batch (tools/lab/mlp_bench.py, forward + input gradient of one layer):
+// library GEMMs 321-326 us; split while staging 239; split once 266-275 (each node tile's images
+// were re-read by 8 column tiles on 8 different XCDs: 324 MB per GEMM past L2 at 4.4 TB/s);
+// XCD-aware tile order 226; a second k-step of look-ahead 239 (190 VGPRs: two workgroups per CU
+// instead of three) — reverted; 160-feature tiles 234-249.
 #include "common.h"
 
 namespace gconv {
@@ -37,9 +45,18 @@ namespace {
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kBM = 128, kBN = 64, kBK = 32;
+constexpr int kBM = 128;                        // nodes per workgroup
+#ifndef GCONV_MLP_BN
+#define GCONV_MLP_BN 80
+#endif
+constexpr int kBN = GCONV_MLP_BN, kNT = kBN / 16;   // features per workgroup, feature tiles
+constexpr int kBK = 32;
 constexpr int kRowB = 80;                       // bytes per LDS row: 32 bf16 + 16 bytes of padding
 constexpr int kAImg = kBM * kRowB, kBImg = kBN * kRowB;
+constexpr int kThreads = 256;
+constexpr int kAPieces = 3 * kBM * 4, kBPieces = 3 * kBN * 4;   // 16-byte pieces per k-step
+constexpr int kALoads = kAPieces / kThreads, kBLoads = (kBPieces + kThreads - 1) / kThreads;
+static_assert(kAPieces % kThreads == 0, "A staging: whole rounds of the workgroup");
 
 __device__ __forceinline__ unsigned short bf16_rn(float x) {   // round to nearest even (v_cvt_pk_bf16_f32)
   const __bf16 b = static_cast<__bf16>(x);
@@ -69,9 +86,15 @@ __device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
 
 }  // namespace
 
-// W [rows, cols] fp32 (or its transpose) -> three bf16 images [3][Mp][Kp], Mp = roundup(M, 64),
-// Kp = roundup(K, 32), zero padded; (M, K) = (rows, cols), or (cols, rows) when transposed.
-__global__ void mlp_split_weights_kernel(const float* __restrict__ w, int rows, int cols, int transpose,
+// padded sizes: K (the contraction) to a multiple of 32; feature counts to a multiple of the
+// feature tile that also covers the 32-padding a bf16-triple OUTPUT needs as the next GEMM's contraction
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static inline int pad_k(int k) { return round_up(k, kBK); }
+static inline int pad_m(int m) { return round_up(pad_k(m), kBN); }
+
+// W [rows, cols] fp32 (or its transpose) -> three bf16 images [3][Mp][Kp], zero padded;
+// (M, K) = (rows, cols), or (cols, rows) when transposed.
+__global__ void mlp_split_weights_kernel(const float* __restrict__ w, int cols, int transpose,
                                          int M, int K, int Mp, int Kp, unsigned short* __restrict__ out) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= Mp * Kp) return;
@@ -84,65 +107,88 @@ __global__ void mlp_split_weights_kernel(const float* __restrict__ w, int rows, 
   out[idx] = hi;
   out[img + idx] = mid;
   out[2 * img + idx] = lo;
-  (void)rows;
 }
 
-// EPI: 0 none, 1 relu, 2 multiply by [mask > 0]
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void mlp_gemm_bf16x3_kernel(const float* __restrict__ A,
-                                                                 const unsigned short* __restrict__ W,
-                                                                 const float* __restrict__ bias,
-                                                                 const float* __restrict__ mask,
-                                                                 float* __restrict__ C, int N, int K, int M,
-                                                                 int Mp, int Kp) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* la = smem;                      // [3][kBM][kRowB]
-  char* lb = smem + 3 * kAImg;          // [3][kBN][kRowB]
-  const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
-  const int row0 = blockIdx.x * kBM, col0 = blockIdx.y * kBN;
-  const size_t wimg = static_cast<size_t>(Mp) * Kp;
+// X [N, K] fp32 -> three bf16 images [3][N][Kp] (columns K .. Kp zero); 4 values per thread
+__global__ void mlp_split_rows_kernel(const float* __restrict__ x, int N, int K, int Kp,
+                                      unsigned short* __restrict__ out) {
+  const int q = Kp / 4;
+  const size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= static_cast<size_t>(N) * q) return;
+  const int r = static_cast<int>(idx / q), k = 4 * static_cast<int>(idx % q);
+  const f32x4 v = k < K ? ldg4(x + static_cast<size_t>(r) * K + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x4 h, m, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    unsigned short hi, mid, lo;
+    split3(v[e], hi, mid, lo);
+    h[e] = static_cast<short>(hi); m[e] = static_cast<short>(mid); l[e] = static_cast<short>(lo);
+  }
+  const size_t img = static_cast<size_t>(N) * Kp, o = static_cast<size_t>(r) * Kp + k;
+  *reinterpret_cast<bf16x4*>(out + o) = h;
+  *reinterpret_cast<bf16x4*>(out + img + o) = m;
+  *reinterpret_cast<bf16x4*>(out + 2 * img + o) = l;
+}
 
-  // staging roles: A tile = 128 rows x 8 float4 -> thread (r = tid / 8 + 32 j, q = tid % 8), j = 0..3;
-  // weight tile = 64 rows x 4 x 16 bytes per image -> thread (r = tid / 4, q = tid % 4), 3 images
-  const int ar = tid >> 3, aq = tid & 7;
-  const int br = tid >> 2, bq = tid & 3;
-  f32x4 av[4];
-  bf16x8 bv[3];
+// C = epi(A W^T + bias).  A3: [3][N][Kp] bf16 images, W3: [3][Mp][Kp].
+//   OUT_SPLIT false: C fp32 [N, M].   true: C as bf16 images [3][N][Mq], Mq = pad_k(M) (columns M .. Mq zero)
+//   EPI 0: none, 1: ReLU, 2: multiply by [mask_hi > 0] (mask_hi: the hi image of a ReLU output, [N][Mq])
+template <int EPI, bool OUT_SPLIT>
+__global__ __launch_bounds__(kThreads, 2) void mlp_gemm_bf16x3_kernel(const unsigned short* __restrict__ A3,
+                                                                      const unsigned short* __restrict__ W3,
+                                                                      const float* __restrict__ bias,
+                                                                      const unsigned short* __restrict__ mask_hi,
+                                                                      float* __restrict__ C,
+                                                                      unsigned short* __restrict__ C3, int N,
+                                                                      int Kp, int M, int Mp, int Mq) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* la = smem;                      // [3][kBM][kRowB]  activations
+  char* lb = smem + 3 * kAImg;          // [3][kBN][kRowB]  weights
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
+  // XCD-aware tile order. Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share
+  // an L2): the column tiles of ONE node tile are given to consecutive workgroups of ONE XCD, so the
+  // node tile's images are fetched into that L2 once and re-read from it by the other column tiles.
+  // Placement is a speed matter only: any dispatch order computes the same tiles.
+  const int ncol = Mp / kBN;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int rt = (slot / ncol) * 8 + xcd;               // node tile
+  if (rt * kBM >= N) return;                            // (grid rounded up to 8 node tiles per group)
+  const int row0 = rt * kBM, col0 = (slot % ncol) * kBN;
+  const size_t aimg = static_cast<size_t>(N) * Kp, wimg = static_cast<size_t>(Mp) * Kp;
+
+  // staging: piece p of a k-step = (image s, row r, 16-byte quarter q) of the tile
+  bf16x8 av[kALoads], bv[kBLoads];
   auto load_tiles = [&](int k0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = row0 + ar + 32 * j, k = k0 + 4 * aq;
-      // (K is a multiple of 4: a float4 is inside the row or outside it)
-      av[j] = (r < N && k < K) ? ldg4(A + static_cast<size_t>(r) * K + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < kALoads; ++j) {
+      const int p = tid + j * kThreads, s = p / (kBM * 4), r = (p / 4) % kBM, q = p & 3;
+      const int row = min(row0 + r, N - 1);   // (rows past N: a valid row, its products are never stored)
+      av[j] = *reinterpret_cast<const bf16x8*>(A3 + s * aimg + static_cast<size_t>(row) * Kp + k0 + 8 * q);
     }
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
-      bv[s] = *reinterpret_cast<const bf16x8*>(W + s * wimg + static_cast<size_t>(col0 + br) * Kp + k0 + 8 * bq);
+    for (int j = 0; j < kBLoads; ++j) {
+      const int p = min(tid + j * kThreads, kBPieces - 1), s = p / (kBN * 4), r = (p / 4) % kBN, q = p & 3;
+      bv[j] = *reinterpret_cast<const bf16x8*>(W3 + s * wimg + static_cast<size_t>(col0 + r) * Kp + k0 + 8 * q);
+    }
   };
   auto park_tiles = [&]() {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      bf16x4 h, m, l;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        unsigned short hi, mid, lo;
-        split3(av[j][e], hi, mid, lo);
-        h[e] = static_cast<short>(hi); m[e] = static_cast<short>(mid); l[e] = static_cast<short>(lo);
-      }
-      const int off = (ar + 32 * j) * kRowB + 8 * aq;
-      *reinterpret_cast<bf16x4*>(la + off) = h;
-      *reinterpret_cast<bf16x4*>(la + kAImg + off) = m;
-      *reinterpret_cast<bf16x4*>(la + 2 * kAImg + off) = l;
+    for (int j = 0; j < kALoads; ++j) {
+      const int p = tid + j * kThreads, s = p / (kBM * 4), r = (p / 4) % kBM, q = p & 3;
+      *reinterpret_cast<bf16x8*>(la + s * kAImg + r * kRowB + 16 * q) = av[j];
     }
 #pragma unroll
-    for (int s = 0; s < 3; ++s) *reinterpret_cast<bf16x8*>(lb + s * kBImg + br * kRowB + 16 * bq) = bv[s];
+    for (int j = 0; j < kBLoads; ++j) {
+      const int p = tid + j * kThreads, s = p / (kBN * 4), r = (p / 4) % kBN, q = p & 3;
+      if (p < kBPieces) *reinterpret_cast<bf16x8*>(lb + s * kBImg + r * kRowB + 16 * q) = bv[j];
+    }
   };
 
-  f32x4 acc[2][4];
+  f32x4 acc[2][kNT];     // [node tile][feature tile]: D[i = feature][j = node]
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < kNT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // fragment addresses: lane l reads row (l & 15), k-group (l >> 4) of a 16 x 32 image slice
   const int frow = lane & 15, fk = lane >> 4;
@@ -153,49 +199,85 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_bf16x3_kernel(const float* __
   for (int k0 = 0; k0 < Kp; k0 += kBK) {
     park_tiles();
     lds_only_barrier();
-    if (k0 + kBK < Kp) load_tiles(k0 + kBK);   // in flight during the MFMAs below (and across the barrier)
+    load_tiles(min(k0 + kBK, Kp - kBK));   // in flight under the MFMAs below (the last one re-reads its own step)
     bf16x8 af[2][3];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int s = 0; s < 3; ++s) af[i][s] = *reinterpret_cast<const bf16x8*>(la + s * kAImg + a_off + 16 * i * kRowB);
+    // weight fragments one feature tile ahead of their MFMAs (an LDS read issued right in front of
+    // its first use exposes its latency once per feature tile)
+    bf16x8 wf[3], wn[3];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      bf16x8 bf[3];
+    for (int s = 0; s < 3; ++s) wf[s] = *reinterpret_cast<const bf16x8*>(lb + s * kBImg + b_off);
 #pragma unroll
-      for (int s = 0; s < 3; ++s) bf[s] = *reinterpret_cast<const bf16x8*>(lb + s * kBImg + b_off + 16 * j * kRowB);
+    for (int j = 0; j < kNT; ++j) {
+      if (j + 1 < kNT) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) wn[s] = *reinterpret_cast<const bf16x8*>(lb + s * kBImg + b_off + 16 * (j + 1) * kRowB);
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         // smallest terms first: the accumulator sees them before the dominant product
         f32x4 c = acc[i][j];
-        c = mfma_bf16(af[i][1], bf[1], c);   // mid * mid
-        c = mfma_bf16(af[i][2], bf[0], c);   // lo  * hi
-        c = mfma_bf16(af[i][0], bf[2], c);   // hi  * lo
-        c = mfma_bf16(af[i][1], bf[0], c);   // mid * hi
-        c = mfma_bf16(af[i][0], bf[1], c);   // hi  * mid
-        c = mfma_bf16(af[i][0], bf[0], c);   // hi  * hi
+        c = mfma_bf16(wf[1], af[i][1], c);   // mid * mid
+        c = mfma_bf16(wf[0], af[i][2], c);   // W hi  * A lo
+        c = mfma_bf16(wf[2], af[i][0], c);   // W lo  * A hi
+        c = mfma_bf16(wf[0], af[i][1], c);   // W hi  * A mid
+        c = mfma_bf16(wf[1], af[i][0], c);   // W mid * A hi
+        c = mfma_bf16(wf[0], af[i][0], c);   // hi * hi
         acc[i][j] = c;
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) wf[s] = wn[s];
     }
     lds_only_barrier();   // the images are rewritten by the next step
   }
 
-  // epilogue: C layout of the 16 x 16 tile: column = lane & 15, row = 4 (lane >> 4) + reg
+  // epilogue: lane l holds features f0 .. f0 + 3 (f0 = col0 + 16 j + 4 (l >> 4)) of node row0 + 32 wave + 16 i + (l & 15)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c = col0 + 16 * j + (lane & 15);
-    const float bc = (bias && c < M) ? bias[c] : 0.f;
+  for (int j = 0; j < kNT; ++j) {
+    const int f0 = col0 + 16 * j + 4 * (lane >> 4);
+    f32x4 bc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) bc[v] = f0 + v < M ? bias[f0 + v] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      const int r = row0 + 32 * wave + 16 * i + (lane & 15);
+      if (r >= N) continue;
+      f32x4 y = acc[i][j] + bc;
+      if (EPI == 1) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int r = row0 + 32 * wave + 16 * i + 4 * (lane >> 4) + v;
-        if (r < N && c < M) {
-          float y = acc[i][j][v] + bc;
-          if (EPI == 1) y = y > 0.f ? y : 0.f;
-          if (EPI == 2) y = mask[static_cast<size_t>(r) * M + c] > 0.f ? y : 0.f;
-          C[static_cast<size_t>(r) * M + c] = y;
+        for (int v = 0; v < 4; ++v) y[v] = y[v] > 0.f ? y[v] : 0.f;
+      }
+      if (EPI == 2 && f0 < Mq) {
+        const bf16x4 mk = *reinterpret_cast<const bf16x4*>(mask_hi + static_cast<size_t>(r) * Mq + f0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) y[v] = mk[v] > 0 ? y[v] : 0.f;   // (bf16 bits as int16: > 0 <=> positive value)
+      }
+      if (!OUT_SPLIT) {
+        if (f0 + 3 < M) {
+          stg4(C + static_cast<size_t>(r) * M + f0, y);
+        } else {
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            if (f0 + v < M) C[static_cast<size_t>(r) * M + f0 + v] = y[v];
         }
+      } else if (f0 < Mq) {   // (Mq is a multiple of 4: the 4 features are inside the padded row or outside it)
+        bf16x4 h, m, l;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          unsigned short hi, mid, lo;
+          split3(f0 + v < M ? y[v] : 0.f, hi, mid, lo);
+          h[v] = static_cast<short>(hi); m[v] = static_cast<short>(mid); l[v] = static_cast<short>(lo);
+        }
+        const size_t img = static_cast<size_t>(N) * Mq, o = static_cast<size_t>(r) * Mq + f0;
+        *reinterpret_cast<bf16x4*>(C3 + o) = h;
+        *reinterpret_cast<bf16x4*>(C3 + img + o) = m;
+        *reinterpret_cast<bf16x4*>(C3 + 2 * img + o) = l;
       }
     }
   }
@@ -205,11 +287,14 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_bf16x3_kernel(const float* __
 
 using namespace gconv;
 
-static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
-
 extern "C" size_t gconv_mlp_split_bytes(int32_t out_features, int32_t in_features) {
   if (out_features <= 0 || in_features <= 0) return 0;
-  return static_cast<size_t>(3) * round_up(out_features, kBN) * round_up(in_features, kBK) * sizeof(unsigned short);
+  return static_cast<size_t>(3) * pad_m(out_features) * pad_k(in_features) * sizeof(unsigned short);
+}
+
+extern "C" size_t gconv_mlp_rows_split_bytes(int32_t num_rows, int32_t features) {
+  if (num_rows < 0 || features <= 0) return 0;
+  return static_cast<size_t>(3) * (num_rows > 0 ? num_rows : 1) * pad_k(features) * sizeof(unsigned short);
 }
 
 extern "C" gconv_status_t gconv_mlp_split_weights_bf16x3(const float* w, int32_t rows, int32_t cols,
@@ -217,36 +302,72 @@ extern "C" gconv_status_t gconv_mlp_split_weights_bf16x3(const float* w, int32_t
                                                          gconv_stream_t stream_) {
   if (!w || !out || rows <= 0 || cols <= 0) return GCONV_E_INVALID_ARG;
   const int M = transpose ? cols : rows, K = transpose ? rows : cols;
-  const int Mp = round_up(M, kBN), Kp = round_up(K, kBK);
+  const int Mp = pad_m(M), Kp = pad_k(K);
   const int total = Mp * Kp;
   mlp_split_weights_kernel<<<(total + 255) / 256, 256, 0, static_cast<hipStream_t>(stream_)>>>(
-      w, rows, cols, transpose ? 1 : 0, M, K, Mp, Kp, static_cast<unsigned short*>(out));
+      w, cols, transpose ? 1 : 0, M, K, Mp, Kp, static_cast<unsigned short*>(out));
   GCONV_LAUNCH_CHECK();
   return GCONV_OK;
 }
 
-extern "C" gconv_status_t gconv_mlp_gemm_bf16x3_f32(const float* a, const void* w_split, const float* bias,
-                                                    const float* mask, float* c, int32_t num_rows,
-                                                    int32_t in_features, int32_t out_features,
-                                                    int32_t epilogue, gconv_stream_t stream_) {
-  if (!a || !w_split || !c || num_rows < 0 || in_features <= 0 || out_features <= 0) return GCONV_E_INVALID_ARG;
-  if (epilogue < 0 || epilogue > 2 || (epilogue == 2 && !mask)) return GCONV_E_INVALID_ARG;
-  if (in_features % 4 != 0) return GCONV_E_UNSUPPORTED;
-  if (!aligned16(a) || !aligned16(w_split)) return GCONV_E_ALIGNMENT;
+extern "C" gconv_status_t gconv_mlp_split_rows_bf16x3(const float* x, int32_t num_rows, int32_t features,
+                                                      void* out, gconv_stream_t stream_) {
+  if (!x || !out || num_rows < 0 || features <= 0) return GCONV_E_INVALID_ARG;
+  if (features % 4 != 0) return GCONV_E_UNSUPPORTED;
+  if (!aligned16(x) || !aligned16(out)) return GCONV_E_ALIGNMENT;
   if (num_rows == 0) return GCONV_OK;
-  const int Mp = round_up(out_features, kBN), Kp = round_up(in_features, kBK);
-  const dim3 grid((num_rows + kBM - 1) / kBM, Mp / kBN);
+  const int Kp = pad_k(features);
+  const size_t total = static_cast<size_t>(num_rows) * (Kp / 4);
+  mlp_split_rows_kernel<<<static_cast<unsigned>((total + 255) / 256), 256, 0, static_cast<hipStream_t>(stream_)>>>(
+      x, num_rows, features, Kp, static_cast<unsigned short*>(out));
+  GCONV_LAUNCH_CHECK();
+  return GCONV_OK;
+}
+
+extern "C" gconv_status_t gconv_mlp_gemm_bf16x3(const void* a_split, const void* w_split, const float* bias,
+                                                const void* mask_split, float* c_f32, void* c_split,
+                                                int32_t num_rows, int32_t in_features, int32_t out_features,
+                                                int32_t epilogue, gconv_stream_t stream_) {
+  if (!a_split || !w_split || num_rows < 0 || in_features <= 0 || out_features <= 0) return GCONV_E_INVALID_ARG;
+  if (epilogue < 0 || epilogue > 2 || (epilogue == 2 && !mask_split)) return GCONV_E_INVALID_ARG;
+  if ((c_f32 == nullptr) == (c_split == nullptr)) return GCONV_E_INVALID_ARG;   // exactly one output form
+  if (!aligned16(a_split) || !aligned16(w_split) || (c_f32 && !aligned16(c_f32)) || (c_split && !aligned16(c_split)) ||
+      (mask_split && !aligned16(mask_split)))
+    return GCONV_E_ALIGNMENT;
+  if (c_f32 && out_features % 4 != 0) return GCONV_E_UNSUPPORTED;
+  if (num_rows == 0) return GCONV_OK;
+  const int Kp = pad_k(in_features), Mp = pad_m(out_features), Mq = pad_k(out_features);
+  const int row_tiles = (num_rows + kBM - 1) / kBM;
+  const dim3 grid(((row_tiles + 7) / 8) * (Mp / kBN) * 8);   // 1-D: the kernel maps it to tiles XCD-aware
   const size_t lds = 3 * (kAImg + kBImg);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const unsigned short* a = static_cast<const unsigned short*>(a_split);
   const unsigned short* w = static_cast<const unsigned short*>(w_split);
-  static_assert(3 * (kAImg + kBImg) <= 48 * 1024, "dynamic LDS above 48 KB needs the opt-in attribute");
-#define GCONV_MLP_LAUNCH(EPI_)                                                                                   \
-  mlp_gemm_bf16x3_kernel<EPI_><<<grid, 256, lds, stream>>>(a, w, bias, mask, c, num_rows, in_features,           \
-                                                           out_features, Mp, Kp)
-  switch (epilogue) {
-    case 0: GCONV_MLP_LAUNCH(0); break;
-    case 1: GCONV_MLP_LAUNCH(1); break;
-    default: GCONV_MLP_LAUNCH(2); break;
+  const unsigned short* mk = static_cast<const unsigned short*>(mask_split);
+  unsigned short* c3 = static_cast<unsigned short*>(c_split);
+#define GCONV_MLP_LAUNCH(EPI_, SPLIT_)                                                                             \
+  do {                                                                                                             \
+    static bool opted_in = false; /* (49.9 KB of dynamic LDS: above the 48 KB default, once per kernel) */         \
+    if (!opted_in) {                                                                                               \
+      GCONV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_gemm_bf16x3_kernel<EPI_, SPLIT_>),          \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));           \
+      opted_in = true;                                                                                             \
+    }                                                                                                              \
+    mlp_gemm_bf16x3_kernel<EPI_, SPLIT_><<<grid, kThreads, lds, stream>>>(a, w, bias, mk, c_f32, c3, num_rows, Kp, \
+                                                                         out_features, Mp, Mq);                    \
+  } while (0)
+  if (c_split) {
+    switch (epilogue) {
+      case 0: GCONV_MLP_LAUNCH(0, true); break;
+      case 1: GCONV_MLP_LAUNCH(1, true); break;
+      default: GCONV_MLP_LAUNCH(2, true); break;
+    }
+  } else {
+    switch (epilogue) {
+      case 0: GCONV_MLP_LAUNCH(0, false); break;
+      case 1: GCONV_MLP_LAUNCH(1, false); break;
+      default: GCONV_MLP_LAUNCH(2, false); break;
+    }
   }
 #undef GCONV_MLP_LAUNCH
   GCONV_LAUNCH_CHECK();

@@ -149,44 +149,64 @@ class _SplitWeights:
         return self.buf
 
 
-def _mlp_gemm(a: torch.Tensor, w_split: torch.Tensor, bias, mask, m: int, epilogue: int) -> torch.Tensor:
+def _split_rows(x: torch.Tensor) -> torch.Tensor:
+    """The bf16 triple of a [N, F] fp32 matrix (``gconv_mlp_split_rows_bf16x3``)."""
     lib = _lib.load()
-    n, k = a.shape
-    out = torch.empty(n, m, dtype=torch.float32, device=a.device)
-    _lib.check(lib.gconv_mlp_gemm_bf16x3_f32(a.data_ptr(), w_split.data_ptr(),
-                                             None if bias is None else bias.data_ptr(),
-                                             None if mask is None else mask.data_ptr(), out.data_ptr(),
-                                             n, k, m, epilogue, _stream(a.device.index)), "mlp_gemm")
+    n, f = x.shape
+    out = torch.empty(int(lib.gconv_mlp_rows_split_bytes(n, f)), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.gconv_mlp_split_rows_bf16x3(x.data_ptr(), n, f, out.data_ptr(), _stream(x.device.index)),
+               "mlp_split_rows")
+    return out
+
+
+def _mlp_gemm(a3: torch.Tensor, n: int, k: int, w3: torch.Tensor, bias, mask3, m: int, epilogue: int,
+              split_out: bool) -> torch.Tensor:
+    """``epi(A W^T + bias)`` on the bf16x3 MFMA kernel; A and W as bf16 triples, the result as fp32
+    ``[n, m]`` or — the hidden activation — as a triple again."""
+    lib = _lib.load()
+    dev = a3.device
+    if split_out:
+        out = torch.empty(int(lib.gconv_mlp_rows_split_bytes(n, m)), dtype=torch.uint8, device=dev)
+    else:
+        out = torch.empty(n, m, dtype=torch.float32, device=dev)
+    _lib.check(lib.gconv_mlp_gemm_bf16x3(a3.data_ptr(), w3.data_ptr(), None if bias is None else bias.data_ptr(),
+                                         None if mask3 is None else mask3.data_ptr(),
+                                         None if split_out else out.data_ptr(), out.data_ptr() if split_out else None,
+                                         n, k, m, epilogue, _stream(dev.index)), "mlp_gemm")
     return out
 
 
 class GinMlpFunction(torch.autograd.Function):
     """``mlp(agg)`` of the frozen layer (``gin_conv.py:24-28,85``) on the bf16x3 MFMA kernel
-    (``csrc/mlp.hip``): forward = two launches (the ReLU in the first one's epilogue), input
-    gradient = two launches (the ReLU mask in the first one's epilogue). No weight gradients:
-    the function is only used while the MLP's parameters are frozen."""
+    (``csrc/mlp.hip``). Forward: split(agg), H = relu(agg W1^T + b1) written as a bf16 triple, Y = H
+    W2^T + b2. Input gradient: split(dY), dH = (dY W2) . [H > 0] as a triple (the mask is read off H's
+    triple), d agg = dH W1. No weight gradients: only used while the MLP's parameters are frozen."""
 
     @staticmethod
     def forward(ctx, agg, mod):
         _require_hip_f32(agg, "agg")
         agg = agg.contiguous()
+        n, d = agg.shape
         l1, l2 = mod.mlp[0], mod.mlp[2]
         sp = mod._mlp_split
-        h = _mlp_gemm(agg, sp[0].get(l1.weight, False), l1.bias, None, l1.out_features, 1)
-        y = _mlp_gemm(h, sp[1].get(l2.weight, False), l2.bias, None, l2.out_features, 0)
+        a3 = _split_rows(agg)
+        h3 = _mlp_gemm(a3, n, d, sp[0].get(l1.weight, False), l1.bias, None, l1.out_features, 1, True)
+        y = _mlp_gemm(h3, n, l1.out_features, sp[1].get(l2.weight, False), l2.bias, None, l2.out_features, 0, False)
         ctx.mod = mod
-        ctx.save_for_backward(h)
+        ctx.save_for_backward(h3)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        (h,) = ctx.saved_tensors
+        (h3,) = ctx.saved_tensors
         mod = ctx.mod
         l1, l2 = mod.mlp[0], mod.mlp[2]
         sp = mod._mlp_split
         gy = gy.contiguous()
-        gh = _mlp_gemm(gy, sp[2].get(l2.weight, True), None, h, l2.in_features, 2)    # (dY W2) . [H > 0]
-        ga = _mlp_gemm(gh, sp[3].get(l1.weight, True), None, None, l1.in_features, 0)  # dZ1 W1
+        n = gy.shape[0]
+        g3 = _split_rows(gy)
+        gh3 = _mlp_gemm(g3, n, l2.out_features, sp[2].get(l2.weight, True), None, h3, l2.in_features, 2, True)
+        ga = _mlp_gemm(gh3, n, l2.in_features, sp[3].get(l1.weight, True), None, None, l1.in_features, 0, False)
         return ga, None
 
 

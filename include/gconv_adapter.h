@@ -485,18 +485,27 @@ gconv_status_t gconv_batch_norm_bwd_f32(const float* grad_y, const float* x, con
  * (the layer is frozen under the adapter recipe, `src/models/inductive/gnn.py:230-241`).
  * fp32 operands as sums of three bf16 values, six bf16 MFMA products per fp32 product, fp32
  * accumulation: fp32-ACCURATE (relative error of a product <= 2^-23), not bit-equal to an fp32 GEMM.
- *   gconv_mlp_split_weights_bf16x3: W [rows, cols] fp32 (or, `transpose`, its transpose) -> the three
- *     bf16 images the GEMM reads ([3][roundup(M, 64)][roundup(K, 32)], zero padded; `out` holds
- *     gconv_mlp_split_bytes(M, K) bytes, 16-byte aligned). Once per frozen weight.
- *   gconv_mlp_gemm_bf16x3_f32: C [N, M] = epi(A [N, K] . W^T + bias); K a multiple of 4;
- *     epilogue 0: none, 1: ReLU, 2: multiply by [mask > 0] (mask [N, M]: the ReLU's output). */
+ * Every value is split ONCE: the frozen weights at load time, the layer input / upstream gradient
+ * by one pass, the hidden activation by the epilogue of the GEMM that produces it (it never exists
+ * in fp32). "bf16 triple" of a [R, F] matrix = three bf16 images [3][R][Fp], Fp = F rounded up to a
+ * multiple of 32, padding columns zero; all triples 16-byte aligned.
+ *   gconv_mlp_split_weights_bf16x3: W [rows, cols] fp32 (or, `transpose`, its transpose) -> its triple
+ *     with the feature rows padded as well ([3][Mp][Kp]; `out` holds gconv_mlp_split_bytes(M, K) bytes).
+ *   gconv_mlp_split_rows_bf16x3: X [N, F] fp32 -> its triple (gconv_mlp_rows_split_bytes(N, F) bytes).
+ *   gconv_mlp_gemm_bf16x3: C [N, M] = epi(A . W^T + bias), A a row triple, W a weight triple;
+ *     exactly one of c_f32 ([N, M] fp32, M a multiple of 4) / c_split (the triple of C) is non-NULL;
+ *     epilogue 0: none, 1: ReLU, 2: multiply by [mask > 0], `mask_split` = the triple of a ReLU
+ *     output of C's shape (its first image is read). */
 size_t gconv_mlp_split_bytes(int32_t out_features, int32_t in_features);
+size_t gconv_mlp_rows_split_bytes(int32_t num_rows, int32_t features);
 gconv_status_t gconv_mlp_split_weights_bf16x3(const float* w, int32_t rows, int32_t cols, int32_t transpose,
                                               void* out, gconv_stream_t stream);
-gconv_status_t gconv_mlp_gemm_bf16x3_f32(const float* a, const void* w_split, const float* bias,
-                                         const float* mask, float* c, int32_t num_rows,
-                                         int32_t in_features, int32_t out_features, int32_t epilogue,
-                                         gconv_stream_t stream);
+gconv_status_t gconv_mlp_split_rows_bf16x3(const float* x, int32_t num_rows, int32_t features, void* out,
+                                           gconv_stream_t stream);
+gconv_status_t gconv_mlp_gemm_bf16x3(const void* a_split, const void* w_split, const float* bias,
+                                     const void* mask_split, float* c_f32, void* c_split, int32_t num_rows,
+                                     int32_t in_features, int32_t out_features, int32_t epilogue,
+                                     gconv_stream_t stream);
 
 #ifdef __cplusplus
 }
