@@ -28,9 +28,8 @@
 // 80 features (2 x 5 accumulator tiles). The MFMA's row operand is the WEIGHT fragment, its column
 // operand the activation fragment: a lane then holds 4 consecutive features of one node — one
 // 16-byte fp32 store, or one 8-byte store per bf16 image. Per k-step of 32 the six images (3 x 128
-// x 32 and 3 x 80 x 32 bf16) go from global memory to LDS through registers, the next k-step's
-// requests in flight under the MFMAs (barriers wait for LDS traffic only); rows are padded to 80
-// bytes so that the 16-byte fragment reads of 16 consecutive rows hit 16 different bank groups.
+// x 32 and 3 x 80 x 32 bf16) go from global memory to LDS by LDS-DMA, double-buffered, XOR-swizzled
+// rows of 64 bytes (see the kernel).
 // Measured on a 512-molecule batch (tools/lab/mlp_bench.py, forward + input gradient of one layer):
 // library GEMMs 321-326 us; split while staging 239; split once 266-275 (each node tile's images
 // were re-read by 8 column tiles on 8 different XCDs: 324 MB per GEMM past L2 at 4.4 TB/s);
@@ -51,12 +50,12 @@ constexpr int kBM = 128;                        // nodes per workgroup
 #endif
 constexpr int kBN = GCONV_MLP_BN, kNT = kBN / 16;   // features per workgroup, feature tiles
 constexpr int kBK = 32;
-constexpr int kRowB = 80;                       // bytes per LDS row: 32 bf16 + 16 bytes of padding
-constexpr int kAImg = kBM * kRowB, kBImg = kBN * kRowB;
 constexpr int kThreads = 256;
-constexpr int kAPieces = 3 * kBM * 4, kBPieces = 3 * kBN * 4;   // 16-byte pieces per k-step
-constexpr int kALoads = kAPieces / kThreads, kBLoads = (kBPieces + kThreads - 1) / kThreads;
-static_assert(kAPieces % kThreads == 0, "A staging: whole rounds of the workgroup");
+// LDS: per buffer the three activation images (kBM rows x 64 B) then the three weight images (kBN
+// rows x 64 B), in 1 KB chunks of 16 rows — what one LDS-DMA wave instruction writes
+constexpr int kAChunks = 3 * kBM / 16, kBChunks = 3 * kBN / 16;
+constexpr int kBufB = (kAChunks + kBChunks) * 1024;
+constexpr int kChunksPerWave = (kAChunks + kBChunks + 3) / 4;
 
 __device__ __forceinline__ unsigned short bf16_rn(float x) {   // round to nearest even (v_cvt_pk_bf16_f32)
   const __bf16 b = static_cast<__bf16>(x);
@@ -78,6 +77,16 @@ __device__ __forceinline__ void split3(float x, unsigned short& hi, unsigned sho
 // NEXT k-step, which are meant to stay in flight across it
 __device__ __forceinline__ void lds_only_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// 16 bytes per lane, global -> LDS without a register in between: lane i's piece lands at dst + 16 i
+// (dst wave-uniform). Counted in vmcnt; visible to other waves after the issuer's wait + a barrier.
+__device__ __forceinline__ void lds_dma16(const void* src, void* dst) {
+  __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) void*>(
+                                       reinterpret_cast<uintptr_t>(src)),
+                                   reinterpret_cast<__attribute__((address_space(3))) void*>(
+                                       static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dst))),
+                                   16, 0, 0);
 }
 
 __device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
@@ -133,6 +142,17 @@ __global__ void mlp_split_rows_kernel(const float* __restrict__ x, int N, int K,
 // C = epi(A W^T + bias).  A3: [3][N][Kp] bf16 images, W3: [3][Mp][Kp].
 //   OUT_SPLIT false: C fp32 [N, M].   true: C as bf16 images [3][N][Mq], Mq = pad_k(M) (columns M .. Mq zero)
 //   EPI 0: none, 1: ReLU, 2: multiply by [mask_hi > 0] (mask_hi: the hi image of a ReLU output, [N][Mq])
+//
+// Staging: the six images of a k-step go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no
+// staging registers, no ds_write instructions), 1 KB = 16 rows x 64 bytes per wave instruction, into
+// one of TWO LDS buffers: the DMA of step k + 1 runs under the MFMAs of step k and ONE barrier per
+// k-step is enough (a buffer is rewritten two steps after it was read). Rows are 64 bytes, not
+// padded: the 16-byte piece q of row r sits in slot q ^ ((4 - (r >> 2)) & 3) of its row, which
+// makes the 16-byte fragment reads of every ds_read_b128 lane group (rows 0-3 / 12-15 at one
+// k-group, rows 4-11 at the next) fall into 16 different bank groups — applied on the SOURCE side:
+// lane i of a DMA instruction always writes LDS slot i, so it fetches the piece that belongs there.
+// (Round-3 lab, tools/lab/prof_mlp.sh: with register staging + ds_write_b128 + 80-byte rows the
+// kernel's skeleton — no global loads, no MFMAs — alone took 30-34 of 48-59 us per GEMM.)
 template <int EPI, bool OUT_SPLIT>
 __global__ __launch_bounds__(kThreads, 2) void mlp_gemm_bf16x3_kernel(const unsigned short* __restrict__ A3,
                                                                       const unsigned short* __restrict__ W3,
@@ -142,8 +162,6 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_gemm_bf16x3_kernel(const unsi
                                                                       unsigned short* __restrict__ C3, int N,
                                                                       int Kp, int M, int Mp, int Mq) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* la = smem;                      // [3][kBM][kRowB]  activations
-  char* lb = smem + 3 * kAImg;          // [3][kBN][kRowB]  weights
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
   // XCD-aware tile order. Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share
   // an L2): the column tiles of ONE node tile are given to consecutive workgroups of ONE XCD, so the
@@ -156,31 +174,25 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_gemm_bf16x3_kernel(const unsi
   const int row0 = rt * kBM, col0 = (slot % ncol) * kBN;
   const size_t aimg = static_cast<size_t>(N) * Kp, wimg = static_cast<size_t>(Mp) * Kp;
 
-  // staging: piece p of a k-step = (image s, row r, 16-byte quarter q) of the tile
-  bf16x8 av[kALoads], bv[kBLoads];
-  auto load_tiles = [&](int k0) {
+  // DMA roles: chunk c of a k-step = 16 rows of one image (c < kAChunks: activations, else weights);
+  // wave w moves the chunks w, w + 4, ...; lane i = (row i >> 2 of the chunk, LDS slot i & 3)
+  const int crow = lane >> 2;
+  const int cq = (lane & 3) ^ ((4 - (crow >> 2)) & 3);   // the piece that belongs in this lane's slot
+  auto dma = [&](int buf, int k0) {
+    char* base = smem + buf * kBufB;
 #pragma unroll
-    for (int j = 0; j < kALoads; ++j) {
-      const int p = tid + j * kThreads, s = p / (kBM * 4), r = (p / 4) % kBM, q = p & 3;
-      const int row = min(row0 + r, N - 1);   // (rows past N: a valid row, its products are never stored)
-      av[j] = *reinterpret_cast<const bf16x8*>(A3 + s * aimg + static_cast<size_t>(row) * Kp + k0 + 8 * q);
-    }
-#pragma unroll
-    for (int j = 0; j < kBLoads; ++j) {
-      const int p = min(tid + j * kThreads, kBPieces - 1), s = p / (kBN * 4), r = (p / 4) % kBN, q = p & 3;
-      bv[j] = *reinterpret_cast<const bf16x8*>(W3 + s * wimg + static_cast<size_t>(col0 + r) * Kp + k0 + 8 * q);
-    }
-  };
-  auto park_tiles = [&]() {
-#pragma unroll
-    for (int j = 0; j < kALoads; ++j) {
-      const int p = tid + j * kThreads, s = p / (kBM * 4), r = (p / 4) % kBM, q = p & 3;
-      *reinterpret_cast<bf16x8*>(la + s * kAImg + r * kRowB + 16 * q) = av[j];
-    }
-#pragma unroll
-    for (int j = 0; j < kBLoads; ++j) {
-      const int p = tid + j * kThreads, s = p / (kBN * 4), r = (p / 4) % kBN, q = p & 3;
-      if (p < kBPieces) *reinterpret_cast<bf16x8*>(lb + s * kBImg + r * kRowB + 16 * q) = bv[j];
+    for (int j = 0; j < kChunksPerWave; ++j) {
+      const int c = wave + 4 * j;
+      if (c < kAChunks) {                     // wave-uniform
+        const int s = c / (kBM / 16), r16 = c % (kBM / 16);
+        const int row = min(row0 + 16 * r16 + crow, N - 1);   // (rows past N: a valid row, never stored)
+        const unsigned short* src = A3 + s * aimg + static_cast<size_t>(row) * Kp + k0 + 8 * cq;
+        lds_dma16(src, base + c * 1024);
+      } else if (c < kAChunks + kBChunks) {
+        const int cb = c - kAChunks, s = cb / (kBN / 16), r16 = cb % (kBN / 16);
+        const unsigned short* src = W3 + s * wimg + static_cast<size_t>(col0 + 16 * r16 + crow) * Kp + k0 + 8 * cq;
+        lds_dma16(src, base + c * 1024);
+      }
     }
   };
 
@@ -190,32 +202,32 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_gemm_bf16x3_kernel(const unsi
 #pragma unroll
     for (int j = 0; j < kNT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // fragment addresses: lane l reads row (l & 15), k-group (l >> 4) of a 16 x 32 image slice
-  const int frow = lane & 15, fk = lane >> 4;
-  const int a_off = (32 * wave + frow) * kRowB + 16 * fk;
-  const int b_off = frow * kRowB + 16 * fk;
+  // fragment addresses: lane l reads row (l & 15), k-group (l >> 4) of a 16-row slice of an image
+  const int frow = lane & 15;
+  const int fslot = (lane >> 4) ^ ((4 - (frow >> 2)) & 3);
+  const int f_off = frow * 64 + 16 * fslot;
+  const int a_off = 2 * wave * 1024 + f_off;            // this wave's 32 nodes = chunks 2 wave, 2 wave + 1 of an image
 
-  load_tiles(0);
-  for (int k0 = 0; k0 < Kp; k0 += kBK) {
-    park_tiles();
-    lds_only_barrier();
-    load_tiles(min(k0 + kBK, Kp - kBK));   // in flight under the MFMAs below (the last one re-reads its own step)
+  dma(0, 0);
+  int buf = 0;
+  for (int k0 = 0; k0 < Kp; k0 += kBK, buf ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of step k0 have landed ...
+    lds_only_barrier();                                  // ... and so have everybody else's; step k0 - 1 is read out
+    if (k0 + kBK < Kp) dma(buf ^ 1, k0 + kBK);           // (wave-uniform) under the MFMAs below
+    const char* la = smem + buf * kBufB;
+    const char* lb = la + kAChunks * 1024;
     bf16x8 af[2][3];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int s = 0; s < 3; ++s) af[i][s] = *reinterpret_cast<const bf16x8*>(la + s * kAImg + a_off + 16 * i * kRowB);
-    // weight fragments one feature tile ahead of their MFMAs (an LDS read issued right in front of
-    // its first use exposes its latency once per feature tile)
-    bf16x8 wf[3], wn[3];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) wf[s] = *reinterpret_cast<const bf16x8*>(lb + s * kBImg + b_off);
+      for (int s = 0; s < 3; ++s)
+        af[i][s] = *reinterpret_cast<const bf16x8*>(la + s * (kBM / 16) * 1024 + a_off + i * 1024);
 #pragma unroll
     for (int j = 0; j < kNT; ++j) {
-      if (j + 1 < kNT) {
+      bf16x8 wf[3];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) wn[s] = *reinterpret_cast<const bf16x8*>(lb + s * kBImg + b_off + 16 * (j + 1) * kRowB);
-      }
+      for (int s = 0; s < 3; ++s)
+        wf[s] = *reinterpret_cast<const bf16x8*>(lb + (s * (kBN / 16) + j) * 1024 + f_off);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         // smallest terms first: the accumulator sees them before the dominant product
@@ -228,11 +240,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_gemm_bf16x3_kernel(const unsi
         c = mfma_bf16(wf[0], af[i][0], c);   // hi * hi
         acc[i][j] = c;
       }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s = 0; s < 3; ++s) wf[s] = wn[s];
     }
-    lds_only_barrier();   // the images are rewritten by the next step
   }
 
   // epilogue: lane l holds features f0 .. f0 + 3 (f0 = col0 + 16 j + 4 (l >> 4)) of node row0 + 32 wave + 16 i + (l & 15)
@@ -339,7 +347,7 @@ extern "C" gconv_status_t gconv_mlp_gemm_bf16x3(const void* a_split, const void*
   const int Kp = pad_k(in_features), Mp = pad_m(out_features), Mq = pad_k(out_features);
   const int row_tiles = (num_rows + kBM - 1) / kBM;
   const dim3 grid(((row_tiles + 7) / 8) * (Mp / kBN) * 8);   // 1-D: the kernel maps it to tiles XCD-aware
-  const size_t lds = 3 * (kAImg + kBImg);
+  const size_t lds = 2 * kBufB;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const unsigned short* a = static_cast<const unsigned short*>(a_split);
   const unsigned short* w = static_cast<const unsigned short*>(w_split);
@@ -347,7 +355,7 @@ extern "C" gconv_status_t gconv_mlp_gemm_bf16x3(const void* a_split, const void*
   unsigned short* c3 = static_cast<unsigned short*>(c_split);
 #define GCONV_MLP_LAUNCH(EPI_, SPLIT_)                                                                             \
   do {                                                                                                             \
-    static bool opted_in = false; /* (49.9 KB of dynamic LDS: above the 48 KB default, once per kernel) */         \
+    static bool opted_in = false; /* (two 39 KB buffers of dynamic LDS: above the 48 KB default; once per kernel) */ \
     if (!opted_in) {                                                                                               \
       GCONV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_gemm_bf16x3_kernel<EPI_, SPLIT_>),          \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));           \
