@@ -17,7 +17,9 @@
 //      size sort of the tile records
 #include <hipcub/hipcub.hpp>
 
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 
 #include "common.h"
 #include "tiles.h"
@@ -41,6 +43,8 @@ int tile_nominal(int n) {
   const int t = ceil_div(n, kNumCU * k);
   return t < GCONV_TILE_NODES ? GCONV_TILE_NODES : t;
 }
+
+constexpr int kSmallMaxEdges = 4096, kSmallMaxNodes = 4096;   // the single-workgroup build (below)
 
 enum {
   INFO_NNZ = 0, INFO_NLONG = 1, INFO_NSEG = 2, INFO_MAXDEG = 3, INFO_BAD = 4,
@@ -174,14 +178,23 @@ struct CsrSlots {
 };
 struct BuildLayout {
   CsrSlots f, b;
-  size_t dis, tile_ptr, tile_key, tile_key_out, tile_id, tile_id_out, keys_a, keys_b, info, cub, total, cub_bytes;
+  size_t dis, tile_ptr, tile_key, tile_key_out, tile_id, tile_id_out, keys_a, keys_b, ell, info, cub, total, cub_bytes;
   int ntiles, T;
 };
+
+// sizes the counting build takes (counting_build_kernel; the constants are repeated there)
+static bool counting_build_size_ok(int64_t E, int32_t n) {
+  return n > kSmallMaxNodes && n <= (1 << 18) && E > 0 && E <= (static_cast<int64_t>(1) << 20);
+}
 
 static int64_t max_long_rows(int64_t E) { return E / (GCONV_LONG_ROW + 1) + 1; }
 static int64_t max_segments(int64_t E) { return E / GCONV_SEG_EDGES + max_long_rows(E) + 1; }
 
 static size_t cub_bytes_for(int64_t E, int ntiles) {
+  thread_local int64_t last_e = -1;      // (training loops build the same shapes over and over)
+  thread_local int last_nt = -1;
+  thread_local size_t last = 0;
+  if (E == last_e && ntiles == last_nt) return last;
   const int cnt = static_cast<int>(E > 0 ? E : 1);
   size_t s64 = 0, s32 = 0;
   hipcub::DeviceRadixSort::SortKeys(nullptr, s64, static_cast<const uint64_t*>(nullptr),
@@ -193,7 +206,9 @@ static size_t cub_bytes_for(int64_t E, int ntiles) {
                                      static_cast<uint32_t*>(nullptr), static_cast<const uint32_t*>(nullptr),
                                      static_cast<uint32_t*>(nullptr), ntiles, 0, kTileSizeBits, nullptr);
   size_t m = s64 > s32 ? s64 : s32;
-  return m > st ? m : st;
+  last_e = E; last_nt = ntiles;
+  last = m > st ? m : st;
+  return last;
 }
 
 static BuildLayout build_layout(int64_t E, int32_t n) {
@@ -226,6 +241,7 @@ static BuildLayout build_layout(int64_t E, int32_t n) {
   L.tile_id_out = take(nt * 4);
   L.keys_a = take(e1 * 8);
   L.keys_b = take(e1 * 8);
+  L.ell = take(counting_build_size_ok(E, n) ? static_cast<size_t>(n) * 64 : 0);   // kEllWidth x 4 bytes per row
   L.info = take(64 * 4);
   L.cub_bytes = cub_bytes_for(E, L.ntiles);
   L.cub = take(L.cub_bytes + 256);
@@ -282,7 +298,6 @@ static gconv_status_t build_direction(const int64_t* ei, int64_t E, int32_t n, i
 // up to 4096 edges; beyond that the multi-launch pipeline is as fast (6960 edges: 103 us against 94).
 // One workgroup of 1024 threads: with 256 (cheaper barriers, 4-8 keys per thread) the dependent
 // binary searches per thread dominate and the ESOL batch builds in 53 us instead of 48.
-constexpr int kSmallMaxEdges = 4096, kSmallMaxNodes = 4096;
 
 __device__ __forceinline__ int small_lower_bound(const uint32_t* keys, int count, uint32_t v) {
   int lo = 0, hi = count;
@@ -516,14 +531,14 @@ __global__ __launch_bounds__(T) void small_graph_build_kernel(SmallBuildArgs a) 
   const TileInfoSlots is{INFO_NOTILE, INFO_TILEMAX, INFO_TILEEDGES};
   const CsrLds csr_lds{rowptr, keys, ko};
   for (int t = wave; t < a.ntiles; t += T / 64) {
-    const int ts = tile_cut_wave(csr_lds, n, t, a.ntiles, a.T, a.slack, lane);
-    const int te = tile_cut_wave(csr_lds, n, t + 1, a.ntiles, a.T, a.slack, lane);
+    int ts, te, e0, e1;
+    tile_cuts_wave(csr_lds, n, t, a.ntiles, a.T, a.slack, lane, ts, te, e0, e1);
     if (lane == 0) {
       a.tile_ptr[t] = ts;
       tptr[t] = ts;
       if (t == a.ntiles - 1) { a.tile_ptr[a.ntiles] = n; tptr[a.ntiles] = n; }
     }
-    tile_halo_wave(csr_lds, a.dis, ts, te, t, a.lcol_f, a.halo_f, a.recs_f + t, sinfo, is, lane);
+    tile_halo_wave(csr_lds, a.dis, ts, te, e0, e1, t, a.lcol_f, a.halo_f, a.recs_f + t, sinfo, is, lane);
   }
   __syncthreads();
   const bool asym = sinfo[INFO_ASYM] != 0;   // uniform: directed edge list -> S^T as well, in the same launch
@@ -532,7 +547,8 @@ __global__ __launch_bounds__(T) void small_graph_build_kernel(SmallBuildArgs a) 
                     a.long_seg_base_b, a.seg_long_b, a.long_sync_b, 24, sinfo);
     __syncthreads();
     for (int t = wave; t < a.ntiles; t += T / 64)   // (keys / rowptr now hold the transposed CSR)
-      tile_halo_wave(csr_lds, a.dis, tptr[t], tptr[t + 1], t, a.lcol_b, a.halo_b, a.recs_b + t, sinfo, is, lane);
+      tile_halo_wave(csr_lds, a.dis, tptr[t], tptr[t + 1], csr_lds.rowptr(tptr[t]), csr_lds.rowptr(tptr[t + 1]), t,
+                     a.lcol_b, a.halo_b, a.recs_b + t, sinfo, is, lane);
     __syncthreads();
   }
   // size-sorted tile list: rank by (rows incl. halo descending, index ascending) == tile_sort_small_kernel;
@@ -554,6 +570,364 @@ __global__ __launch_bounds__(T) void small_graph_build_kernel(SmallBuildArgs a) 
   if (tid < 64) a.info[tid] = sinfo[tid];
 }
 
+// ---------------------------------------------------------------------------
+// Mid-size graphs of small degree (molecule batches of 10^4 - 10^5 nodes): CSR by COUNTING, no
+// comparison sort of the edge list, in ONE launch. The radix pipeline above is ~12 launches (the
+// hipCUB sort alone is four or five) and two memsets, ~100 us of wall time for a 512-molecule
+// shard whose five-adapter step takes 200. Here kCountGrid workgroups — all resident: one per CU —
+// walk through three phases together, separated by two grid barriers (grid_sync):
+//   A gather : every edge takes the next free slot of its row (atomic fetch-add on the row's degree
+//              counter: the returned value is its position) and drops its source into that slot of
+//              the row's 64-byte line of a temporary ELL table (kEllWidth = 16 slots); it also
+//              counts itself into its row CHUNK's total (256 chunks: one per workgroup of phase B)
+//              — and validates the indices on the way
+//   B rows   : workgroup w owns chunk w: the chunk totals below it are its first edge offset, a
+//              workgroup scan of the degrees gives rowptr; each thread ranks its rows' <= 16 slots
+//              in registers and writes them ascending into col; dis; maximum degree. Then, a thread
+//              per edge, the exact symmetry test on the ELL rows: the multiset equals its transpose
+//              iff every stored (i <- j) has as many copies as (j <- i)
+//   C tiles  : one wave per tile (tiles.h); the counters go back to zero; the last workgroup to
+//              finish copies the info words into pinned host memory: the host only synchronises the
+//              stream, no D2H copy command
+// A row with more than 16 edges, a directed edge list or a graph beyond kCountMaxNodes make the
+// host repeat the build on the radix pipeline (arrival order in the ELL rows is not reproducible,
+// the ascending row is).
+//
+// State between launches — barrier words, info words, chunk totals, degree counters — is library-
+// owned device memory, one block per device, ALL ZEROS between launches (the kernel puts back what
+// it used), used under a host mutex: the build is synchronous, so no two launches ever share it.
+// No zeroing pass, no third barrier. A workgroup that waits longer than kSpinMax polls (~1 s: some
+// workgroup never became resident, which a grid of one workgroup per CU rules out short of a hung
+// device) leaves; the others follow at their next barrier, so the grid always drains; the host
+// sees no completion mark, clears the state block and rebuilds on the radix pipeline.
+//
+// Data that one workgroup writes and another reads in a later phase of the SAME launch goes through
+// device-scope accesses (sc1: stores write through the XCD's L2, loads do not hit a stale line of
+// it): the eight L2s are not coherent with one another inside a kernel, and the generic remedy — a
+// device-scope fence per barrier, i.e. an L2 write-back + invalidate from each of the 256 workgroups —
+// cost 23 us per barrier (measured: 159 us per build; a chain of six launches took 97).
+// ---------------------------------------------------------------------------
+constexpr int kCountMaxNodes = 1 << 18, kCountMinNodes = kSmallMaxNodes + 1;
+constexpr int64_t kCountMaxEdges = static_cast<int64_t>(1) << 20;
+constexpr int kCountGrid = kNumCU, kCountThreads = 256, kCountGroups = 8;
+constexpr int kEllWidth = 16;
+constexpr int kSpinMax = 1 << 20;
+// state block, in 4-byte words: barrier words (one 256-byte line per group + one for the grid),
+// info words, chunk totals, degree counters
+constexpr int kBarLine = 64;
+constexpr int kStateBar = 0, kStateInfo = (kCountGroups + 2) * kBarLine, kStateChunk = kStateInfo + 64,
+              kStateDeg = kStateChunk + kCountGrid, kStateWords = kStateDeg + kCountMaxNodes + 1;
+enum { INFO_DONE = 10 };
+static_assert(kEllWidth <= GCONV_LONG_ROW, "rows of the counting build are never long rows");
+
+struct CountArgs {
+  const int64_t* ei; int64_t E; int32_t n, normalize;
+  int32_t* state;                              // library-owned (see above)
+  int32_t* ell;                                // arena scratch: [n][kEllWidth]
+  int32_t *rowptr, *col; float* dis;
+  int32_t *tile_ptr, *lcol, *slots; gconv_tile_t* recs;
+  int32_t* host_info;
+  int32_t ntiles, T, slack, fwd;               // fwd: first forward counter word of info
+  TileInfoSlots is;
+};
+
+__device__ __forceinline__ int ldc(const int32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void stc(int32_t* p, int v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#ifndef GCONV_COUNT_STAMPS
+#define GCONV_COUNT_STAMPS 0
+#endif
+#ifndef GCONV_COUNT_TILES_CACHED
+#define GCONV_COUNT_TILES_CACHED 1
+#endif
+constexpr int kAuxDeviceScope = 16;            // sc1 of a buffer access
+struct CsrCoherent {   // tiles.h accessor over the CSR this launch has just produced
+  const int32_t* rowptr_;
+  const int32_t* col_;
+  __device__ __forceinline__ int rowptr(int i) const { return ldc(rowptr_ + i); }
+  __device__ __forceinline__ int col(int e) const { return ldc(col_ + e); }
+};
+
+// All kCountGrid workgroups arrive — in kCountGroups groups, each on its own counter (256 arrivals
+// on one word took 6 - 10 us: device-scope atomics on one address are serialised at the memory
+// side), the last of a group for the group at the grid's counter — and the last one of all opens
+// the next generation in every group's line. false: gave up waiting.
+// No device-scope fence (see above): every wave waits for its stores (vmcnt(0)), which for a
+// device-scope store means written through.
+__device__ __forceinline__ bool grid_sync(int32_t* state, uint32_t& gen, int* ok_s) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t* bar = reinterpret_cast<uint32_t*>(state + kStateBar);
+    const int grp = blockIdx.x % kCountGroups;
+    uint32_t* mine = bar + grp * kBarLine;           // [0] arrivals of the group, [1] its copy of the generation
+    uint32_t* top = bar + kCountGroups * kBarLine;   // [0] groups arrived
+    bool ok = true;
+    bool opener = false;
+    if (__hip_atomic_fetch_add(&mine[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+        static_cast<uint32_t>(kCountGrid / kCountGroups - 1)) {
+      __hip_atomic_store(&mine[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__hip_atomic_fetch_add(&top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+          static_cast<uint32_t>(kCountGroups - 1)) {
+        __hip_atomic_store(&top[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int g = 0; g < kCountGroups; ++g)
+          __hip_atomic_store(&bar[g * kBarLine + 1], gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        opener = true;
+      }
+    }
+    if (!opener) {
+      int spins = 0;
+      while (__hip_atomic_load(&mine[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kSpinMax) { ok = false; break; }
+      }
+    }
+    *ok_s = ok ? 1 : 0;
+  }
+  ++gen;
+  __syncthreads();
+  return *ok_s != 0;
+}
+
+__global__ __launch_bounds__(kCountThreads) void counting_build_kernel(CountArgs a) {
+  __shared__ int ok_s, last_s;
+  __shared__ int32_t wred[kCountThreads / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
+  const int64_t gtid = static_cast<int64_t>(wg) * kCountThreads + tid, gsize = static_cast<int64_t>(kCountGrid) * kCountThreads;
+  const int32_t n = a.n;
+  const int64_t E = a.E;
+  int32_t* info = a.state + kStateInfo;
+  int32_t* chunk_cnt = a.state + kStateChunk;
+  int32_t* deg = a.state + kStateDeg;
+  // generation of this workgroup's group line, read before any arrival (all groups hold the same)
+  uint32_t gen = static_cast<uint32_t>(ldc(a.state + kStateBar + (wg % kCountGroups) * kBarLine + 1));
+  const int chunk = (n + kCountGrid - 1) / kCountGrid;            // rows per workgroup in phase B
+#define GCONV_GRID_SYNC()                               \
+  do {                                                  \
+    if (!grid_sync(a.state, gen, &ok_s)) return;        \
+  } while (0)
+#if GCONV_COUNT_STAMPS   // lab builds (tools/lab/k0_stamps.py): workgroup 0's clock at the phase boundaries
+#define GCONV_STAMP(k) do { if (wg == 0 && tid == 0) stc(info + 32 + (k), static_cast<int32_t>(wall_clock64())); } while (0)
+#else
+#define GCONV_STAMP(k) do { } while (0)
+#endif
+
+  // ---- A: gather ----
+  GCONV_STAMP(0);
+  int s0 = 0, d0 = 0;                                  // the thread's first edge, kept for phase B (0, 0: none / invalid)
+  for (int64_t e0 = static_cast<int64_t>(wg) * kCountThreads + (tid & ~63); e0 < E; e0 += gsize) {   // wave-uniform trip count
+    const int64_t e = e0 + lane;
+    int ck = -1;                                       // the edge's row chunk, -1: not stored
+    if (e < E) {
+      const int64_t s = a.ei[e], d = a.ei[E + e];
+      if (s < 0 || s >= n || d < 0 || d >= n) {
+        atomicOr(&info[INFO_BAD], 1);
+      } else {
+        const int di = static_cast<int>(d);
+        if (e == gtid) { s0 = static_cast<int>(s); d0 = di; }
+        if (!(a.normalize && s == d)) {
+          const int p = atomicAdd(&deg[di], 1);
+          if (p < kEllWidth) stc(a.ell + static_cast<size_t>(di) * kEllWidth + p, static_cast<int32_t>(s));
+          ck = di / chunk;
+        }
+      }
+    }
+    // chunk totals, one atomic per distinct chunk of the wave (a collated batch keeps a wave's 64 edges
+    // within two or three chunks; 64 same-address atomics per wave made this phase 33 us)
+    unsigned long long todo = __ballot(ck >= 0);
+    while (todo) {
+      const int c0 = __builtin_amdgcn_readlane(ck, __ffsll(static_cast<long long>(todo)) - 1);
+      const unsigned long long same = __ballot(ck == c0);
+      if (lane == __ffsll(static_cast<long long>(same)) - 1) atomicAdd(&chunk_cnt[c0], __popcll(same));
+      todo &= ~same;
+    }
+  }
+  GCONV_STAMP(1);
+  GCONV_GRID_SYNC();
+  GCONV_STAMP(2);
+
+  // ---- B: rows. Workgroup w owns rows [w * chunk, (w + 1) * chunk), thread t rows t * per .. ----
+  const int per = (chunk + kCountThreads - 1) / kCountThreads;
+  const int r0 = min(wg * chunk + tid * per, n);
+  const int r1 = min(min(r0 + per, (wg + 1) * chunk), n);
+  const rsrc_t ell_r = make_rsrc(a.ell, static_cast<uint32_t>(n) * kEllWidth * 4u);
+  auto ell_row = [&](int row, i32x4 (&v)[kEllWidth / 4]) {
+#pragma unroll
+    for (int q = 0; q < kEllWidth / 4; ++q)
+      v[q] = __builtin_amdgcn_raw_buffer_load_b128(ell_r, (row * kEllWidth + 4 * q) * 4, 0, kAuxDeviceScope);
+  };
+  {
+    // every load of the phase that does not depend on the scan is issued here, in one batch: the chunk
+    // totals, the degrees and the slots of the thread's first row, and both ELL rows of its first edge
+    const bool bad = ldc(info + INFO_BAD) != 0;                   // grid-uniform: the host refuses the list
+    int cc[kCountGrid / 64];
+#pragma unroll
+    for (int k = 0; k < kCountGrid / 64; ++k) cc[k] = ldc(chunk_cnt + k * 64 + lane);
+    i32x4 row0[kEllWidth / 4], rd[kEllWidth / 4], rs[kEllWidth / 4];
+    ell_row(min(r0, n - 1), row0);
+    const int dd0 = ldc(deg + d0), ds0 = ldc(deg + s0);
+    ell_row(d0, rd);
+    ell_row(s0, rs);
+    int below = 0, all = 0;                            // kCountGrid = 256 chunk totals: four per lane
+#pragma unroll
+    for (int k = 0; k < kCountGrid / 64; ++k) {
+      all += cc[k];
+      if (k * 64 + lane < wg) below += cc[k];
+    }
+    below = wave_sum_i(below);
+    all = wave_sum_i(all);
+    int mysum = 0, mymax = 0;
+    for (int i = r0; i < r1; ++i) {
+      const int v = ldc(deg + i);
+      mysum += v;
+      mymax = max(mymax, v);
+    }
+    int incl = mysum;                                  // inclusive scan over the workgroup's threads
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(incl, off);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) wred[wave] = incl;
+    mymax = wave_max_i(mymax);
+    if (lane == 0 && mymax > 0) atomicMax(&info[a.fwd + 3], mymax);
+    __syncthreads();
+    int wbase = 0;
+#pragma unroll
+    for (int w = 0; w < kCountThreads / 64; ++w)
+      if (w < wave) wbase += wred[w];
+    int run = below + wbase + incl - mysum;
+    for (int i = r0; i < r1; ++i) {
+      const int dg = ldc(deg + i);
+      stc(a.rowptr + i, run);
+      if (a.dis) stc(reinterpret_cast<int32_t*>(a.dis) + i, __float_as_int(1.0f / sqrtf(static_cast<float>(dg + 1))));
+      if (i > r0) ell_row(i, row0);
+      if (!bad && dg <= kEllWidth && dg > 0) {         // the row's slots, ranked in registers -> ascending
+#pragma unroll
+        for (int j = 0; j < kEllWidth; ++j) {
+          if (j < dg) {
+            const int vj = row0[j / 4][j % 4];
+            int rank = 0;
+#pragma unroll
+            for (int k = 0; k < kEllWidth; ++k) {
+              const int vk = row0[k / 4][k % 4];
+              rank += (k < dg) && (vk < vj || (vk == vj && k < j));
+            }
+            stc(a.col + run + rank, vj);
+          }
+        }
+      }
+      run += dg;
+    }
+    if (wg == 0 && tid == 0) {
+      stc(a.rowptr + n, all);
+      atomicExch(&info[a.fwd + 0], all);               // nnz; no long rows on this path (n_long = n_seg = 0)
+    }
+    if (!bad) {   // symmetry, a thread per edge, on the ELL rows (complete since the barrier)
+      bool asym = false;
+      auto test = [&](int s, int d, int dd, int ds) {
+        if (s == d || dd > kEllWidth || ds > kEllWidth) return;    // (the host rebuilds: maximum degree)
+        int fwd = 0, back = 0;
+#pragma unroll
+        for (int k = 0; k < kEllWidth; ++k) {
+          fwd += (k < dd) && rd[k / 4][k % 4] == s;
+          back += (k < ds) && rs[k / 4][k % 4] == d;
+        }
+        asym |= fwd != back;
+      };
+      test(s0, d0, dd0, ds0);                          // (0, 0 when the thread has no first edge: skipped as a self-loop)
+      for (int64_t e = gtid + gsize; e < E; e += gsize) {
+        const int s = static_cast<int>(a.ei[e]), d = static_cast<int>(a.ei[E + e]);
+        const int dd = ldc(deg + d), ds = ldc(deg + s);
+        ell_row(d, rd);
+        ell_row(s, rs);
+        test(s, d, dd, ds);
+      }
+      if (asym) atomicOr(&info[INFO_ASYM], 1);
+    }
+  }
+  GCONV_STAMP(3);
+  GCONV_GRID_SYNC();
+  GCONV_STAMP(4);
+
+  // ---- C: tiles: tile t on workgroup t mod grid (one wave per tile, a tile per CU first); counters
+  //         back to zero ----
+  for (int i = r0; i < r1; ++i) stc(deg + i, 0);
+  if (tid == 0) stc(chunk_cnt + wg, 0);
+  const int c_bad = ldc(info + INFO_BAD), c_deg = ldc(info + a.fwd + 3), c_asym = ldc(info + INFO_ASYM);   // one batch
+  if ((c_bad == 0) & (c_deg <= kEllWidth) & (c_asym == 0)) {
+#if GCONV_COUNT_TILES_CACHED
+    // rowptr / col / dis are complete and written through: drop what this XCD's L2 and the CU's L1 may
+    // hold of them (an invalidate, no write-back) and read them like any kernel would, cached
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const CsrGlobal csr{a.rowptr, a.col};
+#else
+    const CsrCoherent csr{a.rowptr, a.col};
+#endif
+    for (int t = wg + kCountGrid * wave; t < a.ntiles; t += kCountGrid * (kCountThreads / 64)) {
+      int ts, te, e0, e1;
+      tile_cuts_wave(csr, n, t, a.ntiles, a.T, a.slack, lane, ts, te, e0, e1);
+      if (lane == 0) {
+        a.tile_ptr[t] = ts;
+        if (t == a.ntiles - 1) a.tile_ptr[a.ntiles] = n;
+      }
+      tile_halo_wave<decltype(csr), !GCONV_COUNT_TILES_CACHED>(csr, a.dis, ts, te, e0, e1, t, a.lcol, a.slots, a.recs + t, info,
+                                                                a.is, lane);
+    }
+  }
+  GCONV_STAMP(5);
+  // ---- the last workgroup to get here reports to the host and clears the info words ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t* done = reinterpret_cast<uint32_t*>(a.state + kStateBar) + (kCountGroups + 1) * kBarLine;
+    const uint32_t old = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_s = old == static_cast<uint32_t>(kCountGrid - 1);
+    if (last_s) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (last_s && tid < 64) {
+    int v = ldc(info + tid);
+#if GCONV_COUNT_STAMPS
+    if (tid == 32 + 6) v = static_cast<int32_t>(wall_clock64());
+#endif
+    if (tid == INFO_DONE) v = 1;
+    stc(info + tid, 0);
+    if (tid != INFO_DONE) a.host_info[tid] = v;
+    __threadfence_system();   // the other 63 words and the zeroed state block first, then the completion mark
+    if (tid == INFO_DONE) a.host_info[tid] = v;
+    __threadfence_system();
+  }
+#undef GCONV_GRID_SYNC
+#undef GCONV_STAMP
+}
+
+// library-owned state of counting_build_kernel, one per device (see the comment above)
+struct CountState {
+  std::mutex mu;
+  int32_t* state = nullptr;       // device: kStateWords words, zero between launches
+  int32_t* host_info = nullptr;   // pinned, mapped: 64 words
+  bool ready = false, broken = false;
+};
+static CountState* count_state() {
+  static CountState states[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  return &states[dev];
+}
+
+static bool counting_build_ok(int64_t E, int32_t n) {   // (env read per call: the tests compare the builders)
+  const char* v = std::getenv("GCONV_NO_COUNTING_BUILD");
+  const bool off = v != nullptr && v[0] != '\0' && v[0] != '0';
+  static_assert(kCountMinNodes == kSmallMaxNodes + 1 && kCountMaxNodes == (1 << 18) && kEllWidth * 4 == 64 &&
+                kCountMaxEdges == (static_cast<int64_t>(1) << 20), "counting_build_size_ok repeats these");
+  return !off && counting_build_size_ok(E, n);
+}
+
 static bool small_build_ok(int64_t E, int32_t n) {   // (env read per call: the tests compare both builders)
   const char* v = std::getenv("GCONV_NO_SMALL_BUILD");
   const bool off = v != nullptr && v[0] != '\0' && v[0] != '0';
@@ -563,6 +937,36 @@ static bool small_build_ok(int64_t E, int32_t n) {   // (env read per call: the 
 }  // namespace gconv
 
 using namespace gconv;
+
+// size sort of the tile records (queued on `stream`, not waited for): node order for <= 256 tiles (one
+// per persistent workgroup: no launch; the kernels know a tile's halo slot from the workgroup index,
+// before its record has arrived), one ranking workgroup up to 2048 tiles, a stable radix sort beyond
+template <class Layout>
+static gconv_status_t sort_tiles(const Layout& L, char* arena, gconv_tile_t* recs_f, gconv_tile_t* recs_b,
+                                 gconv_tile_t* tiles_f, gconv_tile_t* tiles_b, gconv_graph_t* g,
+                                 hipStream_t stream) {
+  const int T = 256;
+  if (L.ntiles <= kNumCU) {
+    g->tiles_fwd.tiles = recs_f;
+    g->tiles_bwd.tiles = recs_b ? recs_b : recs_f;
+  } else if (L.ntiles <= kSmallSortMax) {
+    tile_sort_small_kernel<<<1, 1024, 0, stream>>>(recs_f, recs_b, L.ntiles, tiles_f, tiles_b);
+    GCONV_LAUNCH_CHECK();
+  } else {  // largest tile first; stable, so the order is a function of the graph alone
+    uint32_t* key = reinterpret_cast<uint32_t*>(arena + L.tile_key);
+    uint32_t* key_out = reinterpret_cast<uint32_t*>(arena + L.tile_key_out);
+    uint32_t* id = reinterpret_cast<uint32_t*>(arena + L.tile_id);
+    uint32_t* id_out = reinterpret_cast<uint32_t*>(arena + L.tile_id_out);
+    tile_sort_keys_kernel<<<(L.ntiles + T - 1) / T, T, 0, stream>>>(recs_f, L.ntiles, key, id);
+    GCONV_LAUNCH_CHECK();
+    size_t cub_bytes = L.cub_bytes;
+    GCONV_HIP(hipcub::DeviceRadixSort::SortPairs(arena + L.cub, cub_bytes, key, key_out, id, id_out, L.ntiles, 0,
+                                                 kTileSizeBits, stream));
+    tile_sort_gather_kernel<<<(L.ntiles + T - 1) / T, T, 0, stream>>>(recs_f, recs_b, id_out, L.ntiles, tiles_f, tiles_b);
+    GCONV_LAUNCH_CHECK();
+  }
+  return GCONV_OK;
+}
 
 extern "C" int32_t gconv_tile_nodes(int32_t num_nodes) { return tile_nominal(num_nodes); }
 
@@ -671,6 +1075,74 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
     return GCONV_OK;
   }
 
+  const int T = 256;
+  int32_t h[64];
+  CountState* cs = counting_build_ok(E, n) ? count_state() : nullptr;
+  if (cs) {   // one launch (see counting_build_kernel)
+    std::lock_guard<std::mutex> lock(cs->mu);
+    if (!cs->ready) {
+      GCONV_HIP(hipMalloc(reinterpret_cast<void**>(&cs->state), kStateWords * sizeof(int32_t)));
+      GCONV_HIP(hipHostMalloc(reinterpret_cast<void**>(&cs->host_info), 64 * sizeof(int32_t), hipHostMallocMapped));
+      cs->ready = cs->broken = true;
+    }
+    if (cs->broken) {   // first use, or a launch that gave up: everything back to zero
+      GCONV_HIP(hipMemset(cs->state, 0, kStateWords * sizeof(int32_t)));
+      cs->broken = false;
+    }
+    CountArgs a{};
+    a.ei = edge_index; a.E = E; a.n = n; a.normalize = normalize ? 1 : 0;
+    a.state = cs->state;
+    a.ell = reinterpret_cast<int32_t*>(arena + L.ell);
+    a.rowptr = of.rowptr; a.col = of.col; a.dis = dis;
+    a.tile_ptr = tile_ptr; a.lcol = tf.lcol; a.slots = tf.halo; a.recs = tf.recs;
+    void* host_dev = nullptr;
+    GCONV_HIP(hipHostGetDevicePointer(&host_dev, cs->host_info, 0));
+    a.host_info = static_cast<int32_t*>(host_dev);
+    a.ntiles = L.ntiles; a.T = L.T; a.slack = slack; a.fwd = FWD; a.is = is;
+    volatile int32_t* hv = cs->host_info;
+    hv[INFO_DONE] = 0;
+    counting_build_kernel<<<kCountGrid, kCountThreads, 0, stream>>>(a);
+    GCONV_LAUNCH_CHECK();
+    // Wait on the completion mark in pinned memory, looking at the stream now and then (a kernel that
+    // gave up or faulted never writes it). No stream synchronisation once the mark has arrived: the
+    // kernel is at its last instruction, its results are ordered on `stream` like any kernel's, and the
+    // runtime's completion handling (5 - 6 us, hipStreamQuery as much as hipStreamSynchronize) stays off
+    // the build's path.
+    for (long spins = 0; !hv[INFO_DONE]; ++spins)
+      if ((spins & 1023) == 1023 && hipStreamQuery(stream) != hipErrorNotReady) break;
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (!hv[INFO_DONE]) GCONV_HIP(hipStreamSynchronize(stream));   // (a fault surfaces here)
+    if (!hv[INFO_DONE]) {
+      cs->broken = true;                       // gave up at a barrier: the radix pipeline below does the build
+    } else {
+      for (int i = 0; i < 64; ++i) h[i] = hv[i];
+#if GCONV_COUNT_STAMPS
+      for (int i = 1; i <= 6; ++i) fprintf(stderr, "%d:%.2f ", i, (h[32 + i] - h[32 + i - 1]) * 0.01);
+      fprintf(stderr, "us\n");
+#endif
+      if (h[INFO_BAD]) {
+        g->bad_index = 1;
+        return GCONV_E_BAD_INDEX;
+      }
+      if (!h[INFO_ASYM] && h[FWD + 3] <= kEllWidth) {   // symmetric, every row fitted its slots: done
+        fill(g->fwd, of, h + FWD);
+        g->max_degree = h[FWD + 3];
+        g->symmetric = 1;
+        g->bwd = g->fwd;
+        g->dis = dis;
+        fill_tiles(h, true);
+        if (g->n_tiles > 0) {
+          gconv_status_t ts = sort_tiles(L, arena, tf.recs, nullptr, tf.tiles, tb.tiles, g, stream);
+          if (ts != GCONV_OK) return ts;
+        }
+        g->normalize = normalize ? 1 : 0;
+        g->bad_index = 0;
+        return GCONV_OK;
+      }
+      // a row of more than kEllWidth edges or a directed list: the radix pipeline does the whole build again
+    }
+  }
+
   GCONV_HIP(hipMemsetAsync(info, 0, 64 * sizeof(int32_t), stream));
   const int b = index_bits(n);
   const bool k32 = 2 * b <= 32;
@@ -679,7 +1151,6 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
           : build_direction<uint64_t>(edge_index, E, n, normalize, 0, b, arena, L, of, dis, info, FWD, stream);
   if (st != GCONV_OK) return st;
 
-  const int T = 256;
   if (E > 0) {
     sym_check_kernel<<<static_cast<unsigned>((E + T - 1) / T), T, 0, stream>>>(
         of.rowptr, of.col, n, info + FWD, info + INFO_ASYM);
@@ -690,7 +1161,6 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
                                                                     tile_ptr, tf.lcol, tf.halo, tf.recs, info, is);
     GCONV_LAUNCH_CHECK();
   }
-  int32_t h[64];
   GCONV_HIP(hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, stream));
   GCONV_HIP(hipStreamSynchronize(stream));
   if (h[INFO_BAD]) {
@@ -718,28 +1188,9 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
   }
   g->dis = dis;
   fill_tiles(h, g->symmetric != 0);
-  gconv_tile_t* recs_b = g->symmetric ? nullptr : tb.recs;
-  if (g->n_tiles > 0 && L.ntiles <= kNumCU) {
-    // one tile per persistent workgroup: node order (no sort launch; the kernels know a tile's halo
-    // slot from the workgroup index, before its record has arrived)
-    g->tiles_fwd.tiles = tf.recs;
-    g->tiles_bwd.tiles = g->symmetric ? tf.recs : tb.recs;
-  } else if (g->n_tiles > 0 && L.ntiles <= kSmallSortMax) {
-    tile_sort_small_kernel<<<1, 1024, 0, stream>>>(tf.recs, recs_b, L.ntiles, tf.tiles, tb.tiles);
-    GCONV_LAUNCH_CHECK();
-  } else if (g->n_tiles > 0) {  // largest tile first; stable, so the order is a function of the graph alone
-    uint32_t* key = reinterpret_cast<uint32_t*>(arena + L.tile_key);
-    uint32_t* key_out = reinterpret_cast<uint32_t*>(arena + L.tile_key_out);
-    uint32_t* id = reinterpret_cast<uint32_t*>(arena + L.tile_id);
-    uint32_t* id_out = reinterpret_cast<uint32_t*>(arena + L.tile_id_out);
-    tile_sort_keys_kernel<<<(L.ntiles + T - 1) / T, T, 0, stream>>>(tf.recs, L.ntiles, key, id);
-    GCONV_LAUNCH_CHECK();
-    size_t cub_bytes = L.cub_bytes;
-    GCONV_HIP(hipcub::DeviceRadixSort::SortPairs(arena + L.cub, cub_bytes, key, key_out, id, id_out, L.ntiles, 0,
-                                                 kTileSizeBits, stream));
-    tile_sort_gather_kernel<<<(L.ntiles + T - 1) / T, T, 0, stream>>>(tf.recs, recs_b, id_out, L.ntiles, tf.tiles,
-                                                                      tb.tiles);
-    GCONV_LAUNCH_CHECK();
+  if (g->n_tiles > 0) {
+    st = sort_tiles(L, arena, tf.recs, g->symmetric ? nullptr : tb.recs, tf.tiles, tb.tiles, g, stream);
+    if (st != GCONV_OK) return st;
   }
   g->normalize = normalize ? 1 : 0;
   g->bad_index = 0;

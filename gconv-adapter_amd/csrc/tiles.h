@@ -69,31 +69,46 @@ __device__ __forceinline__ int wave_min_i(int v) {
 // column (rows are sorted): exact for the tree-plus-chords layouts of molecules, a heuristic in
 // general — correctness never depends on it (tile_halo_wave finds every crossing edge).
 // One wave; all lanes return the cut.
+// The loads of one cut, apart from the arithmetic: a wave that places two cuts (its tile's lower and
+// upper one) issues both sets before it waits for either — two memory round trips, not four.
+struct CutReach { int mxA, mxB, mnB, mnC, rpB, rpC; };   // rp: rowptr of the lane's row of B / C
+
 template <class Csr>
-__device__ __forceinline__ int tile_cut_wave(const Csr& csr, int n, int k, int ntiles, int T, int slack, int lane) {
+__device__ __forceinline__ CutReach tile_cut_reach(const Csr& csr, int n, int k, int ntiles, int T, int lane) {
+  // branch-free (clamped row, clamped edge; E = 0 builds still own one readable column word), so that
+  // the compiler keeps the six row reads of two cuts in one batch
+  const int q0 = (k <= 0 || k >= ntiles) ? 0 : k * T;
+  auto reach = [&](int row, int& mx, int& mn, int& a) {
+    const bool in = row >= 0 && row < n;
+    const int rc = in ? row : 0;
+    a = csr.rowptr(rc);
+    const int b = csr.rowptr(rc + 1);
+    const bool any = in && b > a;
+    const int lo = csr.col(any ? a : 0), hi = csr.col(any ? b - 1 : 0);
+    mn = any ? lo : INT_MAX;
+    mx = any ? hi : -1;
+  };
+  CutReach r;
+  int mnA, mxC, rpA;
+  reach(q0 - 128 + lane, r.mxA, mnA, rpA);
+  reach(q0 - 64 + lane, r.mxB, r.mnB, r.rpB);    // lane b <-> row q0 - 64 + b
+  reach(q0 + lane, mxC, r.mnC, r.rpC);
+  (void)mnA; (void)mxC; (void)rpA;
+  return r;
+}
+
+__device__ __forceinline__ int tile_cut_pick(const CutReach& r, int n, int k, int ntiles, int T, int slack, int lane) {
   if (k <= 0) return 0;
   if (k >= ntiles) return n;
   const int q0 = k * T;
-  auto reach = [&](int row, int& mx, int& mn) {
-    mx = -1; mn = INT_MAX;
-    if (row >= 0 && row < n) {
-      const int a = csr.rowptr(row), b = csr.rowptr(row + 1);
-      if (b > a) { mn = csr.col(a); mx = csr.col(b - 1); }
-    }
-  };
-  int mxA, mnA, mxB, mnB, mxC, mnC;
-  reach(q0 - 128 + lane, mxA, mnA);
-  reach(q0 - 64 + lane, mxB, mnB);    // lane b <-> row q0 - 64 + b
-  reach(q0 + lane, mxC, mnC);
-  (void)mnA; (void)mxC;
-  const int maxA = wave_max_i(mxA), minC = wave_min_i(mnC);
-  int pm = mxB;                        // inclusive prefix maximum over the lanes of B
+  const int maxA = wave_max_i(r.mxA), minC = wave_min_i(r.mnC);
+  int pm = r.mxB;                      // inclusive prefix maximum over the lanes of B
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     const int v = __shfl_up(pm, off);
     if (lane >= off) pm = max(pm, v);
   }
-  int sm = mnB;                        // inclusive suffix minimum over the lanes of B
+  int sm = r.mnB;                      // inclusive suffix minimum over the lanes of B
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     const int v = __shfl_down(sm, off);
@@ -110,6 +125,25 @@ __device__ __forceinline__ int tile_cut_wave(const Csr& csr, int n, int k, int n
   return q0 - 63 + (63 - __clzll(static_cast<long long>(m)));
 }
 
+// rowptr of an inner cut q of cut k (0 < k < ntiles), from the reach's loads: q is in [q0 - 63, q0]
+__device__ __forceinline__ int tile_cut_rowptr(const CutReach& r, int k, int T, int q) {
+  const int q0 = k * T;
+  return q == q0 ? __builtin_amdgcn_readlane(r.rpC, 0) : __builtin_amdgcn_readlane(r.rpB, q - q0 + 64);
+}
+
+// both cuts of tile t: rows [ts, te), edges [e0, e1) — the cuts' rowptr values come out of the same loads
+template <class Csr>
+__device__ __forceinline__ void tile_cuts_wave(const Csr& csr, int n, int t, int ntiles, int T, int slack, int lane,
+                                               int& ts, int& te, int& e0, int& e1) {
+  const CutReach lo = tile_cut_reach(csr, n, t, ntiles, T, lane);
+  const CutReach hi = tile_cut_reach(csr, n, t + 1, ntiles, T, lane);
+  const int nnz = csr.rowptr(n);
+  ts = tile_cut_pick(lo, n, t, ntiles, T, slack, lane);
+  te = tile_cut_pick(hi, n, t + 1, ntiles, T, slack, lane);
+  e0 = t <= 0 ? csr.rowptr(0) : tile_cut_rowptr(lo, t, T, ts);
+  e1 = t + 1 >= ntiles ? nnz : tile_cut_rowptr(hi, t + 1, T, te);
+}
+
 // Halo, local column ids and record of tile t = rows [ts, te) of one CSR (forward or transposed).
 // One wave. `rec` receives the unsorted record (slot = t).
 //
@@ -122,6 +156,7 @@ __device__ __forceinline__ int tile_cut_wave(const Csr& csr, int n, int k, int n
 // (hub rows of a power-law graph would otherwise be walked edge by edge), and once one tile has
 // been given up the graph is not tileable and the other waves stop as well.
 constexpr int kTileMaxOwnEdges = 1 << 14;
+constexpr int kOwnRegs = 4, kHaloRegs = 6;   // edges of a tile kept in registers between the two sweeps
 
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
@@ -129,16 +164,15 @@ __device__ __forceinline__ int wave_sum_i(int v) {
   return v;
 }
 
-template <class Csr>
-__device__ __forceinline__ void tile_halo_wave(const Csr& csr, const float* __restrict__ dis, int ts, int te, int t,
-                                               int32_t* __restrict__ lcol, int32_t* __restrict__ slots,
+template <class Csr, bool COHERENT_DIS = false>
+__device__ __forceinline__ void tile_halo_wave(const Csr& csr, const float* __restrict__ dis, int ts, int te, int e0,
+                                               int e1, int t, int32_t* __restrict__ lcol, int32_t* __restrict__ slots,
                                                gconv_tile_t* __restrict__ rec, int32_t* info,
                                                TileInfoSlots is, int lane) {
   const int nt = te - ts;
   int32_t* hnodes = slots + static_cast<size_t>(t) * kHaloSlot;
   int32_t* hrp = hnodes + kHaloRpOff;
   int32_t* hcol = hnodes + kHaloColOff;
-  const int e0 = csr.rowptr(ts), e1 = csr.rowptr(te);
   auto give_up = [&]() {
     if (lane == 0) {
       atomicOr(&info[is.notile], 1);
@@ -156,9 +190,9 @@ __device__ __forceinline__ void tile_halo_wave(const Csr& csr, const float* __re
   // appends the nodes c of the lanes in m that are not in the list yet, in lane order
   auto append = [&](unsigned long long m, int c) {
     while (m && !overflow) {
-      const int b = __ffsll(static_cast<long long>(m)) - 1;
+      const int b = __ffsll(static_cast<long long>(m)) - 1;   // wave-uniform: v_readlane, not a permute through LDS
       m &= m - 1;
-      const int v = __shfl(c, b);
+      const int v = __builtin_amdgcn_readlane(c, b);
       if (__ballot(hval == v) == 0) {
         if (hcount < kHaloNodes) {
           if (lane == hcount) hval = v;
@@ -169,7 +203,17 @@ __device__ __forceinline__ void tile_halo_wave(const Csr& csr, const float* __re
       }
     }
   };
-  for (int base = e0; base < e1 && !overflow; base += 64) {   // halo1: outside columns of the own rows
+  // the first kOwnRegs x 64 own edges (all of a molecule tile's) are read ONCE, in one batch of loads
+  int cown[kOwnRegs];
+#pragma unroll
+  for (int j = 0; j < kOwnRegs; ++j) {
+    const int e = e0 + 64 * j + lane;
+    cown[j] = e < e1 ? csr.col(e) : ts;
+  }
+#pragma unroll
+  for (int j = 0; j < kOwnRegs; ++j)                          // halo1: outside columns of the own rows
+    if (e0 + 64 * j < e1 && !overflow) append(__ballot(cown[j] < ts || cown[j] >= te), cown[j]);
+  for (int base = e0 + 64 * kOwnRegs; base < e1 && !overflow; base += 64) {
     const int e = base + lane;
     const int c = e < e1 ? csr.col(e) : ts;
     append(__ballot(e < e1 && (c < ts || c >= te)), c);
@@ -189,31 +233,55 @@ __device__ __forceinline__ void tile_halo_wave(const Csr& csr, const float* __re
     if (lane >= off) hoff += v;
   }
   hoff -= hdeg;                                               // exclusive: first edge slot of this lane's row
-  for (int k = 0; k < dmax && !overflow; ++k) {               // halo2: outside columns of the halo1 rows
+  int chalo[kHaloRegs];                                       // the halo1 rows' first columns, one batch
+#pragma unroll
+  for (int k = 0; k < kHaloRegs; ++k) chalo[k] = k < hdeg ? csr.col(ha + k) : ts;
+#pragma unroll
+  for (int k = 0; k < kHaloRegs; ++k)                         // halo2: outside columns of the halo1 rows
+    if (k < dmax && !overflow) append(__ballot(chalo[k] < ts || chalo[k] >= te), chalo[k]);
+  for (int k = kHaloRegs; k < dmax && !overflow; ++k) {
     const bool ok = k < hdeg;
     const int c = ok ? csr.col(ha + k) : ts;
     append(__ballot(ok && (c < ts || c >= te)), c);
   }
   if (overflow) { give_up(); return; }
-  // tile-local id of column c (uniform control flow: every lane walks the list when any needs it)
+  // tile-local id of column c: own nodes by subtraction, halo nodes by their position in the list —
+  // one step per OUTSIDE lane (a few per 64 edges), not per list entry (uniform control flow)
   auto local_id = [&](int c, bool outside) {
     int id = c - ts;
-    if (__ballot(outside)) {
-      for (int j = 0; j < hcount; ++j) {
-        const int v = __shfl(hval, j);
-        if (outside && v == c) id = nt + j;
-      }
+    unsigned long long m = __ballot(outside);
+    while (m) {
+      const int b = __ffsll(static_cast<long long>(m)) - 1;
+      m &= m - 1;
+      const int v = __builtin_amdgcn_readlane(c, b);
+      const int j = __ffsll(static_cast<long long>(__ballot(hval == v))) - 1;   // v is in the list
+      if (lane == b) id = nt + j;
     }
     return id;
   };
-  for (int base = e0; base < e1; base += 64) {
+#pragma unroll
+  for (int j = 0; j < kOwnRegs; ++j) {
+    const int e = e0 + 64 * j + lane;
+    if (e0 + 64 * j < e1) {                                   // wave-uniform
+      const int id = local_id(cown[j], cown[j] < ts || cown[j] >= te);
+      if (e < e1) lcol[e] = id;
+    }
+  }
+  for (int base = e0 + 64 * kOwnRegs; base < e1; base += 64) {
     const int e = base + lane;
     const bool ok = e < e1;
     const int c = ok ? csr.col(e) : ts;
     const int id = local_id(c, ok && (c < ts || c >= te));
     if (ok) lcol[e] = id;
   }
-  for (int k = 0; k < dmax; ++k) {
+#pragma unroll
+  for (int k = 0; k < kHaloRegs; ++k) {
+    if (k < dmax) {                                           // wave-uniform
+      const int id = local_id(chalo[k], chalo[k] < ts || chalo[k] >= te);
+      if (k < hdeg) hcol[hoff + k] = id;
+    }
+  }
+  for (int k = kHaloRegs; k < dmax; ++k) {
     const bool ok = k < hdeg;
     const int c = ok ? csr.col(ha + k) : ts;
     const int id = local_id(c, ok && (c < ts || c >= te));
@@ -223,7 +291,12 @@ __device__ __forceinline__ void tile_halo_wave(const Csr& csr, const float* __re
   if (lane < nh1) hrp[lane + 1] = hoff + hdeg;
   if (lane < hcount) {
     hnodes[lane] = hval;
-    if (dis) reinterpret_cast<float*>(hnodes + kHaloDisOff)[lane] = dis[hval];
+    // (COHERENT_DIS: dis was written earlier in this launch by another workgroup — see graph_prep.hip)
+    if (dis)
+      hnodes[kHaloDisOff + lane] =
+          COHERENT_DIS ? __hip_atomic_load(reinterpret_cast<const int32_t*>(dis) + hval, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT)
+                       : __float_as_int(dis[hval]);
   }
   if (lane == 0) {
     gconv_tile_t r;
@@ -249,11 +322,10 @@ __global__ __launch_bounds__(256) void tile_build_kernel(const int32_t* __restri
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= ntiles) return;   // wave-uniform
-  int ts, te;
+  int ts, te, e0, e1;
   const CsrGlobal csr{rowptr, col};
   if (CUTS) {
-    ts = tile_cut_wave(csr, n, t, ntiles, T, slack, lane);
-    te = tile_cut_wave(csr, n, t + 1, ntiles, T, slack, lane);
+    tile_cuts_wave(csr, n, t, ntiles, T, slack, lane, ts, te, e0, e1);
     if (lane == 0) {
       tile_ptr[t] = ts;
       if (t == ntiles - 1) tile_ptr[ntiles] = n;
@@ -261,8 +333,10 @@ __global__ __launch_bounds__(256) void tile_build_kernel(const int32_t* __restri
   } else {
     ts = tile_ptr[t];
     te = tile_ptr[t + 1];
+    e0 = rowptr[ts];
+    e1 = rowptr[te];
   }
-  tile_halo_wave(csr, dis, ts, te, t, lcol, slots, recs + t, info, is, lane);
+  tile_halo_wave(csr, dis, ts, te, e0, e1, t, lcol, slots, recs + t, info, is, lane);
 }
 
 // Size-sorted tile list for small tile counts (a molecule batch has a few hundred tiles): ONE

@@ -172,16 +172,25 @@ typedef struct gconv_graph {
 /* Bytes of device memory gconv_graph_build needs (outputs + scratch, upper bound). */
 size_t gconv_graph_build_bytes(int64_t num_edges, int32_t num_nodes);
 
-/* Builds the whole graph plan from a COO edge list in ONE call:
- *   key build -> radix sort -> CSR (+ deg^-1/2, long-row segments) -> exact symmetry
- *   test on device -> S^T only if the edge list is not symmetric -> tiles (cuts, halos).
+/* Builds the whole graph plan from a COO edge list in ONE call. Three builders, same outputs
+ * (bit-identical arrays and counters; the tests compare them):
+ *   <= 4096 nodes and edges      ONE single-workgroup launch (sort, CSR, symmetry, tiles in LDS)
+ *   4097 .. 262144 nodes,        ONE launch of 256 resident workgroups, no sort: every edge takes a
+ *   <= 2^20 edges, rows <= 16    slot of its row by atomic counting, rows are ranked in registers,
+ *   edges, symmetric             two grid barriers (graph_prep.hip: counting_build_kernel). Uses a
+ *                                ~1 MB block of device memory the library allocates once per device
+ *                                and serialises concurrent builds of this kind on a mutex.
+ *   anything else                key build -> radix sort -> CSR (+ deg^-1/2, long-row segments) ->
+ *                                exact symmetry test -> S^T only if not symmetric -> tiles
  * `arena` (device, >= gconv_graph_build_bytes, 256-B aligned) receives every output
  * array; it must stay alive as long as `graph_host_out` is used.
- * Synchronises `stream` once (twice for asymmetric edge lists) to return the counters;
- * the LAST launch (the size sort that fills `tiles_fwd.tiles`) is queued on `stream` AFTER that
- * synchronisation and may still be pending when the call returns: consumers on `stream` are
- * ordered behind it by the stream itself, a consumer on ANOTHER stream must first wait for an
- * event recorded on `stream` after this call.
+ * The call waits for the counters (nnz, symmetry, maxima) to reach the host — a stream
+ * synchronisation, or for the one-launch builders a completion mark in pinned memory — so it is
+ * not hipGraph-capturable. The results are ORDERED ON `stream`, not globally complete: the last
+ * launch (the size sort that fills `tiles_fwd.tiles`, or the build kernel's final instructions)
+ * may still be pending when the call returns. Consumers on `stream` are ordered behind it by the
+ * stream itself, a consumer on ANOTHER stream must first wait for an event recorded on `stream`
+ * after this call.
  * Returns GCONV_E_BAD_INDEX if an endpoint is out of range — never a device fault. */
 gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t num_edges,
                                  int32_t num_nodes, int32_t normalize,

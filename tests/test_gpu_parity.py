@@ -1275,3 +1275,97 @@ def test_single_workgroup_graph_build_equals_multi_launch_build(dev, kind, norma
             monkeypatch.setenv("GCONV_NO_SMALL_BUILD", off)
             with pytest.raises(RuntimeError, match="outside"):
                 ga.GraphPlan(bad.to(dev), n, normalize)
+
+
+@pytest.mark.parametrize("normalize", [True, False])
+@pytest.mark.parametrize("kind", ["hiv512", "hiv2000", "random_sym", "dups_and_loops", "directed", "hub", "bad"])
+def test_counting_graph_build_equals_radix_build(dev, kind, normalize, monkeypatch):
+    """Graphs of 4097 .. 262144 nodes are built by COUNTING (five launches: count, scan, fill, row
+    sort, symmetry test + tiles) instead of the radix-sort pipeline; a hub row or a directed list makes
+    the host fall back to it. Every array and counter must equal the radix builder's."""
+    g = torch.Generator().manual_seed(7)
+    if kind == "hiv512":
+        b, _ = ga.synth.make_workload("hiv"); ei, n = b.edge_index, b.num_nodes
+    elif kind == "hiv2000":
+        b, _ = ga.synth.make_workload("hiv", graphs=2000); ei, n = b.edge_index, b.num_nodes
+    elif kind == "random_sym":
+        n = 9000; ei = _random_graph(n, 20000, 51, symmetric=True, loops=False)
+    elif kind == "dups_and_loops":
+        n = 5000; ei = _random_graph(n, 6000, 52, symmetric=True)
+        ei = torch.cat([ei, ei[:, :500], torch.arange(100).repeat(2, 1)], dim=1)     # duplicates, self-loops
+    elif kind == "directed":
+        n = 6000; ei = _random_graph(n, 15000, 53, symmetric=False)
+    elif kind == "hub":
+        n = 7000
+        spokes = torch.stack([torch.randint(1, n, (900,), generator=g), torch.zeros(900, dtype=torch.long)])
+        rnd = torch.stack([torch.randint(n, (5000,), generator=g), torch.randint(n, (5000,), generator=g)])
+        pairs = torch.cat([spokes, rnd], dim=1)
+        ei = torch.cat([pairs, pairs.flip(0)], dim=1)
+    else:
+        n = 5000; ei = _random_graph(n, 9000, 54, symmetric=True); ei[1, 17] = n + 3
+    eid = ei.to(dev)
+    if kind == "bad":
+        for off in ("1", "0"):
+            monkeypatch.setenv("GCONV_NO_COUNTING_BUILD", off)
+            with pytest.raises(RuntimeError, match="outside"):
+                ga.GraphPlan(eid, n, normalize)
+        return
+    plans = []
+    for off in ("1", "0"):
+        monkeypatch.setenv("GCONV_NO_COUNTING_BUILD", off)
+        plans.append(_plan_arrays(ga.GraphPlan(eid, n, normalize)))
+    _same(plans[0], plans[1])
+    rp, col = _numpy_csr(ei.numpy(), n, normalize, False)
+    np.testing.assert_array_equal(plans[1]["fwd"]["rowptr"].numpy(), rp)
+    np.testing.assert_array_equal(plans[1]["fwd"]["col"].numpy()[:rp[-1]], col)
+    if kind == "hub":
+        assert plans[1]["fwd"]["n_long"] >= 1
+    if kind == "directed":
+        assert not plans[1]["symmetric"]
+
+
+@pytest.mark.parametrize("hub_degree", [16, 17])
+def test_counting_graph_build_row_capacity(dev, hub_degree, monkeypatch):
+    """The counting builder keeps a row's edges in 16 slots: a row of exactly 16 is built by it, one of
+    17 makes the host repeat the build on the radix pipeline. Same plan either way."""
+    n = 5000
+    ring = torch.stack([torch.arange(n), (torch.arange(n) + 1) % n])
+    spokes = torch.stack([torch.arange(100, 100 + hub_degree - 2) * 7, torch.full((hub_degree - 2,), 3)])
+    pairs = torch.cat([ring, spokes], dim=1)
+    ei = torch.cat([pairs, pairs.flip(0)], dim=1).to(dev)
+    plans = []
+    for off in ("1", "0"):
+        monkeypatch.setenv("GCONV_NO_COUNTING_BUILD", off)
+        plans.append(_plan_arrays(ga.GraphPlan(ei, n, True)))
+    _same(plans[0], plans[1])
+    assert plans[1]["max_degree"] == hub_degree
+
+
+def test_counting_graph_build_from_two_threads(dev):
+    """The one-launch builder keeps its barrier and counter words in library-owned device memory that
+    must read all zeros between launches; concurrent builds (the collation thread and the training
+    loop) are serialised on a mutex. Two threads, own streams, alternating sizes: every plan equals the
+    one built alone."""
+    import threading
+    batches = [ga.synth.make_workload("hiv", graphs=g)[0] for g in (300, 512)]
+    eis = [b.edge_index.to(dev) for b in batches]
+    want = [_plan_arrays(ga.GraphPlan(ei, b.num_nodes, True)) for ei, b in zip(eis, batches)]
+    errors = []
+
+    def work(k):
+        try:
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(stream):
+                for it in range(25):
+                    j = (it + k) % 2
+                    got = _plan_arrays(ga.GraphPlan(eis[j], batches[j].num_nodes, True))
+                    _same(want[j], got)
+        except Exception as exc:   # noqa: BLE001 - reported by the main thread
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[0]
