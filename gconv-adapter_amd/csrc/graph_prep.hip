@@ -48,7 +48,8 @@ constexpr int kSmallMaxEdges = 4096, kSmallMaxNodes = 4096;   // the single-work
 
 enum {
   INFO_NNZ = 0, INFO_NLONG = 1, INFO_NSEG = 2, INFO_MAXDEG = 3, INFO_BAD = 4,
-  INFO_ASYM = 5, INFO_NOTILE = 6, INFO_TILEMAX = 7, INFO_TILEEDGES = 8, INFO_WORDS = 9
+  INFO_ASYM = 5, INFO_NOTILE = 6, INFO_TILEMAX = 7, INFO_TILEEDGES = 8, INFO_WORDS = 9,
+  INFO_DONE = 10   // completion mark of the one-launch builders (pinned host copy only)
 };
 
 int tile_slack(int T, int n) {
@@ -566,8 +567,16 @@ __global__ __launch_bounds__(T) void small_graph_build_kernel(SmallBuildArgs a) 
     a.tiles_f[rank] = a.recs_f[t];
     if (asym) a.tiles_b[rank] = a.recs_b[t];
   }
+  // counters -> pinned host memory (a.info is the device address of a mapped host buffer): every global
+  // store of the workgroup first, then 63 words, then the completion mark (word INFO_DONE) the host polls
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid < 64) a.info[tid] = sinfo[tid];
+  if (tid < 64) {
+    if (tid != INFO_DONE) a.info[tid] = sinfo[tid];
+    __threadfence_system();
+    if (tid == INFO_DONE) a.info[tid] = 1;
+    __threadfence_system();
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -617,7 +626,6 @@ constexpr int kSpinMax = 1 << 20;
 constexpr int kBarLine = 64;
 constexpr int kStateBar = 0, kStateInfo = (kCountGroups + 2) * kBarLine, kStateChunk = kStateInfo + 64,
               kStateDeg = kStateChunk + kCountGrid, kStateWords = kStateDeg + kCountMaxNodes + 1;
-enum { INFO_DONE = 10 };
 static_assert(kEllWidth <= GCONV_LONG_ROW, "rows of the counting build are never long rows");
 
 struct CountArgs {
@@ -906,12 +914,50 @@ __global__ __launch_bounds__(kCountThreads) void counting_build_kernel(CountArgs
 #undef GCONV_STAMP
 }
 
-// library-owned state of counting_build_kernel, one per device (see the comment above)
+// library-owned state of the one-launch builders, one per device: the pinned words both report into,
+// and counting_build_kernel's device block (see the comment above). Used under `mu`.
 struct CountState {
   std::mutex mu;
   int32_t* state = nullptr;       // device: kStateWords words, zero between launches
   int32_t* host_info = nullptr;   // pinned, mapped: 64 words
-  bool ready = false, broken = false;
+  int32_t* host_info_dev = nullptr;   // its device address
+  bool broken = true;             // the device block must be cleared before its next use
+
+  gconv_status_t ensure(bool device_block) {
+    if (!host_info) {
+      GCONV_HIP(hipHostMalloc(reinterpret_cast<void**>(&host_info), 64 * sizeof(int32_t), hipHostMallocMapped));
+      void* p = nullptr;
+      GCONV_HIP(hipHostGetDevicePointer(&p, host_info, 0));
+      host_info_dev = static_cast<int32_t*>(p);
+    }
+    if (device_block) {
+      if (!state) GCONV_HIP(hipMalloc(reinterpret_cast<void**>(&state), kStateWords * sizeof(int32_t)));
+      if (broken) {   // first use, or a launch that gave up: everything back to zero
+        GCONV_HIP(hipMemset(state, 0, kStateWords * sizeof(int32_t)));
+        broken = false;
+      }
+    }
+    return GCONV_OK;
+  }
+  // Waits for the completion mark in pinned memory, looking at the stream now and then (a kernel that
+  // gave up or faulted never writes it). No stream synchronisation once the mark has arrived: the
+  // kernel is at its last instruction, its results are ordered on `stream` like any kernel's, and the
+  // runtime's completion handling (5 - 6 us, hipStreamQuery as much as hipStreamSynchronize; a D2H
+  // copy of the counters another 4) stays off the build's path. false: no mark.
+  bool wait_mark(hipStream_t stream, int32_t* h) {
+    volatile int32_t* hv = host_info;
+    for (long spins = 0; !hv[INFO_DONE]; ++spins)
+      if ((spins & 1023) == 1023 && hipStreamQuery(stream) != hipErrorNotReady) break;
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (!hv[INFO_DONE]) return false;
+    for (int i = 0; i < 64; ++i) h[i] = hv[i];
+    return true;
+  }
+  void arm() {
+    volatile int32_t* hv = host_info;
+    hv[INFO_DONE] = 0;
+    std::atomic_thread_fence(std::memory_order_release);
+  }
 };
 static CountState* count_state() {
   static CountState states[16];
@@ -1027,7 +1073,13 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
     g->tile_nodes_max = h[INFO_TILEMAX];
     g->tile_edges_max = h[INFO_TILEEDGES];
   };
-  if (small_build_ok(E, n)) {   // ONE launch, ONE synchronisation (see small_graph_build_kernel)
+  CountState* cs_small = small_build_ok(E, n) ? count_state() : nullptr;
+  if (cs_small) {   // ONE launch, counters straight into pinned memory (see small_graph_build_kernel)
+    CountState* cs = cs_small;
+    std::lock_guard<std::mutex> lock(cs->mu);
+    gconv_status_t es = cs->ensure(false);
+    if (es != GCONV_OK) return es;
+    cs->arm();
     SmallBuildArgs a{};
     a.ei = edge_index; a.E = static_cast<int32_t>(E); a.n = n; a.normalize = normalize ? 1 : 0;
     a.shift = index_bits(n); a.ntiles = L.ntiles; a.T = L.T; a.slack = slack;
@@ -1038,7 +1090,7 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
     a.seg_long_f = of.seg_long; a.long_sync_f = of.long_sync;
     a.rowptr_b = ob.rowptr; a.col_b = ob.col; a.long_rows_b = ob.long_rows; a.long_seg_base_b = ob.long_seg_base;
     a.seg_long_b = ob.seg_long; a.long_sync_b = ob.long_sync;
-    a.dis = dis; a.tile_ptr = tile_ptr; a.info = info;
+    a.dis = dis; a.tile_ptr = tile_ptr; a.info = cs->host_info_dev;
     a.recs_f = tf.recs; a.recs_b = tb.recs; a.tiles_f = tf.tiles; a.tiles_b = tb.tiles;
     a.lcol_f = tf.lcol; a.lcol_b = tb.lcol; a.halo_f = tf.halo; a.halo_b = tb.halo;
     const size_t lds = (static_cast<size_t>(a.nsort) + (n + 1) + 2 * static_cast<size_t>(n) + threads +
@@ -1058,8 +1110,10 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
 #undef GCONV_SMALL_BUILD
     GCONV_LAUNCH_CHECK();
     int32_t h[64];
-    GCONV_HIP(hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, stream));
-    GCONV_HIP(hipStreamSynchronize(stream));
+    if (!cs->wait_mark(stream, h)) {
+      GCONV_HIP(hipStreamSynchronize(stream));
+      return static_cast<gconv_status_t>(hipErrorUnknown);   // ended without reporting: cannot happen short of a fault
+    }
     if (h[INFO_BAD]) {
       g->bad_index = 1;
       return GCONV_E_BAD_INDEX;
@@ -1080,42 +1134,23 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
   CountState* cs = counting_build_ok(E, n) ? count_state() : nullptr;
   if (cs) {   // one launch (see counting_build_kernel)
     std::lock_guard<std::mutex> lock(cs->mu);
-    if (!cs->ready) {
-      GCONV_HIP(hipMalloc(reinterpret_cast<void**>(&cs->state), kStateWords * sizeof(int32_t)));
-      GCONV_HIP(hipHostMalloc(reinterpret_cast<void**>(&cs->host_info), 64 * sizeof(int32_t), hipHostMallocMapped));
-      cs->ready = cs->broken = true;
-    }
-    if (cs->broken) {   // first use, or a launch that gave up: everything back to zero
-      GCONV_HIP(hipMemset(cs->state, 0, kStateWords * sizeof(int32_t)));
-      cs->broken = false;
-    }
+    gconv_status_t es = cs->ensure(true);
+    if (es != GCONV_OK) return es;
     CountArgs a{};
     a.ei = edge_index; a.E = E; a.n = n; a.normalize = normalize ? 1 : 0;
     a.state = cs->state;
     a.ell = reinterpret_cast<int32_t*>(arena + L.ell);
     a.rowptr = of.rowptr; a.col = of.col; a.dis = dis;
     a.tile_ptr = tile_ptr; a.lcol = tf.lcol; a.slots = tf.halo; a.recs = tf.recs;
-    void* host_dev = nullptr;
-    GCONV_HIP(hipHostGetDevicePointer(&host_dev, cs->host_info, 0));
-    a.host_info = static_cast<int32_t*>(host_dev);
+    a.host_info = cs->host_info_dev;
     a.ntiles = L.ntiles; a.T = L.T; a.slack = slack; a.fwd = FWD; a.is = is;
-    volatile int32_t* hv = cs->host_info;
-    hv[INFO_DONE] = 0;
+    cs->arm();
     counting_build_kernel<<<kCountGrid, kCountThreads, 0, stream>>>(a);
     GCONV_LAUNCH_CHECK();
-    // Wait on the completion mark in pinned memory, looking at the stream now and then (a kernel that
-    // gave up or faulted never writes it). No stream synchronisation once the mark has arrived: the
-    // kernel is at its last instruction, its results are ordered on `stream` like any kernel's, and the
-    // runtime's completion handling (5 - 6 us, hipStreamQuery as much as hipStreamSynchronize) stays off
-    // the build's path.
-    for (long spins = 0; !hv[INFO_DONE]; ++spins)
-      if ((spins & 1023) == 1023 && hipStreamQuery(stream) != hipErrorNotReady) break;
-    std::atomic_thread_fence(std::memory_order_acquire);
-    if (!hv[INFO_DONE]) GCONV_HIP(hipStreamSynchronize(stream));   // (a fault surfaces here)
-    if (!hv[INFO_DONE]) {
+    if (!cs->wait_mark(stream, h)) {
+      GCONV_HIP(hipStreamSynchronize(stream));   // (a fault surfaces here)
       cs->broken = true;                       // gave up at a barrier: the radix pipeline below does the build
     } else {
-      for (int i = 0; i < 64; ++i) h[i] = hv[i];
 #if GCONV_COUNT_STAMPS
       for (int i = 1; i <= 6; ++i) fprintf(stderr, "%d:%.2f ", i, (h[32 + i] - h[32 + i - 1]) * 0.01);
       fprintf(stderr, "us\n");
