@@ -83,9 +83,29 @@ __global__ __launch_bounds__(256) void gemm_rowsA_kernel(RowsAArgs a) {
   // DEPTH block periods to arrive (one period is shorter than the memory latency under load).
   int blk = blockIdx.x * 4 + wave;
   f32x4 x[DEPTH][NQ];
+  // Epilogue operands (row scale, P rows) travel ONE BLOCK AHEAD like the tiles: vmcnt retires in order
+  // and stores count in it, so a small load issued after a block's `out` stores can only be waited for
+  // by waiting for those stores' acknowledgements first — a write round trip (~2 us) per block and
+  // wave, which is what these kernels spent most of their time on through round 2.
+  float rs[DEPTH][4], pv[DEPTH][NCB][4];
+  auto load_epi = [&](int block, float (&rsv)[4], float (&pvv)[NCB][4]) {
+    const int i0 = block * 16;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int rowc = min(i0 + 4 * kq + m, a.n - 1);
+      rsv[m] = rsp[has_rs ? rowc : 0];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const int cc = min(16 * cb + node, a.fp - 1);
+        pvv[cb][m] = pp[has_p ? static_cast<size_t>(rowc) * a.fp + cc : 0];
+      }
+    }
+  };
 #pragma unroll
   for (int dd = 0; dd < DEPTH; ++dd) {
-    const float* xb = a.X + static_cast<size_t>(min(min(blk + dd * stride, nblk - 1) * 16 + node, a.n - 1)) * a.d;
+    const int b0 = min(blk + dd * stride, nblk - 1);
+    load_epi(b0, rs[dd], pv[dd]);
+    const float* xb = a.X + static_cast<size_t>(min(b0 * 16 + node, a.n - 1)) * a.d;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) x[dd][q] = ldg4(xb + koff[q]);
   }
@@ -98,21 +118,8 @@ __global__ __launch_bounds__(256) void gemm_rowsA_kernel(RowsAArgs a) {
       // the block this ring holds next (clamped: redundant at the tail, never invalid)
       const int nb = min(cur + DEPTH * stride, nblk - 1);
       const float* __restrict__ xn = a.X + static_cast<size_t>(min(nb * 16 + node, a.n - 1)) * a.d;
-      // Epilogue operands of THIS block first: vmcnt retires in order, so a small load issued
-      // after the ring refills could only be waited for by draining the whole prefetch.
-      float rs[4], pv[NCB][4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int rowc = min(i0 + 4 * kq + m, a.n - 1);
-        const float v = rsp[has_rs ? rowc : 0];
-        rs[m] = has_rs ? v : 1.f;
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) {
-          const int cc = min(16 * cb + node, a.fp - 1);
-          const float pvv = pp[has_p ? static_cast<size_t>(rowc) * a.fp + cc : 0];
-          pv[cb][m] = has_p ? pvv : 0.f;
-        }
-      }
+      float rsn[4], pvn[NCB][4];
+      load_epi(nb, rsn, pvn);                      // next block's epilogue operands: ahead of the ring refills
       __builtin_amdgcn_sched_barrier(0);  // keep those loads ahead of the ring refills
       f32x4 acc[NCB][2];
 #pragma unroll
@@ -152,11 +159,17 @@ __global__ __launch_bounds__(256) void gemm_rowsA_kernel(RowsAArgs a) {
           const int row = i0 + 4 * kq + m;
           if (live && row < a.n && c < a.fp) {
             float v = res[m];
-            ds_acc += v * pv[cb][m];
+            ds_acc += v * (has_p ? pv[dd][cb][m] : 0.f);
             if (a.mode == ROWSA_DP) v *= sval;
-            a.out[static_cast<size_t>(row) * a.fp + c] = v * rs[m];
+            a.out[static_cast<size_t>(row) * a.fp + c] = v * (has_rs ? rs[dd][m] : 1.f);
           }
         }
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        rs[dd][m] = rsn[m];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) pv[dd][cb][m] = pvn[cb][m];
       }
     }
     blk += DEPTH * stride;
@@ -401,41 +414,57 @@ __global__ __launch_bounds__(TB) void bwd_main_kernel(BwdMainArgs a, int nchunks
   const int stride = gridDim.x * nslots;
   int blk = blockIdx.x * nslots + slot;
   f32x4 gv[4], xv[4], gn[4], xn[4];
+  // Rank-width operands of a block (T / P rows as MFMA A operands, T fragments for dX). EVERYTHING a
+  // block reads is requested one block ahead, tiles and fragments alike: vmcnt retires in order and
+  // stores count in it, so a fragment load issued after the previous block's dX stores (round 2) could
+  // only be waited for by waiting for those stores' acknowledgements — a write round trip per block and
+  // wave: 7 us per block where the MFMAs take 1.3.
+  float at[4][NCB], ap[4][NCB], ta[NEED_DX ? KS : 1];
+  auto load_frags = [&](int block, float (&atv)[4][NCB], float (&apv)[4][NCB], float (&tav)[NEED_DX ? KS : 1]) {
+    const int i0 = block * 16;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const size_t rb = static_cast<size_t>(min(i0 + 4 * t + m, a.n - 1)) * FP;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const int rc = min(16 * cb + jj, FP - 1);  // rank column this lane feeds as the A row
+        atv[m][cb] = a.T[rb + rc];
+        apv[m][cb] = a.P[rb + rc];
+      }
+    }
+    if constexpr (NEED_DX) load_rank_frag<FP>(a.T, min(i0 + jj, a.n - 1), t, tav);
+  };
   if (blk < nblk) {
+    load_frags(blk, at, ap, ta);
     load_tile_L(a.G, blk * 16, t, a.n, a.d, colbase, colvalid, gv);
     load_tile_L(a.X, blk * 16, t, a.n, a.d, colbase, colvalid, xv);
   }
   while (blk < nblk) {
     const int i0 = blk * 16, nxt = blk + stride;
-    // Rank-width operands of THIS block first (L2-resident, small), the prefetch of the next
-    // block's G / X tiles after them: vmcnt retires in order, so the other way round every
-    // use of a fragment would drain the prefetch.
-    float at[4][NCB], ap[4][NCB];
+    float atn[4][NCB], apn[4][NCB], tan[NEED_DX ? KS : 1];
+    {  // the next block's fragments and G / X tiles (unconditional, clamped block index)
+      const int nc = min(nxt, nblk - 1);
+      load_frags(nc, atn, apn, tan);
+      // (tiles: clamped addresses, NO select here — a select would have to wait for its load on the spot)
+      const int colc = min(colbase, a.d - 4);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int row = i0 + 4 * t + m;
-      const size_t rb = static_cast<size_t>(min(row, a.n - 1)) * FP;
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) {
-        const int rc = 16 * cb + jj;  // rank column this lane feeds as the A row
-        const float vt = a.T[rb + min(rc, FP - 1)], vp = a.P[rb + min(rc, FP - 1)];
-        const bool ok = row < a.n && rc < FP;
-        at[m][cb] = ok ? vt : 0.f;
-        ap[m][cb] = ok ? vp : 0.f;
+      for (int m = 0; m < 4; ++m) {
+        const size_t ro = static_cast<size_t>(min(nc * 16 + 4 * t + m, a.n - 1)) * a.d + colc;
+        gn[m] = ldg4(a.G + ro);
+        xn[m] = ldg4(a.X + ro);
       }
     }
-    float ta[KS];
-    if constexpr (NEED_DX) load_rank_frag<FP>(a.T, min(i0 + jj, a.n - 1), t, ta);
-    __builtin_amdgcn_sched_barrier(0);  // keep the fragment loads ahead of the prefetch
-    {  // prefetch the next block's G and X tiles (unconditional, clamped block index)
-      const int nc = min(nxt, nblk - 1);
-      load_tile_L(a.G, nc * 16, t, a.n, a.d, colbase, colvalid, gn);
-      load_tile_L(a.X, nc * 16, t, a.n, a.d, colbase, colvalid, xn);
+    __builtin_amdgcn_sched_barrier(0);  // requests first, then this block's MFMAs and stores
+    // rows / rank columns past the end contribute zeros (the loads above were clamped)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const bool ok = i0 + 4 * t + m < a.n && 16 * cb + jj < FP;
+        at[m][cb] = ok ? at[m][cb] : 0.f;
+        ap[m][cb] = ok ? ap[m][cb] : 0.f;
+      }
     }
-    // (hipcc sinks these eight loads below most of the block's ~90 MFMAs. Pinning them ahead of
-    // the burst with a second sched_barrier was measured in round 2: 72.7 -> 87.4 us at S-arxiv —
-    // the loads then share the issue window with the fragment loads above and the dX stores of
-    // the previous block queue behind them; left to the compiler.)
 
     // contraction over the 16 nodes: k-step m covers nodes i0 + 4 t + m
 #pragma unroll
@@ -473,7 +502,17 @@ __global__ __launch_bounds__(TB) void bwd_main_kernel(BwdMainArgs a, int nchunks
       }
     }
 #pragma unroll
-    for (int m = 0; m < 4; ++m) { gv[m] = gn[m]; xv[m] = xn[m]; }
+    for (int m = 0; m < 4; ++m) {
+      const bool ok = colvalid && nxt * 16 + 4 * t + m < a.n;   // (nxt >= nblk: the loop ends, values unused)
+      gv[m] = ok ? gn[m] : f32x4{0.f, 0.f, 0.f, 0.f};
+      xv[m] = ok ? xn[m] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) { at[m][cb] = atn[m][cb]; ap[m][cb] = apn[m][cb]; }
+    }
+    if constexpr (NEED_DX) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) ta[s] = tan[s];
+    }
     blk = nxt;
   }
 

@@ -7,6 +7,6 @@ OUT=${1:-gpurun_out/pmc_mfma}
 ROOT=$(pwd)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d "$ROOT/$OUT/sq" -- python3 "$ROOT/tools/arxiv_adapter_only.py" > "$ROOT/$OUT/sq.log" 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$ROOT/$OUT/sq" -- python3 "$ROOT/tools/arxiv_adapter_only.py" > "$ROOT/$OUT/sq.log" 2>&1
 cd "$ROOT"
 python3 tools/pmc_mfma.py "$OUT"
