@@ -16,10 +16,24 @@ from .gin import MolecularGINConv
 from .norm import BatchNorm1d
 from .relbias import add_conv_relational_bias
 
+
+
+def register_ops():
+    """Loads the C++ binding (if it is not loaded yet) and returns ``torch.ops.gconv``: the torch custom
+    ops ``graph_plan``, ``graph_prep``, ``adapter_fwd``, ``adapter_bwd``, ``adapter`` (differentiable)
+    and ``spmm`` (csrc/torch_binding.cpp, TORCH_LIBRARY(gconv, ...)). Raises if the binding is not
+    built or disabled (GCONV_PY_BINDING=1)."""
+    import torch
+    if _torch_ext.get() is None:
+        raise RuntimeError("gconv_adapter_amd: lib/_gconv_torch.so is not built (python -c 'import __graft_entry__ as g; "
+                           "g.build()') or GCONV_PY_BINDING is set")
+    return torch.ops.gconv
+
+
 __all__ = [
     "GConvAdapter", "GCNConvParams", "GConvAdapterFunction", "gconv_adapter", "spmm",
     "gemm_down", "gemm_up_fused", "GraphPlan", "PlanCache", "PLAN_CACHE", "get_plan", "prefetch_plan",
     "instantiate", "load_finetune_config", "synth", "dist", "optim", "FusedAdam", "data", "MoleculeStore",
     "partition", "RowSlabGConvAdapter", "RowSlabs", "gin", "MolecularGINConv", "norm", "BatchNorm1d",
-    "relbias", "add_conv_relational_bias",
+    "relbias", "add_conv_relational_bias", "register_ops",
 ]

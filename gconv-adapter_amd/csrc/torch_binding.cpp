@@ -12,6 +12,7 @@
 // `conv_up(act_fn(conv_down(x, ei)), ei)` (/root/reference/src/finetune/gconv_adapter.py:92).
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
+#include <c10/hip/HIPStream.h>
 #include <torch/csrc/autograd/engine.h>
 #include <torch/extension.h>
 
@@ -52,6 +53,11 @@ using ln_bwd_fn_t = gconv_status_t (*)(const float*, const float*, const float*,
                                        const float*, float*, float*, float*, float*, int32_t, int32_t, void*,
                                        size_t, gconv_stream_t);
 using ln_bytes_fn_t = size_t (*)(int32_t, int32_t);
+using rank_fn_t = int32_t (*)(int32_t);
+using ws_fn_t = size_t (*)(const gconv_graph_t*, int32_t, int32_t);
+using spmm_ws_fn_t = size_t (*)(const gconv_csr_t*, int32_t);
+using spmm_fn_t = gconv_status_t (*)(const gconv_csr_t*, const float*, const float*, float*, int32_t, const float*,
+                                     int32_t, uint32_t, void*, size_t, gconv_stream_t);
 
 struct Lib {
   void* handle = nullptr;
@@ -65,6 +71,10 @@ struct Lib {
   ln_fwd_fn_t ln_fwd = nullptr;
   ln_bwd_fn_t ln_bwd = nullptr;
   ln_bytes_fn_t ln_bytes = nullptr;
+  rank_fn_t padded_rank = nullptr;
+  ws_fn_t ws_fwd = nullptr, ws_bwd = nullptr;
+  spmm_ws_fn_t spmm_ws = nullptr;
+  spmm_fn_t spmm = nullptr;
 };
 Lib g_lib;
 
@@ -82,8 +92,14 @@ void load_library(const std::string& path) {
   g_lib.ln_fwd = reinterpret_cast<ln_fwd_fn_t>(dlsym(h, "gconv_layer_norm_scale_fwd_f32"));
   g_lib.ln_bwd = reinterpret_cast<ln_bwd_fn_t>(dlsym(h, "gconv_layer_norm_scale_bwd_f32"));
   g_lib.ln_bytes = reinterpret_cast<ln_bytes_fn_t>(dlsym(h, "gconv_layer_norm_scale_bwd_workspace_bytes"));
+  g_lib.padded_rank = reinterpret_cast<rank_fn_t>(dlsym(h, "gconv_padded_rank"));
+  g_lib.ws_fwd = reinterpret_cast<ws_fn_t>(dlsym(h, "gconv_adapter_fwd_workspace_bytes"));
+  g_lib.ws_bwd = reinterpret_cast<ws_fn_t>(dlsym(h, "gconv_adapter_bwd_workspace_bytes"));
+  g_lib.spmm_ws = reinterpret_cast<spmm_ws_fn_t>(dlsym(h, "gconv_spmm_workspace_bytes"));
+  g_lib.spmm = reinterpret_cast<spmm_fn_t>(dlsym(h, "gconv_spmm_csr_f32"));
   TORCH_CHECK(g_lib.fwd && g_lib.bwd && g_lib.str && g_lib.build_bytes && g_lib.build && g_lib.bwd_partial &&
-                  g_lib.bwd_finalize && g_lib.ln_fwd && g_lib.ln_bwd && g_lib.ln_bytes,
+                  g_lib.bwd_finalize && g_lib.ln_fwd && g_lib.ln_bwd && g_lib.ln_bytes && g_lib.padded_rank &&
+                  g_lib.ws_fwd && g_lib.ws_bwd && g_lib.spmm_ws && g_lib.spmm,
               "gconv_adapter_amd: C ABI symbols missing in ", path);
   g_lib.handle = h;
 }
@@ -765,6 +781,232 @@ at::Tensor layer_norm_scale(at::Tensor z, c10::optional<at::Tensor> gamma, c10::
 }
 
 }  // namespace
+
+// ---------------------------------------------------------------------------------------
+// torch custom ops: `torch.ops.gconv.*`. The dispatcher-visible surface of the
+// same C ABI calls, for callers that want the pieces rather than the nn.Module — isolated
+// benchmarking (`spmm`), a maintainer wiring the adapter into their own autograd code
+// (`adapter_fwd` / `adapter_bwd`), torch.library tooling. The module's fast path above stays on
+// pybind (a dispatcher round trip is ~2 us of a ~10 us host path) and computes the same numbers:
+// both end in gconv_adapter_fwd_f32 / gconv_adapter_bwd_f32.
+//
+// A graph travels as two tensors: `arena` (uint8, device: every array of the plan) and `plan`
+// (uint8, CPU: the gconv_graph_t whose pointers point into the arena). Keep them together.
+// ---------------------------------------------------------------------------------------
+namespace ops {
+
+int64_t act_code(const std::string& act) {
+  if (act == "none") return GCONV_ACT_NONE;
+  if (act == "relu") return GCONV_ACT_RELU;
+  if (act == "silu" || act == "swish") return GCONV_ACT_SILU;
+  TORCH_CHECK(false, "gconv: non_linearity must be one of none / relu / silu (swish), got '", act, "'");
+}
+
+// torch's current stream on the tensor's device, as the hipStream_t the C ABI takes
+void* current_stream(const at::Tensor& t) {
+  return c10::hip::getCurrentHIPStream(static_cast<c10::DeviceIndex>(t.get_device())).stream();
+}
+
+gconv_graph_t plan_struct(const at::Tensor& arena, const at::Tensor& plan) {
+  TORCH_CHECK(plan.device().is_cpu() && plan.scalar_type() == at::kByte && plan.is_contiguous() &&
+                  plan.numel() == static_cast<int64_t>(sizeof(gconv_graph_t)),
+              "gconv: `plan` must be the CPU uint8 tensor returned by gconv::graph_plan");
+  TORCH_CHECK(arena.is_cuda() && arena.scalar_type() == at::kByte, "gconv: `arena` must be the device tensor "
+              "returned by gconv::graph_plan");
+  gconv_graph_t g;
+  std::memcpy(&g, plan.data_ptr(), sizeof(g));
+  const char* lo = static_cast<const char*>(arena.data_ptr());
+  const char* rp = reinterpret_cast<const char*>(g.fwd.rowptr);
+  TORCH_CHECK(rp >= lo && rp < lo + arena.numel(), "gconv: `plan` does not belong to this `arena`");
+  return g;
+}
+
+// graph_plan(edge_index, num_nodes, normalize) -> (arena, plan)
+std::tuple<at::Tensor, at::Tensor> graph_plan(const at::Tensor& edge_index, int64_t num_nodes, bool normalize) {
+  TORCH_CHECK(g_lib.handle, "gconv_adapter_amd: library not loaded");
+  TORCH_CHECK(edge_index.dim() == 2 && edge_index.size(0) == 2, "edge_index must have shape [2, num_edges]");
+  TORCH_CHECK(edge_index.scalar_type() == at::kLong, "edge_index must be int64 (PyG convention)");
+  TORCH_CHECK(edge_index.is_cuda(), "gconv_adapter_amd has no CPU path: edge_index must live on a HIP device");
+  const at::Tensor ei = edge_index.contiguous();
+  const int64_t e = ei.size(1);
+  const size_t bytes = g_lib.build_bytes(e, static_cast<int32_t>(num_nodes));
+  at::Tensor arena = at::empty({static_cast<int64_t>(bytes)}, ei.options().dtype(at::kByte));
+  at::Tensor plan = at::empty({static_cast<int64_t>(sizeof(gconv_graph_t))}, at::TensorOptions().dtype(at::kByte));
+  gconv_graph_t g;
+  std::memset(&g, 0, sizeof(g));
+  c10::OptionalDeviceGuard guard(ei.device());
+  check(g_lib.build(ei.data_ptr<int64_t>(), e, static_cast<int32_t>(num_nodes), normalize ? 1 : 0, arena.data_ptr(),
+                    bytes, &g, current_stream(ei)),
+        "graph_build");
+  std::memcpy(plan.data_ptr(), &g, sizeof(g));
+  return {arena, plan};
+}
+
+at::Tensor arena_view(const at::Tensor& arena, const void* ptr, int64_t count, at::ScalarType dt) {
+  if (ptr == nullptr || count <= 0) return at::empty({0}, arena.options().dtype(dt));
+  const int64_t off = static_cast<const char*>(ptr) - static_cast<const char*>(arena.data_ptr());
+  const int64_t isz = static_cast<int64_t>(c10::elementSize(dt));
+  TORCH_CHECK(off >= 0 && off + count * isz <= arena.numel(), "gconv: plan array outside its arena");
+  return arena.narrow(0, off, count * isz).view(dt);
+}
+
+// graph_prep(edge_index, num_nodes, normalize) -> (rowptr, col, dis, symmetric, rowptr_t, col_t):
+// the CSR of S (in-edges per target row, columns ascending, self-loops dropped when normalising),
+// deg^-1/2 (empty when not normalising), the exact symmetry flag and — for directed edge lists —
+// the CSR of S^T (empty when symmetric: S^T == S). Views into one arena.
+std::tuple<at::Tensor, at::Tensor, at::Tensor, bool, at::Tensor, at::Tensor> graph_prep(const at::Tensor& edge_index,
+                                                                                      int64_t num_nodes,
+                                                                                      bool normalize) {
+  auto [arena, plan] = graph_plan(edge_index, num_nodes, normalize);
+  gconv_graph_t g;
+  std::memcpy(&g, plan.data_ptr(), sizeof(g));
+  const int64_t n = g.fwd.num_nodes;
+  at::Tensor rowptr = arena_view(arena, g.fwd.rowptr, n + 1, at::kInt), col = arena_view(arena, g.fwd.col, g.fwd.nnz, at::kInt);
+  at::Tensor dis = arena_view(arena, g.dis, g.dis ? n : 0, at::kFloat);
+  at::Tensor rowptr_t = arena_view(arena, g.symmetric ? nullptr : g.bwd.rowptr, n + 1, at::kInt);
+  at::Tensor col_t = arena_view(arena, g.symmetric ? nullptr : g.bwd.col, g.bwd.nnz, at::kInt);
+  return {rowptr, col, dis, g.symmetric != 0, rowptr_t, col_t};
+}
+
+struct Shapes { int64_t n, d, r, fp; };
+Shapes check_adapter_args(const gconv_graph_t& g, const at::Tensor& x, const at::Tensor& w_down, const at::Tensor& w_up) {
+  TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.dim() == 2,
+              "gconv computes in fp32 on a HIP device (no CPU path); x must be [N, d]");
+  TORCH_CHECK(w_down.dim() == 2 && w_up.dim() == 2 && w_down.size(1) == x.size(1) && w_up.size(0) == x.size(1) &&
+                  w_up.size(1) == w_down.size(0),
+              "gconv: conv_down.lin.weight is [r, d], conv_up.lin.weight is [d, r]");
+  TORCH_CHECK(x.size(0) == g.fwd.num_nodes, "x has ", x.size(0), " nodes but the graph plan was built for ", g.fwd.num_nodes);
+  const int64_t fp = g_lib.padded_rank(static_cast<int32_t>(w_down.size(0)));
+  TORCH_CHECK(fp > 0, "bottleneck_size=", w_down.size(0), " is unsupported (1..64)");
+  return {x.size(0), x.size(1), w_down.size(0), fp};
+}
+
+// adapter_fwd(x, w_down, b_down?, w_up, b_up?, scalar?, arena, plan, act, skip) -> (out, saved):
+// saved = [2 or 3, N, Fp]: H (post-activation, pre-scaled), P, and with SiLU the pre-activation H1
+std::tuple<at::Tensor, at::Tensor> adapter_fwd(const at::Tensor& x_, const at::Tensor& w_down_,
+                                               const c10::optional<at::Tensor>& b_down_, const at::Tensor& w_up_,
+                                               const c10::optional<at::Tensor>& b_up_,
+                                               const c10::optional<at::Tensor>& scalar_, const at::Tensor& arena,
+                                               const at::Tensor& plan, std::string act_, bool skip) {
+  TORCH_CHECK(g_lib.handle, "gconv_adapter_amd: library not loaded");
+  const gconv_graph_t g = plan_struct(arena, plan);
+  const at::Tensor x = x_.contiguous(), w_down = w_down_.contiguous(), w_up = w_up_.contiguous();
+  const at::Tensor b_down = b_down_.value_or(at::Tensor()), b_up = b_up_.value_or(at::Tensor()),
+                   scalar = scalar_.value_or(at::Tensor());
+  const Shapes sh = check_adapter_args(g, x, w_down, w_up);
+  const int64_t act = act_code(act_);
+  at::Tensor out = at::empty_like(x);
+  at::Tensor saved = at::empty({act == GCONV_ACT_SILU ? 3 : 2, sh.n, sh.fp}, x.options());
+  const size_t wsb = std::max<size_t>(g_lib.ws_fwd(&g, static_cast<int32_t>(sh.d), static_cast<int32_t>(sh.r)), 16);
+  at::Tensor ws = at::empty({static_cast<int64_t>(wsb)}, x.options().dtype(at::kByte));
+  float* sv = saved.data_ptr<float>();
+  gconv_adapter_params_t p{fptr(w_down), fptr(b_down), fptr(w_up), fptr(b_up), fptr(scalar), static_cast<int32_t>(sh.d),
+                           static_cast<int32_t>(sh.r), static_cast<int32_t>(act), skip ? 1 : 0};
+  c10::OptionalDeviceGuard guard(x.device());
+  check(g_lib.fwd(&g, &p, x.data_ptr<float>(), out.data_ptr<float>(), sv,
+                  act == GCONV_ACT_SILU ? sv + 2 * sh.n * sh.fp : nullptr, sv + sh.n * sh.fp, ws.data_ptr(), wsb,
+                  current_stream(x)),
+        "adapter_fwd");
+  return {out, saved};
+}
+
+// adapter_bwd(grad_out, x, saved, w_down, w_up, b_up?, scalar?, arena, plan, act, skip, needs_dx)
+//   -> (dx, dw_down, db_down, dw_up, db_up, dscalar); dx is empty when !needs_dx, dscalar when scalar is None
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> adapter_bwd(
+    const at::Tensor& grad_out, const at::Tensor& x_, const at::Tensor& saved, const at::Tensor& w_down_,
+    const at::Tensor& w_up_, const c10::optional<at::Tensor>& b_up_, const c10::optional<at::Tensor>& scalar_,
+    const at::Tensor& arena, const at::Tensor& plan, std::string act_, bool skip, bool needs_dx) {
+  TORCH_CHECK(g_lib.handle, "gconv_adapter_amd: library not loaded");
+  const gconv_graph_t g = plan_struct(arena, plan);
+  const at::Tensor x = x_.contiguous(), w_down = w_down_.contiguous(), w_up = w_up_.contiguous(),
+                   go = grad_out.contiguous();
+  const at::Tensor b_up = b_up_.value_or(at::Tensor()), scalar = scalar_.value_or(at::Tensor());
+  const Shapes sh = check_adapter_args(g, x, w_down, w_up);
+  const int64_t act = act_code(act_);
+  TORCH_CHECK(go.is_cuda() && go.scalar_type() == at::kFloat && go.sizes() == x.sizes(),
+              "gconv: grad_out must be an fp32 HIP tensor of x's shape");
+  TORCH_CHECK(saved.is_cuda() && saved.is_contiguous() && saved.dim() == 3 && saved.size(0) == (act == GCONV_ACT_SILU ? 3 : 2) &&
+                  saved.size(1) == sh.n && saved.size(2) == sh.fp,
+              "gconv: `saved` is not what gconv::adapter_fwd returned for these arguments");
+  at::Tensor dx = needs_dx ? at::empty_like(x) : at::empty({0}, x.options());
+  at::Tensor dwd = at::empty_like(w_down), dwu = at::empty_like(w_up);
+  at::Tensor dbd = at::empty({sh.r}, x.options()), dbu = at::empty({sh.d}, x.options());
+  at::Tensor ds = scalar.defined() ? at::empty_like(scalar) : at::empty({0}, x.options());
+  const size_t wsb = std::max<size_t>(g_lib.ws_bwd(&g, static_cast<int32_t>(sh.d), static_cast<int32_t>(sh.r)), 16);
+  at::Tensor ws = at::empty({static_cast<int64_t>(wsb)}, x.options().dtype(at::kByte));
+  const float* svp = saved.data_ptr<float>();
+  gconv_adapter_params_t p{fptr(w_down), nullptr, fptr(w_up), fptr(b_up), fptr(scalar), static_cast<int32_t>(sh.d),
+                           static_cast<int32_t>(sh.r), static_cast<int32_t>(act), skip ? 1 : 0};
+  c10::OptionalDeviceGuard guard(x.device());
+  check(g_lib.bwd(&g, &p, x.data_ptr<float>(), go.data_ptr<float>(), svp,
+                  act == GCONV_ACT_SILU ? svp + 2 * sh.n * sh.fp : nullptr, svp + sh.n * sh.fp,
+                  needs_dx ? dx.data_ptr<float>() : nullptr, dwd.data_ptr<float>(), dbd.data_ptr<float>(),
+                  dwu.data_ptr<float>(), dbu.data_ptr<float>(), scalar.defined() ? ds.data_ptr<float>() : nullptr,
+                  ws.data_ptr(), wsb, current_stream(x)),
+        "adapter_bwd");
+  return {dx, dwd, dbd, dwu, dbu, ds};
+}
+
+// spmm(arena, plan, h, transpose) -> S h (or S^T h): h is [N, width], width in {4, 8, 16, 32, 64}
+at::Tensor spmm(const at::Tensor& arena, const at::Tensor& plan, const at::Tensor& h_, bool transpose) {
+  TORCH_CHECK(g_lib.handle, "gconv_adapter_amd: library not loaded");
+  const gconv_graph_t g = plan_struct(arena, plan);
+  const at::Tensor h = h_.contiguous();
+  TORCH_CHECK(h.is_cuda() && h.scalar_type() == at::kFloat && h.dim() == 2 && h.size(0) == g.fwd.num_nodes,
+              "gconv::spmm: h must be an fp32 HIP tensor [num_nodes, width]");
+  const gconv_csr_t* csr = transpose ? &g.bwd : &g.fwd;
+  const int32_t width = static_cast<int32_t>(h.size(1));
+  at::Tensor y = at::empty_like(h);
+  const size_t wsb = std::max<size_t>(g_lib.spmm_ws(csr, width), 16);
+  at::Tensor ws = at::empty({static_cast<int64_t>(wsb)}, h.options().dtype(at::kByte));
+  c10::OptionalDeviceGuard guard(h.device());
+  check(g_lib.spmm(csr, g.dis, h.data_ptr<float>(), y.data_ptr<float>(), width, nullptr, GCONV_ACT_NONE, 0u,
+                   ws.data_ptr(), wsb, current_stream(h)),
+        "spmm");
+  return y;
+}
+
+// adapter(...) -> out, differentiable: the autograd node is AdapterFn (the same one the module's
+// non-direct path uses)
+at::Tensor adapter(const at::Tensor& x, const at::Tensor& w_down, const c10::optional<at::Tensor>& b_down,
+                   const at::Tensor& w_up, const c10::optional<at::Tensor>& b_up,
+                   const c10::optional<at::Tensor>& scalar, const at::Tensor& arena, const at::Tensor& plan,
+                   std::string act_, bool skip) {
+  TORCH_CHECK(g_lib.handle, "gconv_adapter_amd: library not loaded");
+  const gconv_graph_t g = plan_struct(arena, plan);
+  const Shapes sh = check_adapter_args(g, x, w_down, w_up);
+  const int64_t wsf = std::max<int64_t>(g_lib.ws_fwd(&g, static_cast<int32_t>(sh.d), static_cast<int32_t>(sh.r)), 16);
+  const int64_t wsb = std::max<int64_t>(g_lib.ws_bwd(&g, static_cast<int32_t>(sh.d), static_cast<int32_t>(sh.r)), 16);
+  c10::OptionalDeviceGuard guard(x.device());
+  return AdapterFn::apply(x, w_down, b_down, w_up, b_up, scalar, arena, reinterpret_cast<int64_t>(plan.data_ptr()),
+                          sh.fp, wsf, wsb, act_code(act_), skip, reinterpret_cast<int64_t>(current_stream(x)));
+}
+
+}  // namespace ops
+
+TORCH_LIBRARY(gconv, m) {
+  m.def("graph_plan(Tensor edge_index, int num_nodes, bool normalize) -> (Tensor arena, Tensor plan)");
+  m.def("graph_prep(Tensor edge_index, int num_nodes, bool normalize) -> (Tensor rowptr, Tensor col, Tensor dis, "
+        "bool symmetric, Tensor rowptr_t, Tensor col_t)");
+  m.def("adapter_fwd(Tensor x, Tensor w_down, Tensor? b_down, Tensor w_up, Tensor? b_up, Tensor? scalar, Tensor arena, "
+        "Tensor plan, str act, bool skip) -> (Tensor out, Tensor saved)");
+  m.def("adapter_bwd(Tensor grad_out, Tensor x, Tensor saved, Tensor w_down, Tensor w_up, Tensor? b_up, Tensor? scalar, "
+        "Tensor arena, Tensor plan, str act, bool skip, bool needs_dx) -> (Tensor dx, Tensor dw_down, Tensor db_down, "
+        "Tensor dw_up, Tensor db_up, Tensor dscalar)");
+  m.def("spmm(Tensor arena, Tensor plan, Tensor h, bool transpose) -> Tensor");
+  m.def("adapter(Tensor x, Tensor w_down, Tensor? b_down, Tensor w_up, Tensor? b_up, Tensor? scalar, Tensor arena, "
+        "Tensor plan, str act, bool skip) -> Tensor");
+}
+// (catch-all registrations: the kernels check the devices themselves and `plan` is a CPU tensor among
+// device tensors; `adapter` builds its own autograd node)
+TORCH_LIBRARY_IMPL(gconv, CatchAll, m) {
+  m.impl("graph_plan", &ops::graph_plan);
+  m.impl("graph_prep", &ops::graph_prep);
+  m.impl("adapter_fwd", &ops::adapter_fwd);
+  m.impl("adapter_bwd", &ops::adapter_bwd);
+  m.impl("spmm", &ops::spmm);
+  m.impl("adapter", &ops::adapter);
+}
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "C++ autograd bridge to the gconv_adapter C ABI + native graph-plan prefetch worker";
