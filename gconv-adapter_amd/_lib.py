@@ -94,7 +94,8 @@ class PendingFinalize(C.Structure):
 
 
 FINALIZE_BATCH = 5
-ABI_VERSION = 6   # GCONV_ABI_VERSION of include/gconv_adapter.h this binding was written against
+BUILD_BACKGROUND = 1   # GCONV_BUILD_BACKGROUND
+ABI_VERSION = 7   # GCONV_ABI_VERSION of include/gconv_adapter.h this binding was written against
 
 
 class AdapterParams(C.Structure):
@@ -125,6 +126,7 @@ SIGNATURES = {
     "gconv_tile_nodes": (_i32, [_i32]),
     "gconv_graph_build_bytes": (_sz, [_i64, _i32]),
     "gconv_graph_build": (_i32, [_vp, _i64, _i32, _i32, _vp, _sz, _graph_p, _vp]),
+    "gconv_graph_build_ex": (_i32, [_vp, _i64, _i32, _i32, _u32, _vp, _sz, _graph_p, _vp]),
     "gconv_spmm_workspace_bytes": (_sz, [_csr_p, _i32]),
     "gconv_spmm_csr_f32": (_i32, [_csr_p, _vp, _vp, _vp, _i32, _vp, _i32, _u32, _vp, _sz, _vp]),
     "gconv_gemm_down_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),

@@ -1025,6 +1025,13 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
                                             int32_t num_nodes, int32_t normalize, void* arena_,
                                             size_t arena_bytes, gconv_graph_t* g,
                                             gconv_stream_t stream_) {
+  return gconv_graph_build_ex(edge_index, num_edges, num_nodes, normalize, 0u, arena_, arena_bytes, g, stream_);
+}
+
+extern "C" gconv_status_t gconv_graph_build_ex(const int64_t* edge_index, int64_t num_edges,
+                                               int32_t num_nodes, int32_t normalize, uint32_t flags,
+                                               void* arena_, size_t arena_bytes, gconv_graph_t* g,
+                                               gconv_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (num_edges < 0 || num_nodes < 0 || !arena_ || !g) return GCONV_E_INVALID_ARG;
   if (num_edges > 0 && !edge_index) return GCONV_E_INVALID_ARG;
@@ -1131,7 +1138,8 @@ extern "C" gconv_status_t gconv_graph_build(const int64_t* edge_index, int64_t n
 
   const int T = 256;
   int32_t h[64];
-  CountState* cs = counting_build_ok(E, n) ? count_state() : nullptr;
+  // (GCONV_BUILD_BACKGROUND: no grid-wide launch next to the caller's other kernels — see the header)
+  CountState* cs = counting_build_ok(E, n) && !(flags & GCONV_BUILD_BACKGROUND) ? count_state() : nullptr;
   if (cs) {   // one launch (see counting_build_kernel)
     std::lock_guard<std::mutex> lock(cs->mu);
     gconv_status_t es = cs->ensure(true);

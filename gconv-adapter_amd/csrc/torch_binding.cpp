@@ -42,6 +42,8 @@ using str_fn_t = const char* (*)(gconv_status_t);
 using bytes_fn_t = size_t (*)(int64_t, int32_t);
 using build_fn_t = gconv_status_t (*)(const int64_t*, int64_t, int32_t, int32_t, void*, size_t,
                                       gconv_graph_t*, gconv_stream_t);
+using build_ex_fn_t = gconv_status_t (*)(const int64_t*, int64_t, int32_t, int32_t, uint32_t, void*, size_t,
+                                         gconv_graph_t*, gconv_stream_t);
 using bwd_partial_fn_t = gconv_status_t (*)(const gconv_graph_t*, const gconv_adapter_params_t*,
                                             const float*, const float*, const float*, const float*,
                                             const float*, float*, float*, float*, float*, float*, float*,
@@ -66,6 +68,7 @@ struct Lib {
   str_fn_t str = nullptr;
   bytes_fn_t build_bytes = nullptr;
   build_fn_t build = nullptr;
+  build_ex_fn_t build_ex = nullptr;
   bwd_partial_fn_t bwd_partial = nullptr;
   bwd_finalize_fn_t bwd_finalize = nullptr;
   ln_fwd_fn_t ln_fwd = nullptr;
@@ -87,6 +90,7 @@ void load_library(const std::string& path) {
   g_lib.str = reinterpret_cast<str_fn_t>(dlsym(h, "gconv_status_string"));
   g_lib.build_bytes = reinterpret_cast<bytes_fn_t>(dlsym(h, "gconv_graph_build_bytes"));
   g_lib.build = reinterpret_cast<build_fn_t>(dlsym(h, "gconv_graph_build"));
+  g_lib.build_ex = reinterpret_cast<build_ex_fn_t>(dlsym(h, "gconv_graph_build_ex"));
   g_lib.bwd_partial = reinterpret_cast<bwd_partial_fn_t>(dlsym(h, "gconv_adapter_bwd_partial_f32"));
   g_lib.bwd_finalize = reinterpret_cast<bwd_finalize_fn_t>(dlsym(h, "gconv_adapter_bwd_finalize_f32"));
   g_lib.ln_fwd = reinterpret_cast<ln_fwd_fn_t>(dlsym(h, "gconv_layer_norm_scale_fwd_f32"));
@@ -99,7 +103,7 @@ void load_library(const std::string& path) {
   g_lib.spmm = reinterpret_cast<spmm_fn_t>(dlsym(h, "gconv_spmm_csr_f32"));
   TORCH_CHECK(g_lib.fwd && g_lib.bwd && g_lib.str && g_lib.build_bytes && g_lib.build && g_lib.bwd_partial &&
                   g_lib.bwd_finalize && g_lib.ln_fwd && g_lib.ln_bwd && g_lib.ln_bytes && g_lib.padded_rank &&
-                  g_lib.ws_fwd && g_lib.ws_bwd && g_lib.spmm_ws && g_lib.spmm,
+                  g_lib.ws_fwd && g_lib.ws_bwd && g_lib.spmm_ws && g_lib.spmm && g_lib.build_ex,
               "gconv_adapter_amd: C ABI symbols missing in ", path);
   g_lib.handle = h;
 }
@@ -693,8 +697,10 @@ class PlanWorker {
       hipStream_t side = static_cast<hipStream_t>(job->side_stream);
       gconv_status_t st = static_cast<gconv_status_t>(hipStreamWaitEvent(side, job->ready, 0));
       if (st == 0)
-        st = g_lib.build(job->edge_index.data_ptr<int64_t>(), job->num_edges, job->num_nodes, job->normalize,
-                         job->arena.data_ptr(), static_cast<size_t>(job->arena.numel()), &job->graph, side);
+        // (a prefetched plan is built next to the step's kernels: no grid-wide launch)
+        st = g_lib.build_ex(job->edge_index.data_ptr<int64_t>(), job->num_edges, job->num_nodes, job->normalize,
+                            GCONV_BUILD_BACKGROUND, job->arena.data_ptr(), static_cast<size_t>(job->arena.numel()),
+                            &job->graph, side);
       if (st == 0) st = static_cast<gconv_status_t>(hipEventRecord(job->built, side));
       {
         std::lock_guard<std::mutex> lk(mu_);

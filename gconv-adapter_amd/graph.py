@@ -74,7 +74,10 @@ class GraphPlan:
     """Everything the kernels need to apply S and S^T for one ``edge_index``:
     ONE ``gconv_graph_build`` call, ONE device allocation (the arena)."""
 
-    def __init__(self, edge_index: torch.Tensor, num_nodes: int, normalize: bool, _built=None):
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, normalize: bool, _built=None,
+                 background: bool = False):
+        """``background``: the build runs on a side stream next to other kernels (GCONV_BUILD_BACKGROUND:
+        no grid-wide launch — see include/gconv_adapter.h)."""
         _check_edge_index(edge_index)
         lib = _lib.load()
         ei = edge_index if edge_index.is_contiguous() else edge_index.contiguous()
@@ -99,9 +102,10 @@ class GraphPlan:
             guard = torch.cuda.device(ei.device) if ei.device.index != torch.cuda.current_device() else _NO_GUARD
             with guard:
                 self.arena = torch.empty(nbytes, dtype=torch.uint8, device=ei.device)
-                st = lib.gconv_graph_build(ei.data_ptr(), self.num_edges, self.num_nodes,
-                                           int(self.normalize), self.arena.data_ptr(), nbytes,
-                                           C.byref(self.struct), torch.cuda.current_stream().cuda_stream)
+                st = lib.gconv_graph_build_ex(ei.data_ptr(), self.num_edges, self.num_nodes,
+                                              int(self.normalize), _lib.BUILD_BACKGROUND if background else 0,
+                                              self.arena.data_ptr(), nbytes, C.byref(self.struct),
+                                              torch.cuda.current_stream().cuda_stream)
         _lib.check(st, "graph_build")
         self.symmetric = bool(self.struct.symmetric)
         self.fwd = CsrView(self, self.struct.fwd)
@@ -271,7 +275,7 @@ class PlanCache:
         def build():
             with torch.cuda.device(dev), torch.cuda.stream(side):
                 side.wait_event(ready)
-                return GraphPlan(edge_index, num_nodes, normalize)
+                return GraphPlan(edge_index, num_nodes, normalize, background=True)
 
         self._pending[key] = self._pool.submit(build)
 

@@ -1369,3 +1369,11 @@ def test_counting_graph_build_from_two_threads(dev):
     for t in threads:
         t.join()
     assert not errors, errors[0]
+
+
+def test_background_graph_build_equals_foreground_build(dev):
+    """GraphPlan(background=True) (GCONV_BUILD_BACKGROUND: the prefetch worker's builds) skips the grid-wide
+    one-launch builder; the plan is the same."""
+    b, _ = ga.synth.make_workload("hiv")
+    ei = b.edge_index.to(dev)
+    _same(_plan_arrays(ga.GraphPlan(ei, b.num_nodes, True)), _plan_arrays(ga.GraphPlan(ei, b.num_nodes, True, background=True)))

@@ -1,0 +1,14 @@
+# Round-end measurement set: the driver's bench line, the same command under rocprofv3 (kernel trace +
+# stats), and a 2-rank rehearsal of the N > 1 path on this one GPU (gloo, both ranks on device 0).
+#   usage (GPU box, repo root): bash tools/lab/final_bench.sh gpurun_out/final
+OUT=${1:-gpurun_out/final}
+ROOT=$(pwd)
+mkdir -p "$OUT"
+python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" || exit 1
+tail -1 "$OUT/bench.json"
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/prof" -- python3 "$ROOT/bench.py" > "$ROOT/$OUT/bench_under_rocprof.json" 2> "$ROOT/$OUT/bench_under_rocprof.err") || exit 1
+cp "$OUT"/prof/*/*kernel_stats.csv "$OUT/kernel_stats.csv"
+for mode in weak strong; do
+  GCONV_BENCH_BACKEND=gloo timeout -k 10 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --scaling $mode > "$OUT/bench_2rank_gloo_$mode.json" 2> "$OUT/bench_2rank_gloo_$mode.err" || exit 1
+  tail -1 "$OUT/bench_2rank_gloo_$mode.json" | cut -c1-400
+done
