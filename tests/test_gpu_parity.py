@@ -6,6 +6,8 @@ unnormalised sums). Integer outputs of graph prep are compared exactly.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -342,6 +344,7 @@ def test_adapter_tile_path_width_rank_sweep(dev, d, r, act, normalize):
     _check_workload(dev, batch, d, r, flags, seed=r)
 
 
+@pytest.mark.skipif(bool(os.environ.get("GCONV_NO_TILE_PATH")), reason="asserts that the tile path is taken")
 @pytest.mark.parametrize("chords_per_node", [16, 2])
 def test_adapter_tile_path_large_components(dev, chords_per_node):
     """Components far larger than a tile (400-node rings with chords) next to single-node and two-node

@@ -289,6 +289,8 @@ def _shard_worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
+@pytest.mark.skipif(bool(os.environ.get("GCONV_PY_BINDING")) or bool(os.environ.get("GCONV_AUTOGRAD_PARAM_GRADS")),
+                    reason="gradient sinks belong to the C++ binding's direct-deposit backward node")
 def test_two_ranks_by_graph_with_gradient_sinks(dev, tmp_path):
     """Two processes, one shard of the batch each: the adapters' backward deposits dW /
     db / ds straight into the flat bucket (no cat, no copy back), ONE asynchronous all-reduce per step

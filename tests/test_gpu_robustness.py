@@ -7,6 +7,7 @@ finetune_inductive_learning.py:43-67`): `zero_grad`, forward, `loss.backward()`,
 """
 from __future__ import annotations
 
+import os
 import copy
 import io
 
@@ -322,6 +323,8 @@ def test_replaced_parameter_is_picked_up(dev):
     _check_against_oracle(mod, batch, flags, params2, g, xg, out)
 
 
+@pytest.mark.skipif(bool(os.environ.get("GCONV_PY_BINDING")) or bool(os.environ.get("GCONV_AUTOGRAD_PARAM_GRADS")),
+                    reason="gradient sinks belong to the C++ binding's direct-deposit backward node")
 def test_gradient_sinks_single_process(dev):
     """`FlatGradBucket` / `FusedAdam` register their flat views as gradient sinks: the backward
     deposits there when p.grad is None, accumulates the ordinary way when it is not, hands a sink
