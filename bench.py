@@ -705,6 +705,8 @@ def cpu_baseline(batch, cfg: dict, normalize: bool, budget_s: float = 20.0) -> d
 def run_workload(name: str, normalize: bool, steps: int, warmup: int, rank: int, world: int,
                  device, with_cpu: bool, strong: bool = False) -> dict:
     fresh = ga.synth.WORKLOADS[name]["kind"] == "molecule"   # transductive graphs are static
+    if os.environ.get("GCONV_BENCH_STATIC_PLAN"):   # lab knob: one batch, its plan cached (no build beside the step)
+        fresh = False
     if RESIDENT and fresh and not strong:
         stream = StoreStream(name, rank, device, RESIDENT)
     else:
