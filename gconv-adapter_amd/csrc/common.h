@@ -56,6 +56,18 @@ inline int padded_rank(int r) {
 __device__ __forceinline__ f32x4 ldg4(const float* p) {
   return *reinterpret_cast<const f32x4*>(p);
 }
+// streamed-once output rows (never re-read by the writing kernel): non-temporal, so that they do not
+// push the rows that ARE re-read out of L2 (GCONV_STREAM_STORES_NT=0: plain stores, A/B)
+#ifndef GCONV_STREAM_STORES_NT
+#define GCONV_STREAM_STORES_NT 1
+#endif
+__device__ __forceinline__ void stg4_stream(float* p, f32x4 v) {
+#if GCONV_STREAM_STORES_NT
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+#else
+  *reinterpret_cast<f32x4*>(p) = v;
+#endif
+}
 __device__ __forceinline__ void stg4(float* p, f32x4 v) {
   *reinterpret_cast<f32x4*>(p) = v;
 }

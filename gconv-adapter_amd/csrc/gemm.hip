@@ -307,7 +307,7 @@ __global__ __launch_bounds__(TB) void up_fwd_kernel(UpArgs a, int nchunks, int n
         f32x4 o;
 #pragma unroll
         for (int c = 0; c < 4; ++c) o[c] = sval * (acc[c][m] + bu[c] + xv[m][c]);
-        stg4(a.out + static_cast<size_t>(row) * a.d + colbase, o);
+        stg4_stream(a.out + static_cast<size_t>(row) * a.d + colbase, o);
       }
     }
 #pragma unroll
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(TB) void bwd_main_kernel(BwdMainArgs a, int nchunks
           f32x4 o;
 #pragma unroll
           for (int c = 0; c < 4; ++c) o[c] = acc[c][m] + (a.skip ? sval * gv[m][c] : 0.f);
-          stg4(a.dX + static_cast<size_t>(row) * a.d + colbase, o);
+          stg4_stream(a.dX + static_cast<size_t>(row) * a.d + colbase, o);
         }
       }
     }
