@@ -665,7 +665,10 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
     // row's graph node now (a halo row's comes from the slot), the row itself once the phase-1
     // tile requests are out (`mid`)
     const float* hsel = a.act == GCONV_ACT_SILU ? a.saved_h1 : a.saved_h;
-    const int gfirst = tile_node(tv, min(grp, tv.n1 - 1));
+    // (the halo id is only REQUESTED here: selecting the node — a use of the loaded value — in front of
+    // the phase-1 tile requests put one more cold round trip, ~1.3 us, in front of every backward tile)
+    const int lr_first = min(grp, tv.n1 - 1);
+    const int hid_first = tv.hb[min(max(lr_first - nt, 0), kHaloNodes - 1)];
     f32x4 hfirst;
     const int np4 = nt * LPR;  // the P tile: np4 float4, the first blockDim of them via registers
     const f32x4 pfirst =
@@ -673,6 +676,7 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
     ds1 += tile_rowsA<FP, NQ, NORM, true>(rga, a.g, wl, bufA, a.dis, a.want_ds ? a.saved_p : nullptr, sval, tv,
                                           a.d, rowb, nwaves, wave, lane, [&]() {
                                             csr.advance();
+                                            const int gfirst = lr_first < nt ? ts + lr_first : hid_first;
                                             hfirst = ldg4(hsel + static_cast<size_t>(gfirst) * FP + 4 * sub);
                                           });
     csr.finish();
