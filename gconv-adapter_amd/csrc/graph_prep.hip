@@ -965,6 +965,19 @@ static CountState* count_state() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
   return &states[dev];
 }
+// the state of the current device with its memory in place, or null: a one-launch builder whose few
+// library-owned bytes cannot be allocated (device memory exhausted by the caller) is skipped, the radix
+// pipeline — which needs nothing but the arena — builds the plan
+static CountState* usable_state(bool device_block) {
+  CountState* cs = count_state();
+  if (!cs) return nullptr;
+  std::lock_guard<std::mutex> lock(cs->mu);
+  if (cs->ensure(device_block) != GCONV_OK) {
+    (void)hipGetLastError();   // (the failed allocation's sticky error must not fail the next launch check)
+    return nullptr;
+  }
+  return cs;
+}
 
 static bool counting_build_ok(int64_t E, int32_t n) {   // (env read per call: the tests compare the builders)
   const char* v = std::getenv("GCONV_NO_COUNTING_BUILD");
@@ -1080,12 +1093,10 @@ extern "C" gconv_status_t gconv_graph_build_ex(const int64_t* edge_index, int64_
     g->tile_nodes_max = h[INFO_TILEMAX];
     g->tile_edges_max = h[INFO_TILEEDGES];
   };
-  CountState* cs_small = small_build_ok(E, n) ? count_state() : nullptr;
+  CountState* cs_small = small_build_ok(E, n) ? usable_state(false) : nullptr;
   if (cs_small) {   // ONE launch, counters straight into pinned memory (see small_graph_build_kernel)
     CountState* cs = cs_small;
     std::lock_guard<std::mutex> lock(cs->mu);
-    gconv_status_t es = cs->ensure(false);
-    if (es != GCONV_OK) return es;
     cs->arm();
     SmallBuildArgs a{};
     a.ei = edge_index; a.E = static_cast<int32_t>(E); a.n = n; a.normalize = normalize ? 1 : 0;
@@ -1139,11 +1150,10 @@ extern "C" gconv_status_t gconv_graph_build_ex(const int64_t* edge_index, int64_
   const int T = 256;
   int32_t h[64];
   // (GCONV_BUILD_BACKGROUND: no grid-wide launch next to the caller's other kernels — see the header)
-  CountState* cs = counting_build_ok(E, n) && !(flags & GCONV_BUILD_BACKGROUND) ? count_state() : nullptr;
+  CountState* cs = counting_build_ok(E, n) && !(flags & GCONV_BUILD_BACKGROUND) ? usable_state(true) : nullptr;
   if (cs) {   // one launch (see counting_build_kernel)
     std::lock_guard<std::mutex> lock(cs->mu);
-    gconv_status_t es = cs->ensure(true);
-    if (es != GCONV_OK) return es;
+    if (cs->broken && cs->ensure(true) != GCONV_OK) return GCONV_E_WORKSPACE;   // (re-clearing after a give-up)
     CountArgs a{};
     a.ei = edge_index; a.E = E; a.n = n; a.normalize = normalize ? 1 : 0;
     a.state = cs->state;
