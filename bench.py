@@ -1,7 +1,15 @@
 #!/usr/bin/env python3
 """GConv-Adapter hot-path benchmark (contract: see the task's bench.py section).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hiv|esol|...]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hiv|esol|...] [--scaling strong|weak]
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment makes THIS process a launcher: before
+torch (or anything else that could touch the GPU) is imported it starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 … bench.py <same flags>`
+as a CHILD process (one rank per GPU), relays the ranks' output, prints rank 0's JSON line as its own
+last stdout line and exits with the child's return code. Under `torch.distributed.run` (WORLD_SIZE set)
+the process is a rank. The reference has no counterpart: it is single-process, `cuda:0`
+(`/root/reference/scripts/finetune_inductive_learning.py:179`).
 
 One "step" = one pass of the adapter hot path over one collated batch, exactly
 what the adapters of one model forward+backward cost in the reference's train
@@ -10,19 +18,18 @@ loop (`/root/reference/scripts/finetune_inductive_learning.py:43-67`):
     graph prep for the (new) batch's edge_index      (K0, shared by all adapters)
     A adapters forward, chained                       (A = adapters per model forward)
     backward through all of them (dX + parameter grads)
-    [N > 1] one flat RCCL all-reduce of the adapter gradients
+    [N > 1] one flat grad all-reduce (RCCL over xGMI; gloo only when asked for by GCONV_BENCH_BACKEND)
 
 through the product surface (`GConvAdapter` nn.Module -> autograd.Function ->
 C ABI -> HIP kernels). Inputs are resident in HBM before the timed region.
 
-Default workload: the per-GPU unit of BASELINE.json configs[2] — a 512-molecule
-HIV-like shard (d=300, r=8, 5 pre-adapters); N ranks process N shards (weak
-scaling; N=8 is the 4096-molecule batch of configs[2] split 8 ways). The same
-batch on ONE GPU (fresh plan per step, through the module) is reported at N=1 as
-extra.hiv4096_graphs_per_s: strong-scaling speed-up at 8 GPUs = value(N=8) divided
-by it. `--scaling strong` runs that mode for any N directly (every rank takes
-4096 / N graphs of the SAME batches). `--workload esol` is configs[1]; both
-molecule workloads are reported at N=1 (the other one under "extra").
+Default workload: BASELINE.json configs[2] — the 4096-molecule HIV-like batch (d=300, r=8, 5
+pre-adapters) cut BY GRAPH into N shards, one per GPU (`--scaling strong`, the default for molecule
+workloads: total work fixed, N = 1 runs the whole batch on one GPU, N = 8 runs 512 molecules per
+GPU — north_star's "≥ 6x at 8 GPUs on sharded HIV batches" is value(N=8) / value(N=1)).
+`--scaling weak`: every rank runs its own 512-molecule shard (the round 1-3 headline; at N = 1 it is
+reported under extra.hiv512_*). `--workload esol` is configs[1]; both molecule workloads are
+reported at N=1 (the other one under "extra").
 
 Timing: an untimed pre-roll (`settle`, reported as config.settle_steps) runs the step until
 its rate is steady — a fresh process on the GPU box needs 0.1–0.7 s of activity before the
@@ -46,6 +53,87 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+
+# --------------------------------------------------------------------------- launcher (stdlib only)
+def _requested_gpus(argv) -> int:
+    """`--gpus N` / `--gpus=N` out of an argument list (1 when absent or unparsable)."""
+    n = 1
+    for i, a in enumerate(argv):
+        try:
+            if a == "--gpus" and i + 1 < len(argv):
+                n = int(argv[i + 1])
+            elif a.startswith("--gpus="):
+                n = int(a.split("=", 1)[1])
+        except ValueError:
+            pass
+    return n
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launcher_command(argv, n: int, port: int) -> list:
+    """The child command of the launcher: the driver's own documented form for N > 1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", str(port),
+            os.path.abspath(__file__)] + list(argv)
+
+
+def _visible_gpus() -> int:
+    """`torch.cuda.device_count()` asked of a short-lived CHILD process, so that the launcher itself
+    never loads torch or the HIP runtime (-1 when the question cannot be answered)."""
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                             capture_output=True, text=True, timeout=600)
+        return int(out.stdout.strip().splitlines()[-1])
+    except Exception:
+        return -1
+
+
+def launch_ranks(argv) -> int:
+    """Launcher role (see the module docstring). Returns the exit code for this process.
+    GCONV_BENCH_LAUNCH_DRYRUN=1 prints what would be started (and whether torch is loaded) instead."""
+    import subprocess
+    n = _requested_gpus(argv)
+    cmd = launcher_command(argv, n, _free_port())
+    if os.environ.get("GCONV_BENCH_LAUNCH_DRYRUN"):
+        print(json.dumps({"launcher_cmd": cmd, "torch_loaded": "torch" in sys.modules,
+                          "package_loaded": "gconv_adapter_amd" in sys.modules}))
+        return 0
+    have = _visible_gpus()
+    if 0 <= have < n and os.environ.get("GCONV_BENCH_BACKEND") != "gloo":
+        print(f"bench.py: --gpus {n} but {have} GPU(s) visible; set GCONV_BENCH_BACKEND=gloo for a "
+              f"functional rehearsal with several ranks per GPU (never a measurement)", file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1, env=env)
+    line = None
+    for out in proc.stdout:
+        s = out.strip()
+        if s.startswith("{") and '"metric"' in s:
+            line = s            # rank 0's result: held back, printed last
+        else:
+            sys.stdout.write(out)
+            sys.stdout.flush()
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        print("bench.py: the ranks finished without a result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and _requested_gpus(sys.argv[1:]) > 1:
+    sys.exit(launch_ranks(sys.argv[1:]))      # nothing below has run: no torch, no HIP in this process
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -766,10 +854,10 @@ def main() -> None:
     ap.add_argument("--resident", type=int, default=0, metavar="G",
                     help="keep a G-molecule dataset in HBM and draw a fresh random batch every step "
                          "(device-side collation + plan assembly) instead of rotating 4 fixed batches")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak (default): every rank runs its own 512-molecule shard, N = 8 is the 4096-molecule "
-                         "batch of configs[2] split 8 ways; strong: the SAME 4096-molecule batches for any N, "
-                         "every rank takes 4096 / N graphs (N = 1: the whole batch on one GPU)")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="strong (default for --workload hiv): the SAME 4096-molecule batches of configs[2] for any N, "
+                         "every rank takes 4096 / N graphs (N = 1: the whole batch on one GPU); weak (default for "
+                         "the other workloads): every rank runs its own batch (hiv: a 512-molecule shard)")
     ap.add_argument("--partition", default="graphs", choices=["graphs", "rows"],
                     help="N > 1 on a single-graph workload (cora / pubmed / arxiv): 'graphs' runs one replica "
                          "of the graph per GPU, 'rows' splits the ONE graph by rows over the GPUs "
@@ -782,26 +870,42 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        # a rank's world comes from torch.distributed.run; `--gpus N` without it is handled by the
+        # launcher above (N > 1) — anything else is a mistake in the command line
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; run `python bench.py --gpus N` "
+                         f"(it starts the ranks itself) or `python -m torch.distributed.run --nproc-per-node N "
+                         f"bench.py --gpus N`")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU product path)")
-    # one rank per GPU; on a box with fewer GPUs than ranks (functional rehearsal of the
-    # N > 1 path only) ranks wrap around and RCCL is replaced by gloo
+    # one rank per GPU. Fewer GPUs than ranks is an error unless GCONV_BENCH_BACKEND=gloo asks for a
+    # functional rehearsal of the N > 1 path (ranks wrap around the GPUs; never a measurement)
     ngpu = torch.cuda.device_count()
+    backend = os.environ.get("GCONV_BENCH_BACKEND", "nccl") if world > 1 else "none"
+    if world > ngpu and backend != "gloo":
+        raise SystemExit(f"bench.py: {world} ranks but {ngpu} GPU(s) visible (GCONV_BENCH_BACKEND=gloo rehearses "
+                         f"several ranks per GPU)")
     dev_index = local_rank % max(ngpu, 1)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    devices = [f"cuda:{dev_index} {torch.cuda.get_device_name(dev_index)}"]
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("GCONV_BENCH_BACKEND", "nccl" if world <= ngpu else "gloo")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, f"rank {rank}: {devices[0]}")
+        devices = gathered
     normalize = bool(args.normalize)
     ga._lib.load()
 
     solo = world == 1 and rank == 0
-    strong = args.scaling == "strong" and ga.synth.WORKLOADS[args.workload]["kind"] == "molecule"
+    molecule = ga.synth.WORKLOADS[args.workload]["kind"] == "molecule"
+    if args.scaling is None:   # hiv: configs[2] is ONE 4096-molecule batch over the GPUs
+        args.scaling = "strong" if args.workload in ("hiv", STRONG_WORKLOAD) else "weak"
+    strong = args.scaling == "strong" and molecule
     if strong:
         args.workload = STRONG_WORKLOAD
     main_res = run_workload(args.workload, normalize, args.steps, args.warmup, rank, world, device,
@@ -825,16 +929,20 @@ def main() -> None:
                                f"{main_res['cfg']['adapters']} adapters fwd+bwd, "
                                + ("fresh graph plan per step (built on a side stream while the previous step runs)"
                                   if main_res["cfg"]["kind"] == "molecule" else "static graph (plan built once)")
-                               + (" + ONE flat RCCL grad all-reduce per step (gradients deposited in the bucket "
-                                  "by the backward kernels, collective asynchronous)" if world > 1 else ""),
+                               + (f" + ONE flat grad all-reduce per step over {'RCCL' if backend == 'nccl' else backend} "
+                                  "(gradients deposited in the bucket by the backward kernels, collective "
+                                  "asynchronous)" if world > 1 else ""),
                    "normalize": normalize,
                    "sharding": (f"ONE graph by rows over {world} rank(s): 4 all-gathers of [N, Fp] per adapter "
                                 f"and step + flat grad all-reduce" if main_res["by_rows"]
                                 else (f"by graph: the same {main_res['cfg']['graphs']}-molecule batches cut "
-                                      f"into {world} shard(s) (strong scaling)" if strong
+                                      f"into {world} shard(s) of {main_res['graphs_per_rank']} (strong scaling)" if strong
                                       else f"by graph, {world} rank(s), one {main_res['graphs_per_rank']}-molecule "
                                            f"shard each (weak scaling; strong-scaling reference at N = 1: "
                                            f"extra.{STRONG_WORKLOAD}_graphs_per_s)")),
+                   "backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend),
+                   "world_size": dist.get_world_size() if world > 1 else 1,
+                   "devices": devices,
                    "settle_steps": main_res["settle_steps"],
                    "host_threads": (f"pinned to cores {_PINNED[0]}-{_PINNED[-1]} (GPU's NUMA node)"
                                     if _PINNED else "not pinned"),
@@ -856,13 +964,22 @@ def main() -> None:
             key = "normalize_true" if not normalize else "normalize_false_yaml_default"
             extra[f"{key}_graphs_per_s"] = round(o["value"], 1)
             extra[f"{key}_ms_per_step"] = round(o["ms_per_step"], 4)
-            if not strong:
+            if not strong and molecule:
                 # strong-scaling reference: the whole 4096-molecule batch of configs[2] on this ONE GPU
                 # (fresh plan per step, through the module). value(N = 8, weak) / this = speed-up at 8 GPUs
                 o = run_workload(STRONG_WORKLOAD, normalize, max(20, args.steps // 4), args.warmup, rank, world,
                                  device, with_cpu=False, strong=True)
                 extra[f"{STRONG_WORKLOAD}_graphs_per_s"] = round(o["value"], 1)
                 extra[f"{STRONG_WORKLOAD}_ms_per_step"] = round(o["ms_per_step"], 4)
+                pin_host_threads()
+            if strong:
+                # the per-GPU unit at N = 8 (one 512-molecule shard; the round 1-3 headline) on this ONE GPU:
+                # ms_per_step here + one ~100 KB all-reduce is what a rank of the 8-GPU run has to do
+                o = run_workload("hiv", normalize, args.steps, args.warmup, rank, world, device, with_cpu=False)
+                extra["hiv512_graphs_per_s"] = round(o["value"], 1)
+                extra["hiv512_ms_per_step"] = round(o["ms_per_step"], 4)
+                extra["hiv512_projected_speedup_at_8_gpus_without_collective"] = round(
+                    main_res["ms_per_step"] / o["ms_per_step"], 2)
                 pin_host_threads()
             ax = measure_arxiv(device, banded_control=args.banded)
             line["roofline"] = ax["roofline"]
@@ -875,7 +992,7 @@ def main() -> None:
             for tname in ("cora", "pubmed"):
                 extra.update(measure_transductive(device, tname))
             other = "esol" if args.workload != "esol" else "hiv"
-            o = run_workload(other, normalize, max(20, args.steps // 2), args.warmup, rank, world,
+            o = run_workload(other, normalize, max(20, min(args.steps, 200) // 2), args.warmup, rank, world,
                              device, with_cpu=not args.no_cpu_baseline)
             extra[f"{other}_graphs_per_s"] = round(o["value"], 1)
             extra[f"{other}_ms_per_step"] = round(o["ms_per_step"], 4)

@@ -10,8 +10,11 @@ all-reduce of the trainable-parameter gradients.
 That set is small — adapters + head + norm affine params, ~29 k fp32 ≈ 116 KB
 for HIV / rank 8 (freeze policy ``src/models/inductive/gnn.py:230-241``) — so
 the all-reduce is latency-bound on xGMI: ONE flat bucket, ONE RCCL call per
-step. ``FlatGradBucket`` makes every ``p.grad`` a view into one contiguous
-buffer so no packing copy is needed before the collective.
+step. ``FlatGradBucket`` owns one contiguous buffer; by the time its collective
+is launched every ``p.grad`` is a view into it — written there directly by the
+adapters' backward (gradient sinks), accumulated in place by autograd
+(``bind()``), or packed with one multi-tensor copy (parameters autograd fills
+with fresh tensors: head, norm layers) — and nothing is copied back.
 """
 from __future__ import annotations
 
@@ -85,10 +88,10 @@ class FlatGradBucket:
         self.views = [self.flat[off:off + p.numel()].view_as(p)
                       for p, off in zip(self.params, self.offsets)]
         self._work = None
+        self._pending_div = 0
         self.sinks = False
-        if sinks and dev.type == "cuda" and dt == torch.float32:
-            self.attach_sinks()
-        else:
+        # sinks need the C++ binding; without it (ctypes path, CPU tensors) every p.grad is bound up front
+        if not (sinks and dev.type == "cuda" and dt == torch.float32 and self.attach_sinks()):
             self.bind()
 
     def attach_sinks(self) -> bool:
@@ -132,22 +135,33 @@ class FlatGradBucket:
         self.flat.zero_()
 
     def wait(self) -> None:
-        """Orders the current stream behind the collective launched by an ``async_op`` call."""
+        """Orders the current stream behind the collective launched by an ``async_op`` call (and
+        applies the division of an ``average=True`` call, which has to follow the sum)."""
         if self._work is not None:
             self._work.wait()
             self._work = None
+        if self._pending_div:
+            self.flat.div_(self._pending_div)
+            self._pending_div = 0
 
     def all_reduce(self, average: bool = False, async_op: bool = False):
-        """Sum (or mean) of the bucket over all ranks: one collective per step.
+        """Sum (or mean) of the gradients over all ranks: one collective per step. Gradients that
+        are not in the bucket yet (a parameter without a sink, or one autograd filled with its own
+        tensor) are packed first (``gather_stragglers``): whatever mode the bucket is in, what is
+        reduced is every bucketed parameter's gradient, and afterwards every ``p.grad`` is a view.
 
         With the reference's loss normalisation (sum over valid targets divided by
         the batch's count, ``finetune_inductive_learning.py:62-63``) each rank should
-        divide by the GLOBAL count (see ``global_count``) and use ``average=False``."""
+        divide by the GLOBAL count (see ``global_count``) and use ``average=False``.
+        ``average=True`` with ``async_op=True`` divides in ``wait()``."""
+        self.wait()           # (a collective still in flight from the previous step)
+        self.gather_stragglers()
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return None
         work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
         if async_op:
             self._work = work
+            self._pending_div = dist.get_world_size() if average else 0
         elif average:
             self.flat.div_(dist.get_world_size())
         return work
@@ -174,9 +188,7 @@ class FlatGradBucket:
         """The step's gradient exchange for loops that start from ``p.grad = None``: stragglers in
         (see ``gather_stragglers``), ONE collective on the flat buffer, ``p.grad`` = views of it —
         nothing is copied back. ``async_op``: returns at once, ``wait()`` later."""
-        self.gather_stragglers()
-        work = self.all_reduce(average=average and not async_op, async_op=async_op)
-        return work
+        return self.all_reduce(average=average, async_op=async_op)
 
 
 # ---------------------------------------------------------------------------------------

@@ -67,6 +67,18 @@ def _worker(rank, world, port, out_path):
     packed = torch.cat([p.grad.flatten() for p in bucket.params])
     assert torch.allclose(packed, flat_views, rtol=1e-6, atol=1e-7)
     assert bucket.gather_stragglers() == 0
+    # average=True with async_op=True: the division follows the sum, in wait() (round-3 advisor finding:
+    # it was silently dropped); and the plain all_reduce() packs gradients autograd allocated itself
+    # (a bucket in sink mode on a device without the binding, head / norm parameters) before it reduces
+    for p in bucket.params:
+        p.grad = None
+    loss = ((model(shard.x) - target) ** 2).sum() / count
+    loss.backward()
+    assert bucket.all_reduce(average=True, async_op=True) is not None
+    bucket.wait()
+    assert [p.grad.data_ptr() for p in bucket.params] == views
+    mean = torch.cat([p.grad.flatten() for p in bucket.params])
+    assert torch.allclose(mean * world, flat_views, rtol=1e-6, atol=1e-7)
     if rank == 0:
         torch.save({"flat": flat_views, "count": count}, out_path)
     dist.barrier()

@@ -303,3 +303,49 @@ def test_row_slab_adapter_copies_drop_the_process_group():
     m.__dict__["_group"] = object()           # stands in for a ProcessGroup (not picklable)
     c = copy.deepcopy(m)
     assert "_slabs" not in c.__dict__ and "_group" not in c.__dict__
+
+
+# ---- bench.py as its own launcher (`python bench.py --gpus N`, no torchrun around it) --------------
+def _bench_dryrun(args, env_extra=None):
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(GCONV_BENCH_LAUNCH_DRYRUN="1", **(env_extra or {}))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def test_bench_gpus_n_starts_n_child_ranks_without_loading_torch():
+    """`--gpus N` (N > 1, no WORLD_SIZE) = launcher: the N ranks are CHILDREN started through
+    torch.distributed.run on 127.0.0.1, and the launcher has loaded neither torch nor the package
+    (nothing in it can have initialised HIP) when it starts them."""
+    import sys
+    for flag in (["--gpus", "8"], ["--gpus=8"]):
+        got = _bench_dryrun(flag + ["--steps", "7", "--warmup", "3"])
+        cmd = got["launcher_cmd"]
+        assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+        assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+        assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+        assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+        script = cmd.index(os.path.join(ROOT, "bench.py"))
+        assert cmd[script + 1:] == flag + ["--steps", "7", "--warmup", "3"]      # the ranks get the same flags
+        assert got["torch_loaded"] is False and got["package_loaded"] is False
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head = src[:src.index("\nimport torch")]
+    assert "sys.exit(launch_ranks(" in head, "the launcher must run before torch is imported"
+    assert "os.exec" not in src and "execv" not in src
+
+
+def test_bench_rank_role_is_not_a_launcher():
+    """Under torch.distributed.run (WORLD_SIZE set) the same command line is a rank, and --gpus that
+    contradicts WORLD_SIZE is refused instead of silently measuring another world."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", GCONV_BENCH_LAUNCH_DRYRUN="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "launcher_cmd" not in out.stdout
+    assert "WORLD_SIZE=2" in out.stderr
