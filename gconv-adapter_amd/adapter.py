@@ -152,10 +152,12 @@ class GConvAdapter(nn.Module):
         if self.direct_param_grads and torch.is_grad_enabled():
             pack = self._param_pack(ext, p, fuse_scalar)
             if pack is not None:
-                # W_down rides along as an autograd input whose gradient slot stays undefined: the
-                # node stays alive when only the parameters train, and `backward(inputs=params)`
-                # finds it on the path to a named parameter (the deposit itself is per parameter)
-                anchor = p[0]
+                # ONE trainable parameter rides along as an autograd input whose gradient slot stays
+                # undefined: the node stays alive when only the parameters train, and
+                # `backward(inputs=params)` finds it on the path to a named parameter (the deposit itself
+                # is per parameter). W_down unless it is frozen; then the first parameter that trains
+                anchor = p[0] if p[0].requires_grad else next(
+                    (q for q in p[1:5] if q is not None and q.requires_grad), None)
                 return ext.adapter_apply_direct(x2d, anchor, pack, plan.arena, plan.struct_addr, fp, ws_fwd,
                                                 ws_bwd, p[5], bool(self.skip_connection), _stream(dev.index))
         return ext.adapter_apply(x2d, p[0], p[1], p[2], p[3], p[4] if fuse_scalar else None,

@@ -875,12 +875,29 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, bool, at::Tensor, at::Tensor> gra
 }
 
 struct Shapes { int64_t n, d, r, fp; };
-Shapes check_adapter_args(const gconv_graph_t& g, const at::Tensor& x, const at::Tensor& w_down, const at::Tensor& w_up) {
+// every parameter tensor a kernel will read through a raw pointer: an fp32 HIP tensor on x's device with
+// exactly the elements the kernel indexes (a CPU weight or a short bias would otherwise be a device
+// fault / an out-of-bounds read instead of an error)
+void check_param(const at::Tensor& t, const at::Tensor& x, int64_t numel, const char* name) {
+  if (!t.defined()) return;
+  TORCH_CHECK(t.is_cuda() && t.device() == x.device() && t.scalar_type() == at::kFloat && t.is_contiguous() &&
+                  t.numel() == numel,
+              "gconv: ", name, " must be a contiguous fp32 tensor of ", numel, " elements on ", x.device(), ", got ",
+              t.scalar_type(), " ", t.sizes(), " on ", t.device());
+}
+Shapes check_adapter_args(const gconv_graph_t& g, const at::Tensor& x, const at::Tensor& w_down, const at::Tensor& w_up,
+                          const at::Tensor& b_down = at::Tensor(), const at::Tensor& b_up = at::Tensor(),
+                          const at::Tensor& scalar = at::Tensor()) {
   TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.dim() == 2,
               "gconv computes in fp32 on a HIP device (no CPU path); x must be [N, d]");
   TORCH_CHECK(w_down.dim() == 2 && w_up.dim() == 2 && w_down.size(1) == x.size(1) && w_up.size(0) == x.size(1) &&
                   w_up.size(1) == w_down.size(0),
               "gconv: conv_down.lin.weight is [r, d], conv_up.lin.weight is [d, r]");
+  check_param(w_down, x, w_down.size(0) * x.size(1), "conv_down.lin.weight");
+  check_param(w_up, x, w_down.size(0) * x.size(1), "conv_up.lin.weight");
+  check_param(b_down, x, w_down.size(0), "conv_down.bias");
+  check_param(b_up, x, x.size(1), "conv_up.bias");
+  check_param(scalar, x, 1, "scalar");
   TORCH_CHECK(x.size(0) == g.fwd.num_nodes, "x has ", x.size(0), " nodes but the graph plan was built for ", g.fwd.num_nodes);
   const int64_t fp = g_lib.padded_rank(static_cast<int32_t>(w_down.size(0)));
   TORCH_CHECK(fp > 0, "bottleneck_size=", w_down.size(0), " is unsupported (1..64)");
@@ -897,9 +914,9 @@ std::tuple<at::Tensor, at::Tensor> adapter_fwd(const at::Tensor& x_, const at::T
   TORCH_CHECK(g_lib.handle, "gconv_adapter_amd: library not loaded");
   const gconv_graph_t g = plan_struct(arena, plan);
   const at::Tensor x = x_.contiguous(), w_down = w_down_.contiguous(), w_up = w_up_.contiguous();
-  const at::Tensor b_down = b_down_.value_or(at::Tensor()), b_up = b_up_.value_or(at::Tensor()),
-                   scalar = scalar_.value_or(at::Tensor());
-  const Shapes sh = check_adapter_args(g, x, w_down, w_up);
+  auto cont = [](const c10::optional<at::Tensor>& t) { return t.has_value() && t->defined() ? t->contiguous() : at::Tensor(); };
+  const at::Tensor b_down = cont(b_down_), b_up = cont(b_up_), scalar = cont(scalar_);
+  const Shapes sh = check_adapter_args(g, x, w_down, w_up, b_down, b_up, scalar);
   const int64_t act = act_code(act_);
   at::Tensor out = at::empty_like(x);
   at::Tensor saved = at::empty({act == GCONV_ACT_SILU ? 3 : 2, sh.n, sh.fp}, x.options());
@@ -926,8 +943,9 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tenso
   const gconv_graph_t g = plan_struct(arena, plan);
   const at::Tensor x = x_.contiguous(), w_down = w_down_.contiguous(), w_up = w_up_.contiguous(),
                    go = grad_out.contiguous();
-  const at::Tensor b_up = b_up_.value_or(at::Tensor()), scalar = scalar_.value_or(at::Tensor());
-  const Shapes sh = check_adapter_args(g, x, w_down, w_up);
+  auto cont = [](const c10::optional<at::Tensor>& t) { return t.has_value() && t->defined() ? t->contiguous() : at::Tensor(); };
+  const at::Tensor b_up = cont(b_up_), scalar = cont(scalar_);
+  const Shapes sh = check_adapter_args(g, x, w_down, w_up, at::Tensor(), b_up, scalar);
   const int64_t act = act_code(act_);
   TORCH_CHECK(go.is_cuda() && go.scalar_type() == at::kFloat && go.sizes() == x.sizes(),
               "gconv: grad_out must be an fp32 HIP tensor of x's shape");
@@ -980,7 +998,8 @@ at::Tensor adapter(const at::Tensor& x, const at::Tensor& w_down, const c10::opt
                    std::string act_, bool skip) {
   TORCH_CHECK(g_lib.handle, "gconv_adapter_amd: library not loaded");
   const gconv_graph_t g = plan_struct(arena, plan);
-  const Shapes sh = check_adapter_args(g, x, w_down, w_up);
+  auto cont = [](const c10::optional<at::Tensor>& t) { return t.has_value() && t->defined() ? t->contiguous() : at::Tensor(); };
+  const Shapes sh = check_adapter_args(g, x, w_down.contiguous(), w_up.contiguous(), cont(b_down), cont(b_up), cont(scalar));
   const int64_t wsf = std::max<int64_t>(g_lib.ws_fwd(&g, static_cast<int32_t>(sh.d), static_cast<int32_t>(sh.r)), 16);
   const int64_t wsb = std::max<int64_t>(g_lib.ws_bwd(&g, static_cast<int32_t>(sh.d), static_cast<int32_t>(sh.r)), 16);
   c10::OptionalDeviceGuard guard(x.device());

@@ -17,7 +17,12 @@ scatter-adds it — per layer. Here (``csrc/gin.hip``):
     per BATCH (``edge_code_counts``) and shared by all five GIN layers;
   * backward of a frozen layer only needs d agg -> d x: the same kernel on the transposed CSR.
 
-The MLP (two dense GEMMs) stays ``nn.Linear``: plain library GEMMs belong to rocBLAS / hipBLASLt.
+The MLP (300 -> 600 -> 300) of a FROZEN layer — the adapter recipe freezes the backbone,
+``gnn.py:230-241`` — runs on a hand-written bf16x3 MFMA kernel (``csrc/mlp.hip``: every fp32
+operand as three bf16 values, six products per fp32 product, fp32 accumulation; fp32-accurate,
+``tests/test_gin.py::test_gin_mlp_bf16x3_is_fp32_accurate``), forward and input gradient. A
+backbone that trains its MLP keeps ``nn.Linear`` (weight gradients are torch's business);
+``GCONV_TORCH_MLP=1`` is the A/B knob.
 """
 from __future__ import annotations
 
@@ -129,8 +134,10 @@ TORCH_MLP = bool(os.environ.get("GCONV_TORCH_MLP"))
 
 class _SplitWeights:
     """The three bf16 images of a frozen weight (``gconv_mlp_split_weights_bf16x3``), rebuilt when the
-    parameter's storage or version changes (``load_state_dict``, ``.to()``, an optimizer step on an
-    unfrozen backbone)."""
+    parameter's storage, version counter, device or shape changes (an in-place op, ``.to()``) and when
+    the owning module says so (``MolecularGINConv.invalidate_mlp_split``: after ``load_state_dict`` /
+    ``_apply``, and by hand after a write through ``w.data`` — ``w.data.copy_()``, EMA / manual
+    checkpoint loading — which moves neither the storage nor the version counter)."""
 
     def __init__(self):
         self.key, self.buf, self.shape = None, None, None
@@ -231,6 +238,19 @@ class MolecularGINConv(nn.Module):
         self.validate_edge_attr = False
         # the frozen MLP's weights as bf16 triples: W1, W2 (forward), W2^T, W1^T (input gradient)
         self.__dict__["_mlp_split"] = [_SplitWeights() for _ in range(4)]
+
+        self.register_load_state_dict_post_hook(lambda module, _keys: module.invalidate_mlp_split())
+
+    def invalidate_mlp_split(self) -> None:
+        """Drops the cached bf16 images of the MLP's weights; the next forward splits them again.
+        Called after ``load_state_dict`` and ``.to()`` / ``.cuda()`` / ``.float()``; call it yourself
+        after writing the frozen weights through ``.data`` (which no version counter sees)."""
+        self.__dict__["_mlp_split"] = [_SplitWeights() for _ in range(4)]
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.invalidate_mlp_split()
+        return out
 
     def __getstate__(self):   # (device buffers keyed on the original's parameters: not part of a copy)
         state = self.__dict__.copy()

@@ -149,6 +149,39 @@ def test_backward_with_named_parameter_inputs(dev):
     assert torch.equal(mod.conv_down.lin.weight.grad, got["conv_down.lin.weight"])
 
 
+def test_frozen_down_projection_still_trains_the_rest(dev):
+    """Round-3 advisor finding: the direct-deposit node hung on W_down's grad accumulator alone — with
+    W_down frozen and x not requiring grad the output had no grad_fn and W_up / biases / scalar
+    silently received nothing. The anchor is now the first parameter that trains."""
+    batch, flags, params, mod, g = _setup(dev, seed=12)
+    ei = batch.edge_index.to(dev)
+    frozen_sets = (("conv_down.lin.weight",), ("conv_down.lin.weight", "conv_down.bias"),
+                   ("conv_down.lin.weight", "conv_down.bias", "conv_up.lin.weight", "conv_up.bias"))
+    for frozen in frozen_sets:
+        for x_needs_grad in (False, True):
+            for k, p in mod.named_parameters():
+                p.requires_grad_(k not in frozen)
+            mod.zero_grad(set_to_none=True)
+            xg = batch.x.to(dev).requires_grad_(x_needs_grad)
+            out = mod(xg, ei)
+            assert out.grad_fn is not None
+            out.backward(g.to(dev))
+            want_out, want = oracle.adapter_forward_backward(batch.x.double(), batch.edge_index, params, flags,
+                                                             g.double())
+            assert_close(out.detach().cpu().double(), want_out, "out")
+            for k, p in mod.named_parameters():
+                if k in frozen:
+                    assert p.grad is None, k
+                else:
+                    assert p.grad is not None, f"grad {k} missing with {frozen} frozen"
+                    assert_close(p.grad.cpu().double(), want[k], f"grad {k}", atol=grad_atol(want[k]))
+            if x_needs_grad:
+                assert_close(xg.grad.cpu().double(), want["x"], "grad x")
+    for p in mod.parameters():          # everything frozen, x too: a plain forward, nothing to differentiate
+        p.requires_grad_(False)
+    assert mod(batch.x.to(dev), ei).grad_fn is None
+
+
 def test_hook_registered_after_first_forward_is_honoured(dev):
     """The choice between direct deposit and standard accumulation is made per call: a tensor hook
     or post-accumulate-grad hook added AFTER the first forward still runs."""

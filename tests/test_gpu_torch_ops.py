@@ -122,3 +122,17 @@ def test_ops_raise_runtime_errors(dev, ops):
     bad = ei.clone(); bad[0, 3] = 77
     with pytest.raises(RuntimeError, match="outside"):
         ops.graph_plan(bad, 50, True)
+    # parameter tensors are read through raw pointers: a CPU weight, a short bias, a wrong dtype must be an
+    # error, never a device fault or an out-of-bounds read (round-3 advisor finding)
+    x, wd, wu = torch.randn(50, 32, device=dev), torch.randn(4, 32, device=dev), torch.randn(32, 4, device=dev)
+    with pytest.raises(RuntimeError, match="conv_down.lin.weight"):
+        ops.adapter_fwd(x, wd.cpu(), None, wu, None, None, arena, plan, "relu", True)
+    with pytest.raises(RuntimeError, match="conv_up.bias"):
+        ops.adapter_fwd(x, wd, None, wu, torch.zeros(31, device=dev), None, arena, plan, "relu", True)
+    with pytest.raises(RuntimeError, match="conv_down.bias"):
+        ops.adapter_fwd(x, wd, torch.zeros(4, device=dev, dtype=torch.float64), wu, None, None, arena, plan, "relu", True)
+    with pytest.raises(RuntimeError, match="scalar"):
+        ops.adapter(x, wd, None, wu, None, torch.ones(1), arena, plan, "relu", True)
+    out, saved = ops.adapter_fwd(x, wd, None, wu, None, None, arena, plan, "relu", True)
+    with pytest.raises(RuntimeError, match="conv_up.bias"):
+        ops.adapter_bwd(torch.randn_like(x), x, saved, wd, wu, torch.zeros(32), None, arena, plan, "relu", True, True)
