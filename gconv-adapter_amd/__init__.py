@@ -13,7 +13,7 @@ from .data import MoleculeStore
 from .optim import FusedAdam
 from .partition import RowSlabGConvAdapter, RowSlabs
 from .gin import MolecularGINConv
-from .norm import BatchNorm1d
+from .norm import BatchNorm1d, sync_batch_norm
 from .relbias import add_conv_relational_bias
 
 
@@ -34,6 +34,6 @@ __all__ = [
     "GConvAdapter", "GCNConvParams", "GConvAdapterFunction", "gconv_adapter", "spmm",
     "gemm_down", "gemm_up_fused", "GraphPlan", "PlanCache", "PLAN_CACHE", "get_plan", "prefetch_plan",
     "instantiate", "load_finetune_config", "synth", "dist", "optim", "FusedAdam", "data", "MoleculeStore",
-    "partition", "RowSlabGConvAdapter", "RowSlabs", "gin", "MolecularGINConv", "norm", "BatchNorm1d",
+    "partition", "RowSlabGConvAdapter", "RowSlabs", "gin", "MolecularGINConv", "norm", "BatchNorm1d", "sync_batch_norm",
     "relbias", "add_conv_relational_bias", "register_ops",
 ]

@@ -95,7 +95,7 @@ class PendingFinalize(C.Structure):
 
 FINALIZE_BATCH = 5
 BUILD_BACKGROUND = 1   # GCONV_BUILD_BACKGROUND
-ABI_VERSION = 7   # GCONV_ABI_VERSION of include/gconv_adapter.h this binding was written against
+ABI_VERSION = 8   # GCONV_ABI_VERSION of include/gconv_adapter.h this binding was written against
 
 
 class AdapterParams(C.Structure):
@@ -171,6 +171,12 @@ SIGNATURES = {
                                         _i32, _i32, _vp, _sz, _vp]),
     "gconv_batch_norm_apply_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp]),
     "gconv_batch_norm_bwd_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _sz, _vp]),
+    "gconv_batch_norm_sync_words": (_sz, [_i32]),
+    "gconv_batch_norm_local_stats_f32": (_i32, [_vp, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "gconv_batch_norm_fwd_sync_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _i32, _vp, _vp, _vp, _vp,
+                                             _i32, _i32, _vp, _i32, _vp]),
+    "gconv_batch_norm_bwd_local_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _sz, _vp]),
+    "gconv_batch_norm_bwd_dx_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "gconv_adam_step_f32": (_i32, [_vp, _vp, _vp, _vp, C.c_int64, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_float, C.c_int64, _vp]),
 }

@@ -292,7 +292,7 @@ extern "C" gconv_status_t gconv_layer_norm_scale_bwd_f32(const float* grad_out, 
 // =============================================================================================
 namespace gconv {
 
-enum { BN_SUMS_STATS = 0, BN_SUMS_GRAD = 1 };
+enum { BN_SUMS_STATS = 0, BN_SUMS_GRAD = 1, BN_SUMS_LOCAL = 2 };   // LOCAL: one rank's share of a sharded batch
 
 // part[block][0:d] = sum_rows A, part[block][d:2d] = sum_rows B with
 //   STATS: A = x - x[0], B = (x - x[0])^2        GRAD: A = g', B = g' * xhat   (g' = g where y > 0 if relu)
@@ -367,6 +367,7 @@ __global__ __launch_bounds__(256) void bn_colsums_kernel(const float* __restrict
 // reduces the partial rows (16 columns x 16 row groups per block, fixed order) and finishes:
 //   STATS: mean, rstd (biased variance), running statistics (unbiased variance, torch's rule)
 //   GRAD : dgamma = sum g' xhat, dbeta = sum g'
+//   LOCAL: mean and M2 = sum (x - mean)^2 of THIS rank's rows (combined across ranks by bn_combine_kernel)
 constexpr int kBnFinCl = 4, kBnFinRg = 64;   // columns x row groups of one bn_finalize block (256 threads)
 
 template <int MODE>
@@ -409,7 +410,15 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   }
   if (rg != 0 || c >= d) return;
   const float sa = red[0][0][cl], sb = red[1][0][cl];
-  if (MODE == BN_SUMS_STATS) {
+  if (MODE == BN_SUMS_LOCAL) {
+    const float m1 = n > 0 ? sa / static_cast<float>(n) : 0.f;   // mean - x[0]
+    out0[c] = n > 0 ? x_row0[c] + m1 : 0.f;
+    out1[c] = fmaxf(sb - sa * m1, 0.f);                           // M2
+    if (c == 0) {   // the row count travels with the statistics, as bits (an all-gather does no arithmetic)
+      int* cnt = reinterpret_cast<int*>(out1 + d);
+      cnt[0] = n; cnt[1] = 0; cnt[2] = 0; cnt[3] = 0;
+    }
+  } else if (MODE == BN_SUMS_STATS) {
     const float inv_n = 1.f / static_cast<float>(n);
     const float m1 = sa * inv_n;                        // mean - x[0]
     const float var = fmaxf(sb * inv_n - m1 * m1, 0.f);  // biased
@@ -424,6 +433,42 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   } else {
     if (out0) out0[c] = sb;   // dgamma
     if (out1) out1[c] = sa;   // dbeta
+  }
+}
+
+// Sharded batch (one process per GPU, rows split by graph): every rank's (count, mean, M2) per column,
+// as gathered by the caller's all-gather, merged in RANK ORDER with Chan's pairwise update — the
+// same bits on every rank. gathered[r] = [mean d][M2 d][count as int32 bits, 3 pad words].
+__global__ __launch_bounds__(256) void bn_combine_kernel(const float* __restrict__ gathered, int world, int d,
+                                                         float eps, float momentum,
+                                                         float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                         float* __restrict__ running_mean,
+                                                         float* __restrict__ running_var,
+                                                         int* __restrict__ total_count) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int stride = 2 * d + 4;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  long long total = 0;
+  for (int r = 0; r < world; ++r) {
+    const float* row = gathered + static_cast<size_t>(r) * stride;
+    const int cnt = __float_as_int(row[2 * d]);
+    total += cnt;
+    if (cnt <= 0 || c >= d) continue;
+    const float nr = static_cast<float>(cnt), nn = n + nr;
+    const float delta = row[c] - mean;
+    mean += delta * (nr / nn);
+    m2 += row[d + c] + delta * delta * (n * nr / nn);
+    n = nn;
+  }
+  if (c == 0) *total_count = static_cast<int>(total);
+  if (c >= d) return;
+  const float var = n > 0.f ? m2 / n : 0.f;   // biased
+  mean_out[c] = mean;
+  rstd_out[c] = rsqrtf(var + eps);
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+  if (running_var) {
+    const float unbiased = n > 1.f ? m2 / (n - 1.f) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
   }
 }
 
@@ -463,12 +508,14 @@ __global__ __launch_bounds__(256) void bn_dx_kernel(const float* __restrict__ g,
                                                     const float* __restrict__ gamma,
                                                     const float* __restrict__ dgamma,
                                                     const float* __restrict__ dbeta,
-                                                    float* __restrict__ dx, int n, int d) {
+                                                    float* __restrict__ dx, int n, int d,
+                                                    const int* __restrict__ total_count) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + wave_id();
   if (row >= n) return;
   const int nq = d >> 2;
-  const float inv_n = 1.f / static_cast<float>(n);
+  // a sharded batch divides by the rows of ALL ranks (dgamma / dbeta are then the all-reduced sums)
+  const float inv_n = 1.f / static_cast<float>(total_count ? *total_count : n);
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     const int q = lane + 64 * p;
@@ -602,8 +649,108 @@ extern "C" gconv_status_t gconv_batch_norm_bwd_f32(const float* grad_y, const fl
   GCONV_LAUNCH_CHECK();
   if (grad_x) {
     GCONV_BN_DISPATCH((bn_dx_kernel<NP><<<ceil_div(num_nodes, 4), 256, 0, stream>>>(
-        grad_y, x, y, save_mean, save_rstd, gamma, dg, db, grad_x, num_nodes, hidden)))
+        grad_y, x, y, save_mean, save_rstd, gamma, dg, db, grad_x, num_nodes, hidden, nullptr)))
     GCONV_LAUNCH_CHECK();
   }
+  return GCONV_OK;
+}
+
+// ---- the same BatchNorm over a batch whose rows are sharded across ranks ("optional
+// all_reduce of BN stats"; the reference trains the backbone's BatchNorm on WHOLE-batch statistics,
+// gnn.py:56,109-110). The C ABI never calls a collective: forward and backward are cut where the
+// exchange happens, the caller (norm.py) runs one small collective in between.
+extern "C" size_t gconv_batch_norm_sync_words(int32_t hidden) { return 2 * static_cast<size_t>(hidden) + 4; }
+
+extern "C" gconv_status_t gconv_batch_norm_local_stats_f32(const float* x, int32_t num_nodes, int32_t hidden,
+                                                           float* local, void* workspace,
+                                                           size_t workspace_bytes, gconv_stream_t stream_) {
+  const gconv_status_t st = ln_check(num_nodes, hidden);
+  if (st != GCONV_OK) return st;
+  if (!local || !workspace || (num_nodes > 0 && !x)) return GCONV_E_INVALID_ARG;
+  const BnWs ws = bn_carve(workspace, num_nodes, hidden);
+  if (workspace_bytes < ws.bytes) return GCONV_E_WORKSPACE;
+  if ((x && !aligned16(x)) || !aligned16(local) || !aligned16(workspace)) return GCONV_E_ALIGNMENT;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int grid = bn_grid(num_nodes);
+  if (num_nodes > 0) {
+    GCONV_BN_DISPATCH((bn_colsums_kernel<NP, BN_SUMS_STATS><<<grid, 256, 0, stream>>>(
+        x, nullptr, nullptr, nullptr, nullptr, ws.part, num_nodes, hidden)))
+    GCONV_LAUNCH_CHECK();
+  }
+  bn_finalize_kernel<BN_SUMS_LOCAL><<<ceil_div(hidden, kBnFinCl), 256, 0, stream>>>(
+      ws.part, num_nodes > 0 ? grid : 0, x, num_nodes, hidden, 0.f, 0.f, local, local + hidden, nullptr, nullptr);
+  GCONV_LAUNCH_CHECK();
+  return GCONV_OK;
+}
+
+extern "C" gconv_status_t gconv_batch_norm_fwd_sync_f32(const float* x, const float* gamma, const float* beta,
+                                                        float* running_mean, float* running_var, float momentum,
+                                                        float eps, int32_t relu, float* y, float* save_mean,
+                                                        float* save_rstd, int32_t* total_count,
+                                                        int32_t num_nodes, int32_t hidden, const float* gathered,
+                                                        int32_t world, gconv_stream_t stream_) {
+  const gconv_status_t st = ln_check(num_nodes, hidden);
+  if (st != GCONV_OK) return st;
+  if (!save_mean || !save_rstd || !total_count || !gathered || world < 1 || (num_nodes > 0 && (!x || !y)))
+    return GCONV_E_INVALID_ARG;
+  if ((x && !aligned16(x)) || (y && !aligned16(y)) || !aligned16(save_mean) || !aligned16(save_rstd) ||
+      (gamma && !aligned16(gamma)) || (beta && !aligned16(beta)))
+    return GCONV_E_ALIGNMENT;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  bn_combine_kernel<<<ceil_div(hidden, 256), 256, 0, stream>>>(gathered, world, hidden, eps, momentum, save_mean,
+                                                              save_rstd, running_mean, running_var, total_count);
+  GCONV_LAUNCH_CHECK();
+  if (num_nodes > 0) {
+    GCONV_BN_DISPATCH((bn_apply_kernel<NP><<<ceil_div(num_nodes, 4), 256, 0, stream>>>(
+        x, save_mean, save_rstd, gamma, beta, y, num_nodes, hidden, relu)))
+    GCONV_LAUNCH_CHECK();
+  }
+  return GCONV_OK;
+}
+
+extern "C" gconv_status_t gconv_batch_norm_bwd_local_f32(const float* grad_y, const float* x, const float* y,
+                                                         const float* save_mean, const float* save_rstd,
+                                                         float* sums, int32_t num_nodes, int32_t hidden,
+                                                         void* workspace, size_t workspace_bytes,
+                                                         gconv_stream_t stream_) {
+  const gconv_status_t st = ln_check(num_nodes, hidden);
+  if (st != GCONV_OK) return st;
+  if (!save_mean || !save_rstd || !sums || !workspace || (num_nodes > 0 && (!grad_y || !x)))
+    return GCONV_E_INVALID_ARG;
+  const BnWs ws = bn_carve(workspace, num_nodes, hidden);
+  if (workspace_bytes < ws.bytes) return GCONV_E_WORKSPACE;
+  if ((grad_y && !aligned16(grad_y)) || (x && !aligned16(x)) || (y && !aligned16(y)) || !aligned16(save_mean) ||
+      !aligned16(save_rstd) || !aligned16(sums) || !aligned16(workspace))
+    return GCONV_E_ALIGNMENT;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int grid = bn_grid(num_nodes);
+  if (num_nodes > 0) {
+    GCONV_BN_DISPATCH((bn_colsums_kernel<NP, BN_SUMS_GRAD><<<grid, 256, 0, stream>>>(
+        x, grad_y, y, save_mean, save_rstd, ws.part, num_nodes, hidden)))
+    GCONV_LAUNCH_CHECK();
+  }
+  // sums = [dgamma d][dbeta d]: this rank's share (an empty shard contributes zeros)
+  bn_finalize_kernel<BN_SUMS_GRAD><<<ceil_div(hidden, kBnFinCl), 256, 0, stream>>>(
+      ws.part, num_nodes > 0 ? grid : 0, nullptr, num_nodes, hidden, 0.f, 0.f, sums, sums + hidden, nullptr, nullptr);
+  GCONV_LAUNCH_CHECK();
+  return GCONV_OK;
+}
+
+extern "C" gconv_status_t gconv_batch_norm_bwd_dx_f32(const float* grad_y, const float* x, const float* y,
+                                                      const float* save_mean, const float* save_rstd,
+                                                      const float* gamma, const float* sums_all,
+                                                      const int32_t* total_count, float* grad_x,
+                                                      int32_t num_nodes, int32_t hidden, gconv_stream_t stream_) {
+  const gconv_status_t st = ln_check(num_nodes, hidden);
+  if (st != GCONV_OK) return st;
+  if (num_nodes == 0) return GCONV_OK;
+  if (!grad_y || !x || !save_mean || !save_rstd || !sums_all || !total_count || !grad_x) return GCONV_E_INVALID_ARG;
+  if (!aligned16(grad_y) || !aligned16(x) || (y && !aligned16(y)) || !aligned16(save_mean) || !aligned16(save_rstd) ||
+      (gamma && !aligned16(gamma)) || !aligned16(sums_all) || !aligned16(grad_x))
+    return GCONV_E_ALIGNMENT;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  GCONV_BN_DISPATCH((bn_dx_kernel<NP><<<ceil_div(num_nodes, 4), 256, 0, stream>>>(
+      grad_y, x, y, save_mean, save_rstd, gamma, sums_all, sums_all + hidden, grad_x, num_nodes, hidden, total_count)))
+  GCONV_LAUNCH_CHECK();
   return GCONV_OK;
 }

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GCONV_ABI_VERSION 7
+#define GCONV_ABI_VERSION 8
 
 typedef int32_t gconv_status_t;
 typedef void*   gconv_stream_t; /* hipStream_t */
@@ -501,6 +501,48 @@ gconv_status_t gconv_batch_norm_bwd_f32(const float* grad_y, const float* x, con
                                         float* grad_beta, int32_t num_nodes, int32_t hidden,
                                         void* workspace, size_t workspace_bytes,
                                         gconv_stream_t stream);
+
+/* ---- the same BatchNorm when the batch's rows are sharded BY GRAPH over ranks (ABI 8) ----------
+ * The reference is single-process: `batch_norm_layers[layer](h)` (`src/models/inductive/gnn.py:56,
+ * 109-110`) and the adapter's `batch_norm` tail (`src/finetune/gconv_adapter.py:98-100`) normalise with
+ * the statistics of the WHOLE batch. With one process per GPU and a shard of the batch each (SURVEY
+ * §8e: "optional all_reduce of BN stats") the same result needs one small exchange per direction.
+ * The library never calls a collective: both passes are cut where the exchange happens and the
+ * caller (gconv_adapter_amd/norm.py over torch.distributed / RCCL) runs it in between.
+ *   forward : local_stats  -> `local` [gconv_batch_norm_sync_words(hidden)] = [mean d][M2 d][count, 3 pad]
+ *                              (M2 = sum (x - mean)^2 over this rank's num_nodes >= 0 rows; the count
+ *                              is stored as int32 BITS so that an all-gather carries it unchanged)
+ *             ALL-GATHER   -> `gathered` [world][sync_words], rank order
+ *             fwd_sync     -> merges the ranks' (count, mean, M2) in rank order (Chan's update: same
+ *                              bits on every rank), writes save_mean / save_rstd / *total_count (device),
+ *                              updates the running statistics with torch's rule over the global count,
+ *                              y = [relu](gamma (x - mean) rstd + beta) for this rank's rows
+ *   backward: bwd_local    -> `sums` [2 hidden] = [sum g' xhat][sum g'] over this rank's rows: the rank's
+ *                              CONTRIBUTION to grad_gamma / grad_beta (summed later by the step's flat
+ *                              gradient all-reduce like every other parameter gradient)
+ *             ALL-REDUCE(sum) of a COPY of `sums` -> `sums_all`
+ *             bwd_dx       -> grad_x = gamma rstd (g' - sum_all g' / n_all - xhat sum_all g' xhat / n_all)
+ * Workspace size: gconv_batch_norm_workspace_bytes. An empty shard (num_nodes = 0) is valid.      */
+size_t gconv_batch_norm_sync_words(int32_t hidden);
+gconv_status_t gconv_batch_norm_local_stats_f32(const float* x, int32_t num_nodes, int32_t hidden,
+                                                float* local, void* workspace, size_t workspace_bytes,
+                                                gconv_stream_t stream);
+gconv_status_t gconv_batch_norm_fwd_sync_f32(const float* x, const float* gamma, const float* beta,
+                                             float* running_mean, float* running_var, float momentum,
+                                             float eps, int32_t relu, float* y, float* save_mean,
+                                             float* save_rstd, int32_t* total_count, int32_t num_nodes,
+                                             int32_t hidden, const float* gathered, int32_t world,
+                                             gconv_stream_t stream);
+gconv_status_t gconv_batch_norm_bwd_local_f32(const float* grad_y, const float* x, const float* y,
+                                              const float* save_mean, const float* save_rstd,
+                                              float* sums, int32_t num_nodes, int32_t hidden,
+                                              void* workspace, size_t workspace_bytes,
+                                              gconv_stream_t stream);
+gconv_status_t gconv_batch_norm_bwd_dx_f32(const float* grad_y, const float* x, const float* y,
+                                           const float* save_mean, const float* save_rstd,
+                                           const float* gamma, const float* sums_all,
+                                           const int32_t* total_count, float* grad_x, int32_t num_nodes,
+                                           int32_t hidden, gconv_stream_t stream);
 
 /* ---- next to the path: the frozen GIN layer's MLP -------------------------------
  * replaces: `self.mlp` = Linear(d, 2d) -> ReLU -> Linear(2d, d) of `MolecularGINConv`
