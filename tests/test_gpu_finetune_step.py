@@ -14,6 +14,8 @@ import torch.nn.functional as F
 import gconv_adapter_amd as ga
 from oracle import gin_restated, pyg_restated
 
+from helpers import KinkWatch, assert_close, grad_atol
+
 pytestmark = pytest.mark.gpu
 
 D, R, LAYERS, TASKS = 64, 8, 3, 2
@@ -73,10 +75,10 @@ def _oracle_forward(state, x, ei, ea, batch, num_graphs):
     return F.linear(pooled, state["graph_pred_linear.weight"], state["graph_pred_linear.bias"])
 
 
-def _setup(dev):
+def _setup(dev, seed=2):
     torch.manual_seed(0)
-    b = ga.synth.molecule_batch("esol", 24, hidden=D, seed=2)
-    g = torch.Generator().manual_seed(3)
+    b = ga.synth.molecule_batch("esol", 24, hidden=D, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
     e = b.edge_index.shape[1]
     ea = torch.stack([torch.randint(0, 4, (e,), generator=g), torch.randint(0, 3, (e,), generator=g)], 1)
     sizes = b.graph_ptr[1:] - b.graph_ptr[:-1]
@@ -103,10 +105,19 @@ def test_trainable_set_follows_the_reference_freeze_rule(dev):
 
 
 def test_first_step_matches_the_fp64_oracle_model(dev):
-    b, ea, batch, y, model = _setup(dev)
-    state = {k: v.detach().cpu().double().requires_grad_(True) for k, v in model.state_dict().items()
-             if v.dtype.is_floating_point and "running" not in k}
-    want_loss = _masked_loss(_oracle_forward(state, b.x.double(), b.edge_index, ea, batch, b.num_graphs), y)
+    """Loss and every trainable gradient ELEMENT-WISE at 1e-5 (rounds 2-3: as vectors, by cosine —
+    BatchNorm + ReLU sit between the adapters and the loss and a unit at a ReLU kink may take the other
+    side in fp32). The seeded batch is drawn until the fp64 oracle model has no unit near a kink
+    (`helpers.KinkWatch`), so a difference beyond tolerance is a real one."""
+    for seed in range(2, 66):
+        b, ea, batch, y, model = _setup(dev, seed)
+        state = {k: v.detach().cpu().double().requires_grad_(True) for k, v in model.state_dict().items()
+                 if v.dtype.is_floating_point and "running" not in k}
+        with KinkWatch() as watch:
+            want_loss = _masked_loss(_oracle_forward(state, b.x.double(), b.edge_index, ea, batch, b.num_graphs), y)
+        if watch.risky == 0:
+            break
+    assert watch.risky == 0 and watch.units > 10_000, "no seeded batch without a unit at a ReLU kink"
     want_loss.backward()
     model.train()
     out = model(b.x.to(dev), b.edge_index.to(dev), ea.to(dev), batch.to(dev), b.num_graphs)
@@ -117,12 +128,8 @@ def test_first_step_matches_the_fp64_oracle_model(dev):
         if not p.requires_grad:
             assert p.grad is None, k
             continue
-        got, want = p.grad.cpu().double().flatten(), state[k].grad.flatten()
-        # BatchNorm + ReLU sit between the adapters and the loss: a unit at a ReLU kink may take the
-        # other side in fp32, so gradients are compared as vectors, not element by element
-        cos = torch.dot(got, want) / (got.norm() * want.norm()).clamp(min=1e-30)
-        assert cos > 0.9999, (k, float(cos))
-        assert abs(got.norm() - want.norm()) <= 1e-3 * want.norm(), k
+        want = state[k].grad
+        assert_close(p.grad.cpu().double(), want, f"grad {k}", atol=grad_atol(want))
 
 
 def test_loop_body_trains_and_leaves_the_backbone_untouched(dev):

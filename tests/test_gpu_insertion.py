@@ -23,7 +23,7 @@ import torch.nn.functional as F
 import gconv_adapter_amd as ga
 from oracle import gin_restated, pyg_restated
 
-from helpers import assert_close, grad_atol
+from helpers import KinkWatch, assert_close, grad_atol
 
 pytestmark = pytest.mark.gpu
 
@@ -128,7 +128,9 @@ def _oracle_gnn(state, kind, x, ei, ea):
     return F.linear(hs[-1], state["head.weight"], state["head.bias"])
 
 
-def _compare(model, state, want_loss, loss, elementwise):
+def _compare(model, state, want_loss, loss):
+    """loss and EVERY trainable gradient element-wise (rtol 1e-5; absolute term relative to the tensor's
+    scale for these sums over all nodes, `helpers.grad_atol`)."""
     assert abs(loss.item() - want_loss.item()) <= 1e-5 * max(1.0, abs(want_loss.item()))
     seen = 0
     for k, p in model.named_parameters():
@@ -137,40 +139,42 @@ def _compare(model, state, want_loss, loss, elementwise):
             continue
         seen += 1
         got, want = p.grad.cpu().double(), state[k].grad
-        if elementwise:
-            assert_close(got, want, f"grad {k}", atol=grad_atol(want))
-        else:
-            # BatchNorm + ReLU sit between the adapters and the loss: a unit at a ReLU kink may take
-            # the other side in fp32, so these gradients are compared as vectors
-            got, want = got.flatten(), want.flatten()
-            cos = torch.dot(got, want) / (got.norm() * want.norm()).clamp(min=1e-30)
-            assert cos > 0.9999, (k, float(cos))
-            assert abs(got.norm() - want.norm()) <= 1e-3 * want.norm(), k
+        assert_close(got, want, f"grad {k}", atol=grad_atol(want))
     return seen
 
 
 @pytest.mark.parametrize("positions,kind", MODES)
 def test_molecule_backbone_insertion_modes(dev, positions, kind):
+    """BatchNorm + ReLU sit between the adapters and the loss: a unit within fp32 rounding of a ReLU kink
+    could take the other side on the GPU and move every upstream gradient. Rounds 2-3 therefore compared
+    these gradients as vectors (cosine); now the seeded inputs are drawn until the fp64 oracle model has
+    NO unit near a kink (`helpers.KinkWatch`: ~10^5 ReLU inputs per model, a few tries) and every
+    gradient is compared element-wise."""
     torch.manual_seed(0)
-    b = ga.synth.molecule_batch("esol", 24, hidden=MiniGNN.D, seed=2)
-    g = torch.Generator().manual_seed(3)
-    e = b.edge_index.shape[1]
-    ea = torch.stack([torch.randint(0, 4, (e,), generator=g), torch.randint(0, 3, (e,), generator=g)], 1)
     model = MiniGNN()
     _add_adapters(model, positions, kind, MiniGNN.D, MiniGNN.R, MiniGNN.LAYERS)
     assert len(model.pre_adapters) == (MiniGNN.LAYERS if "pre" in positions else 0)
     assert len(model.post_adapters) == (MiniGNN.LAYERS if "post" in positions else 0)
     model = model.to(dev).train()
-    target = torch.randn(b.num_nodes, 1, generator=g).double()
-    state = {k: v.detach().cpu().double().requires_grad_(True) for k, v in model.state_dict().items()
-             if v.dtype.is_floating_point and "running" not in k}
-    want_loss = (_oracle_gnn(state, kind, b.x.double(), b.edge_index, ea) - target).square().mean()
+    for seed in range(2, 66):
+        b = ga.synth.molecule_batch("esol", 24, hidden=MiniGNN.D, seed=seed)
+        g = torch.Generator().manual_seed(seed + 1)
+        e = b.edge_index.shape[1]
+        ea = torch.stack([torch.randint(0, 4, (e,), generator=g), torch.randint(0, 3, (e,), generator=g)], 1)
+        target = torch.randn(b.num_nodes, 1, generator=g).double()
+        state = {k: v.detach().cpu().double().requires_grad_(True) for k, v in model.state_dict().items()
+                 if v.dtype.is_floating_point and "running" not in k}
+        with KinkWatch() as watch:
+            want_loss = (_oracle_gnn(state, kind, b.x.double(), b.edge_index, ea) - target).square().mean()
+        if watch.risky == 0:
+            break
+    assert watch.risky == 0 and watch.units > 10_000, "no seeded batch without a unit at a ReLU kink"
     want_loss.backward()
     out = model(b.x.to(dev), b.edge_index.to(dev), ea.to(dev))
     loss = (out.double() - target.to(dev)).square().mean()
     loss.backward()
     n_adapters = MiniGNN.LAYERS * len(positions)
-    assert _compare(model, state, want_loss, loss, elementwise=False) == 5 * n_adapters + 2 * MiniGNN.LAYERS + 2
+    assert _compare(model, state, want_loss, loss) == 5 * n_adapters + 2 * MiniGNN.LAYERS + 2
 
 
 # ------------------------------------------------------------------------------------------
@@ -262,4 +266,4 @@ def test_nodeformer_shape_insertion_modes(dev, positions, kind):
     n_adapters = MiniFormer.LAYERS * len(positions)
     # no ReLU / BatchNorm between the adapters and the loss besides the adapters' own (inside the
     # oracle too, on values bounded away from the kink by the 0.1-scale weights): element-wise
-    assert _compare(model, state, want_loss, loss, elementwise=True) == 5 * n_adapters + 2 * (MiniFormer.LAYERS + 1) + 2
+    assert _compare(model, state, want_loss, loss) == 5 * n_adapters + 2 * (MiniFormer.LAYERS + 1) + 2
