@@ -33,6 +33,14 @@
 #ifndef GCONV_BWD_WAVES
 #define GCONV_BWD_WAVES 2
 #endif
+// Workgroups per CU (lab knob): 2 = half-size workgroups (forward and backward:
+// one wave per 64-column chunk, 4 at least), registers capped for 3 waves per SIMD, the backward
+// with ONE (G, X) pair in flight, grid of 2 x CUs — so that two workgroups share a CU and the
+// latency-bound phases of one run under the bandwidth-bound phase 4 of the other. The product
+// build is 1 (measured, slower).
+#ifndef GCONV_TILE_WGPC
+#define GCONV_TILE_WGPC 1
+#endif
 
 // Diagnostic build (-DGCONV_TILE_STAMPS): per-workgroup phase time stamps (100 MHz wall clock)
 // into a side buffer that nothing else reads; never compiled into the product library.
@@ -371,7 +379,11 @@ struct TileCsrStage {
 // forward — persistent workgroups walk the tiles (weights staged / loaded once)
 // ===========================================================================
 template <int FP, int NQ, bool NORM>
+#if GCONV_TILE_WGPC >= 2
+__global__ __launch_bounds__(320, 3) void tile_fwd_kernel(TileFwdArgs a) {
+#else
 __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_kernel(TileFwdArgs a) {
+#endif
   extern __shared__ f32x4 lds4[];
   constexpr int NCB = FP >= 16 ? FP / 16 : 1;
   constexpr int KS = FP / 4;
@@ -555,7 +567,11 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
 // partial row per workgroup reaches HBM and B5 is a single launch.
 // ===========================================================================
 template <int FP, int NQ, bool NORM, bool NEED_DX>
+#if GCONV_TILE_WGPC >= 2
+__global__ __launch_bounds__(320, 3) void tile_bwd_kernel(TileBwdArgs a) {
+#else
 __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdArgs a) {
+#endif
   extern __shared__ f32x4 lds4[];
   constexpr int NCB = FP >= 16 ? FP / 16 : 1;
   constexpr int KS = FP / 4;
@@ -577,6 +593,12 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
   // (prologue: all first-touch requests back to back, LDS staging after them — see forward)
   const float sraw = (a.scalar ? a.scalar : a.w_down)[0];
   i32x4 rec = tile_rec_load(a.tiles, blockIdx.x);   // grid <= n_tiles
+#ifdef GCONV_TILE_STAMPS
+  if (threadIdx.x == 0) {
+    a.stamps[blockIdx.x * 16 + 12] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    a.stamps[blockIdx.x * 16 + 13] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+  }
+#endif
   const int nchunks = ceil_div(a.d, 64);
   const int jj = lane & 15, t = lane >> 4;
   const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR, ngrp = blockDim.x / LPR;
@@ -705,7 +727,7 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
         xq[n] = buf_ld1(rx, off);
       }
     };
-    constexpr bool DEEP = FP < 32;  // rank 17..32: no registers left for the second pair
+    constexpr bool DEEP = FP < 32 && GCONV_TILE_WGPC < 2;  // rank 17..32: no registers left for the second pair
     float ga[16], xa[16], gb[DEEP ? 16 : 1], xb[DEEP ? 16 : 1];
     load_gx(slot, ga, xa);
     if constexpr (DEEP) load_gx(slot + nslots, gb, xb);
@@ -905,7 +927,11 @@ static int tile_nq(int d) {
 //             need more VGPRs)
 //   backward  8 waves (the dW accumulators pin a chunk to one wave: nchunks owner waves)
 static int tile_threads_fwd(int d, int fp) {
+#if GCONV_TILE_WGPC >= 2
+  const int nchunks = ceil_div(d, 64), cap = 5;
+#else
   const int nchunks = ceil_div(d, 64), cap = (fp >= 32 || tile_nq(d) > 19) ? 8 : 10;
+#endif
   int nslots = cap / nchunks;
   if (nslots < 1) nslots = 1;
   int w = nchunks * nslots;
@@ -914,11 +940,11 @@ static int tile_threads_fwd(int d, int fp) {
 }
 static int tile_threads_bwd(int d) {
   int w = ceil_div(d, 64);
-  if (w < 8) w = 8;
+  if (w < (GCONV_TILE_WGPC >= 2 ? 4 : 8)) w = GCONV_TILE_WGPC >= 2 ? 4 : 8;
   return 64 * w;
 }
 
-constexpr size_t kTileMaxLds = 144 * 1024;
+constexpr size_t kTileMaxLds = (GCONV_TILE_WGPC >= 2 ? 72 : 144) * 1024;
 
 size_t tile_lds_bytes(int d, int fp, int tile_nodes_max, int tile_edges_max) {
   const int nq = tile_nq(d), ncb = fp >= 16 ? fp / 16 : 1;
@@ -939,7 +965,7 @@ bool tile_path_ok(const gconv_graph_t* g, int d, int fp) {
     return false;
   // phase 1 addresses ALL rows of X / G through one buffer descriptor with 32-bit byte offsets
   if (static_cast<int64_t>(g->fwd.num_nodes) * d * 4 > 0x7FFF0000LL) return false;
-  if (tile_nq(d) == 0 || fp > 32 || ceil_div(d, 64) > 8) return false;
+  if (tile_nq(d) == 0 || fp > 32 || ceil_div(d, 64) > (GCONV_TILE_WGPC >= 2 ? 5 : 8)) return false;
   // wide rows at high rank do not fit the register budget of the fused kernels (they would
   // spill); the four-launch path is the better one there anyway
   if ((fp >= 32 && tile_nq(d) > 19) || (fp >= 16 && tile_nq(d) > 24)) return false;
@@ -1038,7 +1064,8 @@ GCONV_TILE_DEFINE_FP(GCONV_TILE_ONLY_FP)
   }
 
 int tile_grid(int n_tiles) {  // persistent: one workgroup per CU
-  return n_tiles < kNumCU ? (n_tiles > 0 ? n_tiles : 1) : kNumCU;
+  constexpr int kMax = kNumCU * (GCONV_TILE_WGPC >= 2 ? 2 : 1);
+  return n_tiles < kMax ? (n_tiles > 0 ? n_tiles : 1) : kMax;
 }
 
 gconv_status_t launch_tile_fwd(TileFwdArgs a, int n_tiles, int tile_nodes_max,

@@ -35,7 +35,7 @@ for _ in range(4):
     lib.gconv_adapter_bwd_f32(plan.ref(), C.byref(P), x.data_ptr(), g.data_ptr(), saved[0].data_ptr(), None, saved[1].data_ptr(), gx.data_ptr(),
                               gp[0].data_ptr(), gp[1].data_ptr(), gp[2].data_ptr(), gp[3].data_ptr(), gp[4].data_ptr(), wsB.data_ptr(), wsb, st)
 torch.cuda.synchronize()
-grid = min(plan.n_tiles, 256)
+grid = min(plan.n_tiles, int(os.environ.get("GCONV_STAMPS_GRID", "256")))   # (512 for a -DGCONV_TILE_WGPC=2 build)
 ENTRY = {}
 def show(tag, ws, off):
     st = ws[off:off + grid * 128].view(torch.int64).cpu().numpy().reshape(-1, 16)
@@ -46,6 +46,19 @@ def show(tag, ws, off):
     print(f"     kernel entry -> first tile: {np.percentile((st[:,0]-st[:,8])/100.0,[0,50,100]).round(1)} us; first entry at {(st[:,8].min()-t0)/100.0:.1f}, "
           f"last end at {(st[:, last].max()-t0)/100.0:.1f} (relative to the first workgroup's stamp 0)")
     ENTRY[tag] = (st[:, 8].min(), st[:, last].max())
+    # where the workgroups ran (slot 12 = HW_ID, slot 13 = XCC_ID): workgroups per CU, and how many of a CU's
+    # workgroups were resident at the same time (their [entry, last stamp] intervals overlap)
+    hw, xcc = st[:, 12], st[:, 13] & 0xF
+    cu = (xcc << 16) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)
+    per_cu, overlap = {}, 0
+    for i in range(len(cu)):
+        per_cu.setdefault(int(cu[i]), []).append((st[i, 8], st[i, last]))
+    for ivs in per_cu.values():
+        overlap += sum(1 for a in range(len(ivs)) for b in range(a + 1, len(ivs))
+                       if ivs[a][0] < ivs[b][1] and ivs[b][0] < ivs[a][1])
+    sizes = np.bincount([len(v) for v in per_cu.values()])
+    print(f"     placement: {len(per_cu)} distinct CUs for {len(cu)} workgroups; CUs by workgroup count {dict(enumerate(sizes.tolist()))}; "
+          f"co-resident pairs {overlap}")
     if tag == "fwd": print("     prologue pieces (median us): entry->9 %.2f, stage_weights %.2f, fragment loads %.2f, barrier->0 %.2f" % tuple(np.median((st[:, b] - st[:, a]) / 100.0) for a, b in ((8, 9), (9, 10), (10, 11), (11, 0))))
     print("     nt | start | setup  ph1   ph2   ph3   ph4  " + ("tail" if tag == "bwd" else ""))
     order = np.argsort(-nt)
