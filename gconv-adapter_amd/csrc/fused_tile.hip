@@ -408,6 +408,12 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
   TILE_STAMP(9);
   const float sraw = (a.scalar ? a.scalar : a.w_down)[0];
   i32x4 rec = tile_rec_load(a.tiles, blockIdx.x);   // grid <= n_tiles
+#ifdef GCONV_TILE_STAMPS
+  if (threadIdx.x == 0) {   // where this workgroup runs: HW_ID (wave / simd / cu / sh / se) and XCC_ID
+    a.stamps[blockIdx.x * 16 + 12] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    a.stamps[blockIdx.x * 16 + 13] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+  }
+#endif
 
   // phase-4 ownership: a wave owns ONE 64-column chunk (W_up fragments in registers) and
   // every nslots-th node block of a tile (nchunks <= nwaves is guaranteed by the launcher)

@@ -618,7 +618,9 @@ __global__ __launch_bounds__(T) void small_graph_build_kernel(SmallBuildArgs a) 
 // ---------------------------------------------------------------------------
 constexpr int kCountMaxNodes = 1 << 18, kCountMinNodes = kSmallMaxNodes + 1;
 constexpr int64_t kCountMaxEdges = static_cast<int64_t>(1) << 20;
-constexpr int kCountGrid = kNumCU, kCountThreads = 256, kCountGroups = 8;
+// grid widths: kCountGrid workgroups (a device with that many CUs: one each) for in-stream builds, the
+// narrow kCountGridNarrow for builds next to other kernels (GCONV_BUILD_BACKGROUND) and smaller devices
+constexpr int kCountGrid = 256, kCountGridNarrow = 64, kCountThreads = 256, kCountGroups = 8;
 constexpr int kEllWidth = 16;
 constexpr int kSpinMax = 1 << 20;
 // state block, in 4-byte words: barrier words (one 256-byte line per group + one for the grid),
@@ -637,6 +639,8 @@ struct CountArgs {
   int32_t* host_info;
   int32_t ntiles, T, slack, fwd;               // fwd: first forward counter word of info
   TileInfoSlots is;
+  int32_t phases;                              // bit set of the phases this launch runs: 1 = A, 2 = B, 4 = C (7: all,
+                                               // separated by grid barriers; one bit: a launch per phase, no barrier)
 };
 
 __device__ __forceinline__ int ldc(const int32_t* p) {
@@ -659,12 +663,13 @@ struct CsrCoherent {   // tiles.h accessor over the CSR this launch has just pro
   __device__ __forceinline__ int col(int e) const { return ldc(col_ + e); }
 };
 
-// All kCountGrid workgroups arrive — in kCountGroups groups, each on its own counter (256 arrivals
+// All GRID workgroups arrive — in kCountGroups groups, each on its own counter (256 arrivals
 // on one word took 6 - 10 us: device-scope atomics on one address are serialised at the memory
 // side), the last of a group for the group at the grid's counter — and the last one of all opens
 // the next generation in every group's line. false: gave up waiting.
 // No device-scope fence (see above): every wave waits for its stores (vmcnt(0)), which for a
 // device-scope store means written through.
+template <int GRID>
 __device__ __forceinline__ bool grid_sync(int32_t* state, uint32_t& gen, int* ok_s) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -676,7 +681,7 @@ __device__ __forceinline__ bool grid_sync(int32_t* state, uint32_t& gen, int* ok
     bool ok = true;
     bool opener = false;
     if (__hip_atomic_fetch_add(&mine[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
-        static_cast<uint32_t>(kCountGrid / kCountGroups - 1)) {
+        static_cast<uint32_t>(GRID / kCountGroups - 1)) {
       __hip_atomic_store(&mine[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (__hip_atomic_fetch_add(&top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
           static_cast<uint32_t>(kCountGroups - 1)) {
@@ -701,11 +706,13 @@ __device__ __forceinline__ bool grid_sync(int32_t* state, uint32_t& gen, int* ok
   return *ok_s != 0;
 }
 
+template <int GRID>
 __global__ __launch_bounds__(kCountThreads) void counting_build_kernel(CountArgs a) {
+  static_assert(GRID % 64 == 0 && GRID % kCountGroups == 0 && GRID <= kCountGrid, "chunk totals: GRID / 64 per lane");
   __shared__ int ok_s, last_s;
   __shared__ int32_t wred[kCountThreads / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
-  const int64_t gtid = static_cast<int64_t>(wg) * kCountThreads + tid, gsize = static_cast<int64_t>(kCountGrid) * kCountThreads;
+  const int64_t gtid = static_cast<int64_t>(wg) * kCountThreads + tid, gsize = static_cast<int64_t>(GRID) * kCountThreads;
   const int32_t n = a.n;
   const int64_t E = a.E;
   int32_t* info = a.state + kStateInfo;
@@ -713,10 +720,11 @@ __global__ __launch_bounds__(kCountThreads) void counting_build_kernel(CountArgs
   int32_t* deg = a.state + kStateDeg;
   // generation of this workgroup's group line, read before any arrival (all groups hold the same)
   uint32_t gen = static_cast<uint32_t>(ldc(a.state + kStateBar + (wg % kCountGroups) * kBarLine + 1));
-  const int chunk = (n + kCountGrid - 1) / kCountGrid;            // rows per workgroup in phase B
+  const int chunk = (n + GRID - 1) / GRID;                        // rows per workgroup in phase B
+  const bool run_a = a.phases & 1, run_b = a.phases & 2, run_c = a.phases & 4;   // grid-uniform
 #define GCONV_GRID_SYNC()                               \
   do {                                                  \
-    if (!grid_sync(a.state, gen, &ok_s)) return;        \
+    if (!grid_sync<GRID>(a.state, gen, &ok_s)) return;        \
   } while (0)
 #if GCONV_COUNT_STAMPS   // lab builds (tools/lab/k0_stamps.py): workgroup 0's clock at the phase boundaries
 #define GCONV_STAMP(k) do { if (wg == 0 && tid == 0) stc(info + 32 + (k), static_cast<int32_t>(wall_clock64())); } while (0)
@@ -727,7 +735,11 @@ __global__ __launch_bounds__(kCountThreads) void counting_build_kernel(CountArgs
   // ---- A: gather ----
   GCONV_STAMP(0);
   int s0 = 0, d0 = 0;                                  // the thread's first edge, kept for phase B (0, 0: none / invalid)
-  for (int64_t e0 = static_cast<int64_t>(wg) * kCountThreads + (tid & ~63); e0 < E; e0 += gsize) {   // wave-uniform trip count
+  if (!run_a && run_b && gtid < E) {                   // (phase B as its own launch: asked for again)
+    const int64_t s = a.ei[gtid], d = a.ei[E + gtid];
+    if (s >= 0 && s < n && d >= 0 && d < n) { s0 = static_cast<int>(s); d0 = static_cast<int>(d); }
+  }
+  for (int64_t e0 = static_cast<int64_t>(wg) * kCountThreads + (tid & ~63); run_a && e0 < E; e0 += gsize) {   // wave-uniform trip count
     const int64_t e = e0 + lane;
     int ck = -1;                                       // the edge's row chunk, -1: not stored
     if (e < E) {
@@ -755,7 +767,7 @@ __global__ __launch_bounds__(kCountThreads) void counting_build_kernel(CountArgs
     }
   }
   GCONV_STAMP(1);
-  GCONV_GRID_SYNC();
+  if (run_a && run_b) GCONV_GRID_SYNC();
   GCONV_STAMP(2);
 
   // ---- B: rows. Workgroup w owns rows [w * chunk, (w + 1) * chunk), thread t rows t * per .. ----
@@ -768,21 +780,21 @@ __global__ __launch_bounds__(kCountThreads) void counting_build_kernel(CountArgs
     for (int q = 0; q < kEllWidth / 4; ++q)
       v[q] = __builtin_amdgcn_raw_buffer_load_b128(ell_r, (row * kEllWidth + 4 * q) * 4, 0, kAuxDeviceScope);
   };
-  {
+  if (run_b) {
     // every load of the phase that does not depend on the scan is issued here, in one batch: the chunk
     // totals, the degrees and the slots of the thread's first row, and both ELL rows of its first edge
     const bool bad = ldc(info + INFO_BAD) != 0;                   // grid-uniform: the host refuses the list
-    int cc[kCountGrid / 64];
+    int cc[GRID / 64];
 #pragma unroll
-    for (int k = 0; k < kCountGrid / 64; ++k) cc[k] = ldc(chunk_cnt + k * 64 + lane);
+    for (int k = 0; k < GRID / 64; ++k) cc[k] = ldc(chunk_cnt + k * 64 + lane);
     i32x4 row0[kEllWidth / 4], rd[kEllWidth / 4], rs[kEllWidth / 4];
     ell_row(min(r0, n - 1), row0);
     const int dd0 = ldc(deg + d0), ds0 = ldc(deg + s0);
     ell_row(d0, rd);
     ell_row(s0, rs);
-    int below = 0, all = 0;                            // kCountGrid = 256 chunk totals: four per lane
+    int below = 0, all = 0;                            // GRID chunk totals: GRID / 64 per lane
 #pragma unroll
-    for (int k = 0; k < kCountGrid / 64; ++k) {
+    for (int k = 0; k < GRID / 64; ++k) {
       all += cc[k];
       if (k * 64 + lane < wg) below += cc[k];
     }
@@ -859,8 +871,9 @@ __global__ __launch_bounds__(kCountThreads) void counting_build_kernel(CountArgs
     }
   }
   GCONV_STAMP(3);
-  GCONV_GRID_SYNC();
+  if (run_b && run_c) GCONV_GRID_SYNC();
   GCONV_STAMP(4);
+  if (!run_c) return;
 
   // ---- C: tiles: tile t on workgroup t mod grid (one wave per tile, a tile per CU first); counters
   //         back to zero ----
@@ -876,7 +889,7 @@ __global__ __launch_bounds__(kCountThreads) void counting_build_kernel(CountArgs
 #else
     const CsrCoherent csr{a.rowptr, a.col};
 #endif
-    for (int t = wg + kCountGrid * wave; t < a.ntiles; t += kCountGrid * (kCountThreads / 64)) {
+    for (int t = wg + GRID * wave; t < a.ntiles; t += GRID * (kCountThreads / 64)) {
       int ts, te, e0, e1;
       tile_cuts_wave(csr, n, t, a.ntiles, a.T, a.slack, lane, ts, te, e0, e1);
       if (lane == 0) {
@@ -894,7 +907,7 @@ __global__ __launch_bounds__(kCountThreads) void counting_build_kernel(CountArgs
   if (tid == 0) {
     uint32_t* done = reinterpret_cast<uint32_t*>(a.state + kStateBar) + (kCountGroups + 1) * kBarLine;
     const uint32_t old = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    last_s = old == static_cast<uint32_t>(kCountGrid - 1);
+    last_s = old == static_cast<uint32_t>(GRID - 1);
     if (last_s) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
@@ -977,6 +990,50 @@ static CountState* usable_state(bool device_block) {
     return nullptr;
   }
   return cs;
+}
+
+// How the counting builder may be launched on the current device. The fused launch spins at two grid
+// barriers, so ALL its workgroups must be able to be resident together: grid <= CUs x the kernel's
+// workgroups per CU (hipDeviceProp_t / the occupancy query, asked once per device) — a device too small
+// for the wide grid takes the narrow one, one too small for that takes the radix pipeline at once, instead of
+// finding out by a ~1 s spin. GCONV_COUNT_COOPERATIVE=1 launches it with hipLaunchCooperativeKernel (the
+// runtime then checks the same thing per launch and refuses with an error; measured slower, DESIGN §4
+// round 4). Background builds (next to the caller's kernels, which may hold every CU for a while) never
+// wait inside a kernel: one narrow launch per phase. GCONV_BG_BUILD=radix|split|fused overrides that.
+struct CountPlan { int grid; bool split, cooperative; };
+static CountPlan count_plan(bool background) {
+  struct Caps { int wide = -1, narrow = -1; };
+  static Caps caps[16];
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return {0, false, false};
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    if (caps[dev].wide < 0) {
+      hipDeviceProp_t pr;
+      int per_wide = 0, per_narrow = 0;
+      if (hipGetDeviceProperties(&pr, dev) != hipSuccess ||
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_wide, counting_build_kernel<kCountGrid>, kCountThreads, 0) != hipSuccess ||
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_narrow, counting_build_kernel<kCountGridNarrow>, kCountThreads, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        caps[dev].wide = caps[dev].narrow = 0;
+      } else {
+        caps[dev].wide = pr.multiProcessorCount * per_wide >= kCountGrid ? 1 : 0;
+        caps[dev].narrow = pr.multiProcessorCount * per_narrow >= kCountGridNarrow ? 1 : 0;
+      }
+    }
+  }
+  const char* cv = std::getenv("GCONV_COUNT_COOPERATIVE");   // (read per call: tests and A/B runs)
+  const bool coop = cv && cv[0] == '1';
+  const char* bg = std::getenv("GCONV_BG_BUILD");   // (read per call: bench A/B)
+  if (background) {
+    if (bg && bg[0] == 'r') return {0, false, false};
+    if (bg && bg[0] == 'f') return {caps[dev].narrow ? kCountGridNarrow : 0, false, coop};
+    return {kCountGridNarrow, true, false};            // split launches need no co-residency at all
+  }
+  if (caps[dev].wide) return {kCountGrid, false, coop};
+  if (caps[dev].narrow) return {kCountGridNarrow, false, coop};
+  return {0, false, false};
 }
 
 static bool counting_build_ok(int64_t E, int32_t n) {   // (env read per call: the tests compare the builders)
@@ -1149,8 +1206,11 @@ extern "C" gconv_status_t gconv_graph_build_ex(const int64_t* edge_index, int64_
 
   const int T = 256;
   int32_t h[64];
-  // (GCONV_BUILD_BACKGROUND: no grid-wide launch next to the caller's other kernels — see the header)
-  CountState* cs = counting_build_ok(E, n) && !(flags & GCONV_BUILD_BACKGROUND) ? usable_state(true) : nullptr;
+  // Which one-launch builder this device and this call can take (count_plan): the wide grid in-stream when
+  // every workgroup can be resident at once, the narrow one as three barrier-free launches next to other
+  // kernels (GCONV_BUILD_BACKGROUND), none on a device too small for either -> the radix pipeline.
+  const CountPlan cp = counting_build_ok(E, n) ? count_plan((flags & GCONV_BUILD_BACKGROUND) != 0) : CountPlan{0, false, false};
+  CountState* cs = cp.grid > 0 ? usable_state(true) : nullptr;
   if (cs) {   // one launch (see counting_build_kernel)
     std::lock_guard<std::mutex> lock(cs->mu);
     if (cs->broken && cs->ensure(true) != GCONV_OK) return GCONV_E_WORKSPACE;   // (re-clearing after a give-up)
@@ -1163,9 +1223,31 @@ extern "C" gconv_status_t gconv_graph_build_ex(const int64_t* edge_index, int64_
     a.host_info = cs->host_info_dev;
     a.ntiles = L.ntiles; a.T = L.T; a.slack = slack; a.fwd = FWD; a.is = is;
     cs->arm();
-    counting_build_kernel<<<kCountGrid, kCountThreads, 0, stream>>>(a);
-    GCONV_LAUNCH_CHECK();
-    if (!cs->wait_mark(stream, h)) {
+    bool launched = true;
+    if (cp.split) {          // a launch per phase: nothing waits inside a kernel
+      for (int ph = 1; ph <= 4; ph <<= 1) {
+        a.phases = ph;
+        counting_build_kernel<kCountGridNarrow><<<kCountGridNarrow, kCountThreads, 0, stream>>>(a);
+      }
+    } else {
+      a.phases = 7;
+      if (cp.cooperative) {  // co-residency guaranteed by the runtime, or an immediate launch error
+        void* args[] = {&a};
+        const void* fn = cp.grid == kCountGrid ? reinterpret_cast<const void*>(&counting_build_kernel<kCountGrid>)
+                                               : reinterpret_cast<const void*>(&counting_build_kernel<kCountGridNarrow>);
+        if (hipLaunchCooperativeKernel(fn, dim3(cp.grid), dim3(kCountThreads), args, 0, stream) != hipSuccess) {
+          (void)hipGetLastError();   // too large for this device right now: the radix pipeline builds the plan
+          launched = false;
+        }
+      } else if (cp.grid == kCountGrid) {
+        counting_build_kernel<kCountGrid><<<kCountGrid, kCountThreads, 0, stream>>>(a);
+      } else {
+        counting_build_kernel<kCountGridNarrow><<<kCountGridNarrow, kCountThreads, 0, stream>>>(a);
+      }
+    }
+    if (launched) GCONV_LAUNCH_CHECK();
+    if (!launched) {
+    } else if (!cs->wait_mark(stream, h)) {
       GCONV_HIP(hipStreamSynchronize(stream));   // (a fault surfaces here)
       cs->broken = true;                       // gave up at a barrier: the radix pipeline below does the build
     } else {

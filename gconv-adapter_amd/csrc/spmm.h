@@ -48,6 +48,34 @@ struct RowShape {
 
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 
+// Cache-policy lab knobs of the SpMM (all 0 in the product build — DESIGN §4,
+// round 4): non-temporal policy for the streamed-once arrays, so that they do not compete with the
+// gathered H rows for the 4 MB L2s:  _Y_NT the output rows, _COL_NT the column ids, _SEG_NT the
+// gathers of the long rows' segment path (hub rows: 128 cold, read-once rows per segment wave).
+#ifndef GCONV_SPMM_Y_NT
+#define GCONV_SPMM_Y_NT 0
+#endif
+#ifndef GCONV_SPMM_COL_NT
+#define GCONV_SPMM_COL_NT 0
+#endif
+#ifndef GCONV_SPMM_SEG_NT
+#define GCONV_SPMM_SEG_NT 0
+#endif
+__device__ __forceinline__ int ld_col(const int32_t* p) {
+#if GCONV_SPMM_COL_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void st_y(float* p, f32x4 v) {
+#if GCONV_SPMM_Y_NT
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+#else
+  *reinterpret_cast<f32x4*>(p) = v;
+#endif
+}
+
 // Plain sum over a row's stored edges of the gathered rows of H — the one summation order of
 // every short row (<= GCONV_LONG_ROW edges) in the library: spmm_rows_kernel and the fused
 // gather kernels (fused_gather.hip) call this, so a row's result has the same bits whichever
@@ -72,7 +100,7 @@ __device__ __forceinline__ f32x4 row_gather_sum(const float* __restrict__ H, con
   const int elast = max(e1 - 1, 0);
   int cn[CPL];
 #pragma unroll
-  for (int j = 0; j < CPL; ++j) cn[j] = col[min(e0 + sub + j * LPR, elast)];
+  for (int j = 0; j < CPL; ++j) cn[j] = ld_col(col + min(e0 + sub + j * LPR, elast));
   f32x4 acc0 = zero4(), acc1 = zero4();
   for (int it = 0; it < nbat; ++it) {
     int cc[CPL];
@@ -80,7 +108,7 @@ __device__ __forceinline__ f32x4 row_gather_sum(const float* __restrict__ H, con
     for (int j = 0; j < CPL; ++j) cc[j] = cn[j];
     const int eb = e0 + 8 * it;
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) cn[j] = col[min(eb + 8 + sub + j * LPR, elast)];
+    for (int j = 0; j < CPL; ++j) cn[j] = ld_col(col + min(eb + 8 + sub + j * LPR, elast));
     f32x4 h[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {

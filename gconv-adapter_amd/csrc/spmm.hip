@@ -69,12 +69,12 @@ __device__ __forceinline__ void spmm_epilogue(const SpmmArgs& a, int row, int su
     v = (sum + self) * di;
   }
   if (EPI == EPI_STORE) {
-    stg4(a.Y + off, v);
+    st_y(a.Y + off, v);
   } else if (EPI == EPI_GENERIC) {
     if (a.bias) v += o.bias;
     for (int k = 0; k < 4; ++k) v[k] = act_fwd(a.act, v[k]);
     if (NORM && (a.flags & GCONV_SPMM_OUT_PRESCALE)) v *= di;
-    stg4(a.Y + off, v);
+    st_y(a.Y + off, v);
   } else if (EPI == EPI_FWD1) {
     // h1 = v + b_down ; h2 = act(h1) ; store h2 (row-scaled for the next hop)
     for (int k = 0; k < 4; ++k) {
@@ -84,7 +84,7 @@ __device__ __forceinline__ void spmm_epilogue(const SpmmArgs& a, int row, int su
     if (a.act == GCONV_ACT_SILU && a.Y2) stg4(a.Y2 + off, v);
     for (int k = 0; k < 4; ++k) v[k] = act_fwd(a.act, v[k]);
     if (NORM) v *= di;
-    stg4(a.Y + off, v);
+    st_y(a.Y + off, v);
   } else {  // EPI_BWD1: dh1 = dh2 * act'(h1); accumulate bias grad; store row-scaled dh1
     if (a.act == GCONV_ACT_RELU) {
       const f32x4 h2 = o.saved;  // dis * relu(h1): same sign pattern as relu(h1)
@@ -95,7 +95,7 @@ __device__ __forceinline__ void spmm_epilogue(const SpmmArgs& a, int row, int su
     }
     bias_grad += v;
     if (NORM) v *= di;
-    stg4(a.Y + off, v);
+    st_y(a.Y + off, v);
   }
 }
 
@@ -159,8 +159,12 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(SpmmArgs a) {
       f32x4 acc = zero4();
 #pragma unroll 4
       for (int e = e0 + grp; e < e1; e += RPW) {
-        int c = col[e];
+        int c = ld_col(col + e);
+#if GCONV_SPMM_SEG_NT
+        f32x4 h = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(H + static_cast<size_t>(c) * F + 4 * sub));
+#else
         f32x4 h = ldg4(H + static_cast<size_t>(c) * F + 4 * sub);
+#endif
         if (gather_scale) h *= a.dis[c];
         acc += h;
       }

@@ -1374,9 +1374,40 @@ def test_counting_graph_build_from_two_threads(dev):
     assert not errors, errors[0]
 
 
-def test_background_graph_build_equals_foreground_build(dev):
-    """GraphPlan(background=True) (GCONV_BUILD_BACKGROUND: the prefetch worker's builds) skips the grid-wide
-    one-launch builder; the plan is the same."""
+@pytest.mark.parametrize("mode", ["default", "split", "fused", "radix"])
+def test_background_graph_build_equals_foreground_build(dev, mode, monkeypatch):
+    """GraphPlan(background=True) (GCONV_BUILD_BACKGROUND: the prefetch worker's builds, next to the step's
+    kernels) never waits inside a kernel: the counting builder as one NARROW launch per phase (default /
+    `split`); `fused` = its narrow one-launch form, `radix` = the sort pipeline. Same plan every way, also
+    for the graphs that make the counting builder hand over to the radix pipeline."""
+    if mode != "default":
+        monkeypatch.setenv("GCONV_BG_BUILD", mode)
+    cases = []
+    for graphs in (512, 300, 2000):
+        b, _ = ga.synth.make_workload("hiv", graphs=graphs)
+        cases.append((b.edge_index, b.num_nodes))
+    cases.append((_random_graph(6000, 15000, 53, symmetric=False), 6000))                    # directed: radix after all
+    dl = _random_graph(5000, 6000, 52, symmetric=True)
+    cases.append((torch.cat([dl, dl[:, :500], torch.arange(100).repeat(2, 1)], dim=1), 5000))  # duplicates, self-loops
+    for ei, n in cases:
+        eid = ei.to(dev)
+        for normalize in (True, False):
+            fg = _plan_arrays(ga.GraphPlan(eid, n, normalize))
+            for _ in range(2):   # twice: the library-owned counters must be back at zero after a split build
+                _same(fg, _plan_arrays(ga.GraphPlan(eid, n, normalize, background=True)))
+    bad = cases[0][0].clone(); bad[1, 17] = cases[0][1] + 3
+    with pytest.raises(RuntimeError, match="outside"):
+        ga.GraphPlan(bad.to(dev), cases[0][1], True, background=True)
+    _same(_plan_arrays(ga.GraphPlan(cases[0][0].to(dev), cases[0][1], True)),
+          _plan_arrays(ga.GraphPlan(cases[0][0].to(dev), cases[0][1], True, background=True)))   # and fine after the refusal
+
+
+def test_cooperative_launch_of_the_counting_build(dev, monkeypatch):
+    """GCONV_COUNT_COOPERATIVE=1: the one-launch builder goes through hipLaunchCooperativeKernel (the runtime
+    checks that the whole grid can be resident, or refuses the launch -> radix pipeline). Same plan."""
     b, _ = ga.synth.make_workload("hiv")
     ei = b.edge_index.to(dev)
-    _same(_plan_arrays(ga.GraphPlan(ei, b.num_nodes, True)), _plan_arrays(ga.GraphPlan(ei, b.num_nodes, True, background=True)))
+    want = _plan_arrays(ga.GraphPlan(ei, b.num_nodes, True))
+    monkeypatch.setenv("GCONV_COUNT_COOPERATIVE", "1")
+    for _ in range(3):
+        _same(want, _plan_arrays(ga.GraphPlan(ei, b.num_nodes, True)))

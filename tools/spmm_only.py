@@ -16,3 +16,13 @@ for _ in range(20):
     ga.spmm(plan, h, flags=fl, out=y, workspace=ws)
 torch.cuda.synchronize()
 print("nnz", plan.fwd.nnz, "n_long", plan.fwd.n_long, "n_seg", plan.fwd.n_seg)
+if "--time" in sys.argv:   # launch time, HIP events, best of 5 x 50 (tools/lab/spmm_policy.sh)
+    best = 1e9
+    for _ in range(5):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(50):
+            ga.spmm(plan, h, flags=fl, out=y, workspace=ws)
+        b.record(); b.synchronize()
+        best = min(best, a.elapsed_time(b) / 50 * 1e3)
+    print("spmm us %.2f  lib %s" % (best, os.path.basename(os.environ.get("GCONV_ADAPTER_LIB", "product"))))

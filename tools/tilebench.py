@@ -11,6 +11,9 @@ from gconv_adapter_amd import _lib
 
 dev = torch.device("cuda:0")
 lib = _lib.load()
+if os.environ.get("GCONV_BENCH_HIDDEN"):   # lab: another hidden width for every workload (chunks per row = waves per workgroup)
+    for _w in ga.synth.WORKLOADS.values():
+        _w["d"] = int(os.environ["GCONV_BENCH_HIDDEN"])
 
 
 def ev(fn, iters=200, warm=10, reps=3):

@@ -16,6 +16,9 @@ if "--build-only" in sys.argv or not os.path.exists(alt):   # (build where hipcc
 if "--build-only" in sys.argv:
     sys.exit(0)
 _lib.LIB_PATH = alt
+if os.environ.get("GCONV_BENCH_HIDDEN"):   # lab: another hidden width for every workload (chunks per row = waves per workgroup)
+    for _w in ga.synth.WORKLOADS.values():
+        _w["d"] = int(os.environ["GCONV_BENCH_HIDDEN"])
 dev = torch.device("cuda:0")
 batch, cfg = ga.synth.make_workload(next((a for a in sys.argv[1:] if not a.startswith("-")), "hiv"))
 d, r = cfg["d"], cfg["r"]
