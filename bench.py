@@ -390,7 +390,7 @@ def measure_arxiv(device, iters: int = 50, banded_control: bool = False) -> dict
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "frac_of_measured_copy_peak": round(achieved / HBM_MEASURED_GBS, 4),
             "algorithmic_bytes": b, "avg_launch_us": round(ms * 1e3, 2), "traffic": None}
-    pmc = next((q for q in (os.path.join(ROOT, "profiles", f"r0{k}_spmm_arxiv_pmc.json") for k in (3, 2, 1))
+    pmc = next((q for q in (os.path.join(ROOT, "profiles", f"r0{k}_spmm_arxiv_pmc.json") for k in (4, 3, 2, 1))
                 if os.path.exists(q)), "")
     if os.path.exists(pmc):   # PMC passes cannot run inside the timed bench: committed rocprofv3 result
         with open(pmc) as fh:

@@ -995,11 +995,18 @@ static CountState* usable_state(bool device_block) {
 // How the counting builder may be launched on the current device. The fused launch spins at two grid
 // barriers, so ALL its workgroups must be able to be resident together: grid <= CUs x the kernel's
 // workgroups per CU (hipDeviceProp_t / the occupancy query, asked once per device) — a device too small
-// for the wide grid takes the narrow one, one too small for that takes the radix pipeline at once, instead of
-// finding out by a ~1 s spin. GCONV_COUNT_COOPERATIVE=1 launches it with hipLaunchCooperativeKernel (the
-// runtime then checks the same thing per launch and refuses with an error; measured slower, DESIGN §4
-// round 4). Background builds (next to the caller's kernels, which may hold every CU for a while) never
-// wait inside a kernel: one narrow launch per phase. GCONV_BG_BUILD=radix|split|fused overrides that.
+// for the wide grid takes the narrow one, one too small for that takes the radix pipeline at once, instead
+// of finding out by a ~1 s spin. GCONV_COUNT_COOPERATIVE=1 launches it with hipLaunchCooperativeKernel (the
+// runtime then checks the same thing per launch and refuses with an error): measured +9 us of wall time per
+// plan (HIV-512 49.7 -> 59.0 us, HIV-4096 130 -> 143; profiles/r04_lab_k0_background.txt), so it stays a knob.
+// Background builds (GCONV_BUILD_BACKGROUND: next to the caller's kernels, which may hold every CU for a
+// while) must not wait inside a kernel. Three flavours, all producing the same plan (GCONV_BG_BUILD):
+//   radix (default)  the multi-launch sort pipeline: 99 us of wall time per HIV-512 plan on an idle device,
+//                    but the LEAST disturbance to the step it runs beside (0.205 ms/step; 0.191 with a cached plan)
+//   split            this builder as one narrow launch (64 workgroups) per phase, no barrier: 48 us per plan,
+//                    0.217 ms/step — a few 256-thread workgroups that sit on 64 CUs for ~10 us each cost the
+//                    one-tile-per-CU kernels of the step a second round more often than a dozen 2 - 5 us kernels do
+//   fused            the narrow grid with its two barriers in one launch: 48 us per plan, 0.222 ms/step
 struct CountPlan { int grid; bool split, cooperative; };
 static CountPlan count_plan(bool background) {
   struct Caps { int wide = -1, narrow = -1; };
@@ -1027,9 +1034,9 @@ static CountPlan count_plan(bool background) {
   const bool coop = cv && cv[0] == '1';
   const char* bg = std::getenv("GCONV_BG_BUILD");   // (read per call: bench A/B)
   if (background) {
-    if (bg && bg[0] == 'r') return {0, false, false};
+    if (bg && bg[0] == 's') return {kCountGridNarrow, true, false};   // split launches need no co-residency at all
     if (bg && bg[0] == 'f') return {caps[dev].narrow ? kCountGridNarrow : 0, false, coop};
-    return {kCountGridNarrow, true, false};            // split launches need no co-residency at all
+    return {0, false, false};                          // radix pipeline (measured: least disturbance, see above)
   }
   if (caps[dev].wide) return {kCountGrid, false, coop};
   if (caps[dev].narrow) return {kCountGridNarrow, false, coop};

@@ -48,12 +48,15 @@ struct RowShape {
 
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-// Cache-policy lab knobs of the SpMM (all 0 in the product build — DESIGN §4,
-// round 4): non-temporal policy for the streamed-once arrays, so that they do not compete with the
-// gathered H rows for the 4 MB L2s:  _Y_NT the output rows, _COL_NT the column ids, _SEG_NT the
-// gathers of the long rows' segment path (hub rows: 128 cold, read-once rows per segment wave).
+// Cache policy of the SpMM's streamed-once arrays (round 4 A/B on S-arxiv, rank 32, tools/lab/spmm_policy.sh,
+// profiles/r04_lab_spmm_cache_policy.txt): non-temporal so that they do not compete with the gathered H
+// rows for the 4 MB L2s.   _Y_NT   the output rows: 26.4 -> 25.9 us, traffic 173.0 -> 170.3 MB, L2 hit
+//                                  0.340 -> 0.350: ON in the product build
+//                          _COL_NT the column ids: 28.0 us (a row's ids are re-read by its own lanes:
+//                                  they want to stay in L1 / L2); _SEG_NT the segment path's gathers (hub rows:
+//                                  128 read-once rows per segment wave): 26.9 us; all three: 28.7 us — off
 #ifndef GCONV_SPMM_Y_NT
-#define GCONV_SPMM_Y_NT 0
+#define GCONV_SPMM_Y_NT 1
 #endif
 #ifndef GCONV_SPMM_COL_NT
 #define GCONV_SPMM_COL_NT 0

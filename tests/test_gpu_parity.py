@@ -1377,9 +1377,10 @@ def test_counting_graph_build_from_two_threads(dev):
 @pytest.mark.parametrize("mode", ["default", "split", "fused", "radix"])
 def test_background_graph_build_equals_foreground_build(dev, mode, monkeypatch):
     """GraphPlan(background=True) (GCONV_BUILD_BACKGROUND: the prefetch worker's builds, next to the step's
-    kernels) never waits inside a kernel: the counting builder as one NARROW launch per phase (default /
-    `split`); `fused` = its narrow one-launch form, `radix` = the sort pipeline. Same plan every way, also
-    for the graphs that make the counting builder hand over to the radix pipeline."""
+    kernels) never waits inside a wide kernel: the sort pipeline (default / `radix`: measured to disturb the
+    step least), the counting builder as one NARROW launch per phase (`split`) or its narrow one-launch form
+    (`fused`). Same plan every way, also for the graphs that make the counting builder hand over to the
+    radix pipeline."""
     if mode != "default":
         monkeypatch.setenv("GCONV_BG_BUILD", mode)
     cases = []
