@@ -159,6 +159,12 @@ SIGNATURES = {
     "gconv_mlp_split_weights_bf16x3": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "gconv_mlp_split_rows_bf16x3": (_i32, [_vp, _i32, _i32, _vp, _vp]),
     "gconv_mlp_gemm_bf16x3": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "gconv_mlp_weights_pair_bytes": (_sz, [_i32, _i32]),
+    "gconv_mlp_rows_pair_bytes": (_sz, [_i32, _i32]),
+    "gconv_mlp_split_weights_f16x2": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "gconv_mlp_split_rows_f16x2": (_i32, [_vp, _i32, _i32, _vp, _vp]),
+    "gconv_mlp_gemm_f16x2": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "gconv_gin_aggregate_f16x2": (_i32, [_csr_p, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "gconv_gin_code_count_bytes": (_sz, [_i32]),
     "gconv_gin_code_count": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "gconv_gin_aggregate_f32": (_i32, [_csr_p, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),

@@ -14,7 +14,7 @@
 // row, a row of d floats as float4 lanes (d = 300: 75 of them, two passes), fixed summation
 // order, no float atomics. The gradient w.r.t. x (what an earlier adapter needs from a frozen
 // layer) is the same kernel on the transposed CSR without the bond term.
-#include "common.h"
+#include "mlp_split.h"
 
 namespace gconv {
 
@@ -43,14 +43,19 @@ __global__ __launch_bounds__(256) void gin_code_count_kernel(const int64_t* __re
 // bond-embedding rows live in registers (9 x NP float4 per lane): re-reading them per row cost
 // 3.6x the row's own L1 traffic (18 table loads against ~5 row loads) and made the bond term as
 // expensive as the neighbour sum.
-template <int NP, bool BOND>
+// SPLIT (round 4): the row leaves as the scaled fp16 PAIR the frozen layer's MLP multiplies (mlp_split.h;
+// out2 = [2][n][Kp] fp16, rexp[n]) — the fp32 aggregate and the separate split pass over it (a 15.7 MB
+// round trip and a launch per layer on a 512-molecule batch) never exist.
+template <int NP, bool BOND, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gin_aggregate_kernel(const int32_t* __restrict__ rowptr,
                                                             const int32_t* __restrict__ col,
                                                             const float* __restrict__ x,
                                                             const int32_t* __restrict__ count,
                                                             const float* __restrict__ emb_type,
                                                             const float* __restrict__ emb_dir,
-                                                            float* __restrict__ out, int n, int d) {
+                                                            float* __restrict__ out, int n, int d,
+                                                            _Float16* __restrict__ out2 = nullptr,
+                                                            int32_t* __restrict__ rexp = nullptr) {
   const int lane = threadIdx.x & 63;
   const int nq = d >> 2;
   f32x4 table[BOND ? (kBondTypes + kBondDirs) : 1][NP];
@@ -119,12 +124,48 @@ __global__ __launch_bounds__(256) void gin_aggregate_kernel(const int32_t* __res
         for (int k = 0; k < kBondDirs; ++k) acc[p] += table[kBondTypes + k][p] * nd[k];
       }
     }
+    if constexpr (SPLIT) {
+      float m = 0.f;
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int q = lane + 64 * p;
-      if (q < nq) stg4(out + static_cast<size_t>(row) * d + 4 * q, acc[p]);
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m = fmaxf(m, fabsf(acc[p][k]));   // (lanes past the row hold zeros)
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+      const int e = scale_exp(m);
+      const int kp = mlp_pad_k(d);
+      const size_t img = static_cast<size_t>(n) * kp;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int q = lane + 64 * p;
+        if (4 * q < kp) {   // columns d .. Kp: zeros
+          f16x4 h, l;
+          split2x4(acc[p], e, h, l);
+          const size_t o = static_cast<size_t>(row) * kp + 4 * q;
+          *reinterpret_cast<f16x4*>(out2 + o) = h;
+          *reinterpret_cast<f16x4*>(out2 + img + o) = l;
+        }
+      }
+      if (lane == 0) rexp[row] = e;
+    } else {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int q = lane + 64 * p;
+        if (q < nq) stg4(out + static_cast<size_t>(row) * d + 4 * q, acc[p]);
+      }
     }
   }
+}
+
+template <int NP>
+static void launch_gin_aggregate_pair(const gconv_csr_t* csr, const float* x, const int32_t* count,
+                                      const float* emb_type, const float* emb_dir, void* out_pair, int d,
+                                      hipStream_t stream) {
+  const int grid = min(ceil_div(csr->num_nodes, 4), kNumCU * 4);
+  _Float16* o = static_cast<_Float16*>(out_pair);
+  int32_t* rexp = reinterpret_cast<int32_t*>(static_cast<char*>(out_pair) + mlp_pair_exp_offset(csr->num_nodes, d));
+  gin_aggregate_kernel<NP, true, true><<<grid, 256, 0, stream>>>(csr->rowptr, csr->col, x, count, emb_type, emb_dir,
+                                                                 nullptr, csr->num_nodes, d, o, rexp);
 }
 
 template <int NP>
@@ -183,6 +224,28 @@ extern "C" gconv_status_t gconv_gin_aggregate_f32(const gconv_csr_t* csr, const 
     case 2: launch_gin_aggregate<2>(csr, x, code_count, emb_type, emb_dir, out, hidden, stream); break;
     case 3: launch_gin_aggregate<3>(csr, x, code_count, emb_type, emb_dir, out, hidden, stream); break;
     default: launch_gin_aggregate<4>(csr, x, code_count, emb_type, emb_dir, out, hidden, stream); break;
+  }
+  GCONV_LAUNCH_CHECK();
+  return GCONV_OK;
+}
+
+// The same aggregation (bond term included), written as the scaled fp16 pair the frozen MLP's first GEMM
+// multiplies (gconv_mlp_gemm_f16x2's `a_pair`; gconv_mlp_rows_pair_bytes(num_nodes, hidden) bytes).
+extern "C" gconv_status_t gconv_gin_aggregate_f16x2(const gconv_csr_t* csr, const float* x,
+                                                    const int32_t* code_count, const float* emb_type,
+                                                    const float* emb_dir, void* out_pair, int32_t hidden,
+                                                    gconv_stream_t stream_) {
+  if (!csr || !csr->rowptr || (csr->nnz > 0 && !csr->col) || csr->num_nodes < 0) return GCONV_E_INVALID_ARG;
+  if (hidden <= 0 || hidden % 4 != 0 || hidden > 256 * kGinPasses) return GCONV_E_UNSUPPORTED;
+  if (csr->num_nodes == 0) return GCONV_OK;
+  if (!x || !out_pair || !code_count || !emb_type || !emb_dir) return GCONV_E_INVALID_ARG;
+  if (!aligned16(x) || !aligned16(out_pair) || !aligned16(emb_type) || !aligned16(emb_dir)) return GCONV_E_ALIGNMENT;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  switch (ceil_div(mlp_pad_k(hidden), 256)) {
+    case 1: launch_gin_aggregate_pair<1>(csr, x, code_count, emb_type, emb_dir, out_pair, hidden, stream); break;
+    case 2: launch_gin_aggregate_pair<2>(csr, x, code_count, emb_type, emb_dir, out_pair, hidden, stream); break;
+    case 3: launch_gin_aggregate_pair<3>(csr, x, code_count, emb_type, emb_dir, out_pair, hidden, stream); break;
+    default: launch_gin_aggregate_pair<4>(csr, x, code_count, emb_type, emb_dir, out_pair, hidden, stream); break;
   }
   GCONV_LAUNCH_CHECK();
   return GCONV_OK;

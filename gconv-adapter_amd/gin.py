@@ -18,11 +18,15 @@ scatter-adds it — per layer. Here (``csrc/gin.hip``):
   * backward of a frozen layer only needs d agg -> d x: the same kernel on the transposed CSR.
 
 The MLP (300 -> 600 -> 300) of a FROZEN layer — the adapter recipe freezes the backbone,
-``gnn.py:230-241`` — runs on a hand-written bf16x3 MFMA kernel (``csrc/mlp.hip``: every fp32
-operand as three bf16 values, six products per fp32 product, fp32 accumulation; fp32-accurate,
-``tests/test_gin.py::test_gin_mlp_bf16x3_is_fp32_accurate``), forward and input gradient. A
-backbone that trains its MLP keeps ``nn.Linear`` (weight gradients are torch's business);
-``GCONV_TORCH_MLP=1`` is the A/B knob.
+``gnn.py:230-241`` — runs on hand-written MFMA kernels at fp32 accuracy, forward and input gradient:
+round 4 ``csrc/mlp_f16.hip`` (every fp32 operand as TWO fp16 values of a power-of-two scaled copy —
+one exponent per activation row / weight matrix — three products per fp32 product, fp32
+accumulation), round 3 ``csrc/mlp.hip`` (three bf16 values, six products; ``GCONV_MLP_BF16X3=1``).
+With the bond-embedding tables frozen as well the whole layer is ONE autograd node
+(``GinFrozenLayerFunction``): the aggregation writes the MLP's operand directly, the fp32 aggregate
+never exists. Parity gate: ``tests/test_gin.py::test_gin_mlp_is_fp32_accurate`` (1e-5 vs fp64, at most
+twice torch-fp32's own error). A backbone that trains its MLP keeps ``nn.Linear`` (weight gradients are
+torch's business); ``GCONV_TORCH_MLP=1`` is the A/B knob.
 """
 from __future__ import annotations
 
@@ -217,6 +221,140 @@ class GinMlpFunction(torch.autograd.Function):
         return ga, None
 
 
+#: A/B knob: ``GCONV_MLP_BF16X3=1`` keeps round 3's bf16-triple kernels (six products per fp32 product)
+MLP_BF16X3 = bool(os.environ.get("GCONV_MLP_BF16X3"))
+
+
+class _PairWeights:
+    """A frozen weight as the scaled fp16 pair of ``csrc/mlp_f16.hip`` (``gconv_mlp_split_weights_f16x2``:
+    both images, and beside them 2^-exponent, the largest row 1-norm and the largest |bias| — what the
+    GEMM's epilogue needs to un-scale and to bound the hidden activation). Invalidation: ``_SplitWeights``."""
+
+    def __init__(self):
+        self.key, self.buf = None, None
+
+    def get(self, w: torch.Tensor, bias: Optional[torch.Tensor], transpose: bool) -> torch.Tensor:
+        key = (w.data_ptr(), w._version, w.device, tuple(w.shape), transpose,
+               None if bias is None else (bias.data_ptr(), bias._version))
+        if key != self.key:
+            lib = _lib.load()
+            rows, cols = w.shape
+            m, k = (cols, rows) if transpose else (rows, cols)
+            buf = torch.empty(int(lib.gconv_mlp_weights_pair_bytes(m, k)), dtype=torch.uint8, device=w.device)
+            wc = w.detach().contiguous()
+            _lib.check(lib.gconv_mlp_split_weights_f16x2(wc.data_ptr(), None if bias is None else bias.detach().data_ptr(),
+                                                         rows, cols, int(transpose), buf.data_ptr(),
+                                                         _stream(w.device.index)), "mlp_split_weights_f16x2")
+            self.key, self.buf = key, buf
+        return self.buf
+
+
+def _rows_pair(x: torch.Tensor) -> torch.Tensor:
+    """The scaled fp16 pair of a [N, F] fp32 matrix, one exponent per row (``gconv_mlp_split_rows_f16x2``)."""
+    lib = _lib.load()
+    n, f = x.shape
+    out = torch.empty(int(lib.gconv_mlp_rows_pair_bytes(n, f)), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.gconv_mlp_split_rows_f16x2(x.data_ptr(), n, f, out.data_ptr(), _stream(x.device.index)),
+               "mlp_split_rows_f16x2")
+    return out
+
+
+def _aggregate_pair(csr, x: torch.Tensor, counts, emb_type, emb_dir) -> torch.Tensor:
+    """``_aggregate`` with the result written as the MLP's operand pair (no fp32 aggregate)."""
+    lib = _lib.load()
+    n, d = x.shape
+    out = torch.empty(int(lib.gconv_mlp_rows_pair_bytes(n, d)), dtype=torch.uint8, device=x.device)
+    dev = x.device
+    if dev.index != torch.cuda.current_device():
+        torch.cuda.set_device(dev)
+    st = lib.gconv_gin_aggregate_f16x2(csr.ref(), x.data_ptr(), counts.data_ptr(), emb_type.data_ptr(),
+                                       emb_dir.data_ptr(), out.data_ptr(), d, _stream(dev.index))
+    if st != 0:
+        _lib.check(st, "gin_aggregate_f16x2")
+    return out
+
+
+def _pair_gemm(a2: torch.Tensor, n: int, k: int, w2: torch.Tensor, bias, mask2, m: int, epilogue: int,
+               split_out: bool) -> torch.Tensor:
+    """``epi(A W^T + bias)`` on the fp16 MFMA (``gconv_mlp_gemm_f16x2``); A and W as scaled pairs, the result as
+    fp32 ``[n, m]`` or — the hidden activation — as a pair again."""
+    lib = _lib.load()
+    dev = a2.device
+    if split_out:
+        out = torch.empty(int(lib.gconv_mlp_rows_pair_bytes(n, m)), dtype=torch.uint8, device=dev)
+    else:
+        out = torch.empty(n, m, dtype=torch.float32, device=dev)
+    st = lib.gconv_mlp_gemm_f16x2(a2.data_ptr(), w2.data_ptr(), None if bias is None else bias.data_ptr(),
+                                  None if mask2 is None else mask2.data_ptr(),
+                                  None if split_out else out.data_ptr(), out.data_ptr() if split_out else None,
+                                  n, k, m, epilogue, _stream(dev.index))
+    if st != 0:
+        _lib.check(st, "mlp_gemm_f16x2")
+    return out
+
+
+def _pair_mlp_forward(a2, n, mod):
+    l1, l2 = mod.mlp[0], mod.mlp[2]
+    pw = mod._mlp_pair
+    h2 = _pair_gemm(a2, n, l1.in_features, pw[0].get(l1.weight, l1.bias, False), l1.bias, None, l1.out_features, 1, True)
+    y = _pair_gemm(h2, n, l1.out_features, pw[1].get(l2.weight, l2.bias, False), l2.bias, None, l2.out_features, 0, False)
+    return h2, y
+
+
+def _pair_mlp_backward(gy, h2, mod):
+    l1, l2 = mod.mlp[0], mod.mlp[2]
+    pw = mod._mlp_pair
+    n = gy.shape[0]
+    g2 = _rows_pair(gy)
+    gh2 = _pair_gemm(g2, n, l2.out_features, pw[2].get(l2.weight, None, True), None, h2, l2.in_features, 2, True)
+    return _pair_gemm(gh2, n, l2.in_features, pw[3].get(l1.weight, None, True), None, None, l1.in_features, 0, False)
+
+
+class GinPairMlpFunction(torch.autograd.Function):
+    """``mlp(agg)`` of the frozen layer on the fp16 MFMA (``csrc/mlp_f16.hip``): split(agg) into a scaled pair,
+    H = relu(agg W1^T + b1) written as a pair, Y = H W2^T + b2; input gradient the same way back (the ReLU
+    mask is read off H's hi image). No weight gradients: only used while the MLP's parameters are frozen."""
+
+    @staticmethod
+    def forward(ctx, agg, mod):
+        _require_hip_f32(agg, "agg")
+        agg = agg.contiguous()
+        h2, y = _pair_mlp_forward(_rows_pair(agg), agg.shape[0], mod)
+        ctx.mod = mod
+        ctx.save_for_backward(h2)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (h2,) = ctx.saved_tensors
+        return _pair_mlp_backward(gy.contiguous(), h2, ctx.mod), None
+
+
+class GinFrozenLayerFunction(torch.autograd.Function):
+    """The WHOLE frozen layer (``gin_conv.py:38-85`` with every parameter frozen, the adapter recipe) as one
+    node: aggregation -> the MLP's operand pair (no fp32 aggregate, no split pass) -> two GEMMs; backward: split
+    of dY, two GEMMs, the aggregation on the transposed CSR. Saves the hidden pair only."""
+
+    @staticmethod
+    def forward(ctx, x, plan: GraphPlan, counts, mod):
+        _require_hip_f32(x, "x")
+        x = x.contiguous()
+        if x.dim() != 2 or x.shape[0] != plan.num_nodes:
+            raise RuntimeError(f"x must be [{plan.num_nodes}, d], got {tuple(x.shape)}")
+        a2 = _aggregate_pair(plan.fwd, x, counts, mod.edge_embedding_type.weight.detach().contiguous(),
+                             mod.edge_embedding_direction.weight.detach().contiguous())
+        h2, y = _pair_mlp_forward(a2, x.shape[0], mod)
+        ctx.mod, ctx.plan = mod, plan
+        ctx.save_for_backward(h2)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (h2,) = ctx.saved_tensors
+        ga = _pair_mlp_backward(gy.contiguous(), h2, ctx.mod)
+        return _aggregate(ctx.plan.bwd, ga, None, None, None), None, None, None
+
+
 class MolecularGINConv(nn.Module):
     """Drop-in for the reference's ``MolecularGINConv`` (module docstring)."""
 
@@ -246,6 +384,7 @@ class MolecularGINConv(nn.Module):
         Called after ``load_state_dict`` and ``.to()`` / ``.cuda()`` / ``.float()``; call it yourself
         after writing the frozen weights through ``.data`` (which no version counter sees)."""
         self.__dict__["_mlp_split"] = [_SplitWeights() for _ in range(4)]
+        self.__dict__["_mlp_pair"] = [_PairWeights() for _ in range(4)]
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -255,6 +394,7 @@ class MolecularGINConv(nn.Module):
     def __getstate__(self):   # (device buffers keyed on the original's parameters: not part of a copy)
         state = self.__dict__.copy()
         state["_mlp_split"] = [_SplitWeights() for _ in range(4)]
+        state["_mlp_pair"] = [_PairWeights() for _ in range(4)]
         return state
 
     def _mlp_is_frozen(self) -> bool:
@@ -266,10 +406,17 @@ class MolecularGINConv(nn.Module):
         n = x.shape[0]
         plan = get_plan(edge_index, n, False)
         counts = edge_code_counts(edge_index, edge_attr, n, self.validate_edge_attr)
+        native_mlp = (self._mlp_is_frozen() and not TORCH_MLP and x.dtype == torch.float32 and x.dim() == 2
+                      and x.shape[1] % 4 == 0)
+        tables_frozen = not (self.edge_embedding_type.weight.requires_grad
+                             or self.edge_embedding_direction.weight.requires_grad)
+        if native_mlp and tables_frozen and not MLP_BF16X3:
+            # every parameter frozen (the adapter recipe, gnn.py:230-241): ONE node for the whole layer
+            return GinFrozenLayerFunction.apply(x, plan, counts, self)
         agg = GinAggregateFunction.apply(x, self.edge_embedding_type.weight, self.edge_embedding_direction.weight,
                                          plan, counts)
-        # frozen MLP (the adapter recipe, gnn.py:230-241): the bf16x3 MFMA kernel, input gradient only;
-        # a backbone that trains its MLP keeps nn.Linear (weight gradients are torch's business)
-        if self._mlp_is_frozen() and not TORCH_MLP and agg.dtype == torch.float32 and agg.shape[1] % 4 == 0:
-            return GinMlpFunction.apply(agg, self)
+        # frozen MLP: the MFMA kernels, input gradient only; a backbone that trains its MLP keeps nn.Linear
+        # (weight gradients are torch's business)
+        if native_mlp:
+            return (GinMlpFunction if MLP_BF16X3 else GinPairMlpFunction).apply(agg, self)
         return self.mlp(agg)

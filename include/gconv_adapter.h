@@ -572,6 +572,36 @@ gconv_status_t gconv_mlp_gemm_bf16x3(const void* a_split, const void* w_split, c
                                      int32_t in_features, int32_t out_features, int32_t epilogue,
                                      gconv_stream_t stream);
 
+/* ---- the same MLP on the fp16 MFMA (round 4, ABI 8): two images + power-of-two scaling ---------
+ * replaces the same reference lines as the bf16 triple above (`gin_conv.py:24-28,85`); half the matrix
+ * work, two thirds of the operand bytes, the same fp32 accuracy (`csrc/mlp_f16.hip`). An fp32 matrix
+ * travels as a "scaled pair": x 2^e = hi + lo in fp16 (11 + 11 mantissa bits), with ONE exponent e per row
+ * of an activation / gradient matrix (the row's largest magnitude, or a bound of it, lands in [16, 32))
+ * and one per weight matrix; |x| < 2^100.
+ *   row pair    [2][N][Fp] fp16 images (Fp = F rounded up to 32, padding zero) followed, 16-byte aligned,
+ *               by int32 e[N]: gconv_mlp_rows_pair_bytes(N, F) bytes
+ *   weight pair [2][Mp][Kp] fp16 images of W 2^e followed by 4 floats {2^-e, max row 1-norm, max |bias|,
+ *               e as int bits}: gconv_mlp_weights_pair_bytes(M, K) bytes; `bias` (nullable) is the bias the
+ *               GEMM using this pair will add — its maximum enters the bound of the hidden activation
+ *   gconv_mlp_gemm_f16x2: C = epi(A W^T + bias) in true units; exactly one of `c_f32` ([N, M] fp32) and
+ *     `c_pair` (row pair, exponents written) is non-NULL. epilogue 0 none, 1 ReLU, 2 multiply by
+ *     [mask > 0], `mask_pair` = the row pair of a ReLU output ([N, M]: its hi image is read).
+ *   gconv_gin_aggregate_f16x2: `gconv_gin_aggregate_f32` with the bond term, the result written as the row
+ *     pair the first GEMM multiplies — the fp32 aggregate and the split pass over it never exist.      */
+size_t gconv_mlp_weights_pair_bytes(int32_t out_features, int32_t in_features);
+size_t gconv_mlp_rows_pair_bytes(int32_t num_rows, int32_t features);
+gconv_status_t gconv_mlp_split_weights_f16x2(const float* w, const float* bias, int32_t rows, int32_t cols,
+                                             int32_t transpose, void* out, gconv_stream_t stream);
+gconv_status_t gconv_mlp_split_rows_f16x2(const float* x, int32_t num_rows, int32_t features, void* out,
+                                          gconv_stream_t stream);
+gconv_status_t gconv_mlp_gemm_f16x2(const void* a_pair, const void* w_pair, const float* bias,
+                                    const void* mask_pair, float* c_f32, void* c_pair, int32_t num_rows,
+                                    int32_t in_features, int32_t out_features, int32_t epilogue,
+                                    gconv_stream_t stream);
+gconv_status_t gconv_gin_aggregate_f16x2(const gconv_csr_t* csr, const float* x, const int32_t* code_count,
+                                         const float* emb_type, const float* emb_dir, void* out_pair,
+                                         int32_t hidden, gconv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -142,41 +142,96 @@ def test_gin_layer_directed_graphs_with_duplicates_and_loops(dev, n, e, d):
     _check(dev, x, ei, _bond_attr(e, 7), d, 2, frozen=False)
 
 
+def _mlp_fn(scheme):
+    return {"f16x2": ga.gin.GinPairMlpFunction, "bf16x3": ga.gin.GinMlpFunction}[scheme]
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("scheme", ["f16x2", "bf16x3"])
 @pytest.mark.parametrize("n,d", [(1, 8), (130, 64), (777, 300), (13104, 300), (2000, 1024)])
-def test_gin_mlp_bf16x3_is_fp32_accurate(dev, n, d):
-    """The frozen layer's MLP on the bf16x3 MFMA kernel (csrc/mlp.hip: every fp32 operand as three
-    bf16 values, six products per fp32 product, fp32 accumulation) against the fp64 MLP: forward and
-    input gradient within rtol = atol = 1e-5 (atol relative to the tensor's scale, as for every sum
-    of hundreds of O(1) terms here), and no worse than twice the error of torch's fp32 GEMMs on the
-    same data — fp32-accurate, which is the gate for using it (GCONV_TORCH_MLP=1 is the A/B knob)."""
+def test_gin_mlp_is_fp32_accurate(dev, n, d, scheme):
+    """The frozen layer's MLP on the MFMA kernels — round 4: csrc/mlp_f16.hip (every fp32 operand as two fp16
+    values of a power-of-two scaled copy, three products per fp32 product), round 3: csrc/mlp.hip (three bf16
+    values, six products), fp32 accumulation — against the fp64 MLP: forward and input gradient within
+    rtol = atol = 1e-5 (atol relative to the tensor's scale, as for every sum of hundreds of O(1) terms
+    here), and no worse than twice the error of torch's fp32 GEMMs on the same data — fp32-accurate, which
+    is the gate for using it (GCONV_TORCH_MLP=1 is the A/B knob)."""
     gen = torch.Generator().manual_seed(n + d)
     layer = ga.MolecularGINConv(d).to(dev)
     for p in layer.parameters():
         p.requires_grad_(False)
     a = torch.randn(n, d, generator=gen)
     g = torch.randn(n, d, generator=gen)
+    _mlp_case(dev, layer, a, g, scheme)
+
+
+def _mlp_case(dev, layer, a, g, scheme, row_scaled=False):
+    fn = _mlp_fn(scheme)
     w1, b1, w2, b2 = (layer.mlp[0].weight, layer.mlp[0].bias, layer.mlp[2].weight, layer.mlp[2].bias)
     a64 = a.double().requires_grad_(True)
     h64 = torch.relu(torch.nn.functional.linear(a64, w1.cpu().double(), b1.cpu().double()))
     y64 = torch.nn.functional.linear(h64, w2.cpu().double(), b2.cpu().double())
     y64.backward(g.double())
     ad = a.to(dev).requires_grad_(True)
-    y = ga.gin.GinMlpFunction.apply(ad, layer)
+    y = fn.apply(ad, layer)
     y.backward(g.to(dev))
     at = a.to(dev).requires_grad_(True)
     yt = layer.mlp(at)                                   # torch's fp32 GEMMs on the same data
     yt.backward(g.to(dev))
-    # a hidden unit within 3e-5 of the ReLU kink may switch sides in any fp32 evaluation: leave the
-    # input-gradient rows of such nodes out (see _check)
+    # a hidden unit within 3e-5 (of its row's scale) of the ReLU kink may switch sides in any fp32 evaluation:
+    # leave the input-gradient rows of such nodes out (see _check)
     pre = torch.nn.functional.linear(a.double(), w1.cpu().double(), b1.cpu().double())
-    safe = ~(pre.abs() < 3e-5).any(1)
+    safe = ~(pre.abs() < 3e-5 * pre.abs().amax(1, keepdim=True).clamp(min=1e-30 if row_scaled else 1.0)).any(1)
     for got, ref, want, what in ((y, yt, y64.detach(), "out"), (ad.grad[safe.to(dev)], at.grad[safe.to(dev)],
                                                                  a64.grad[safe], "d agg")):
         got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+        if row_scaled:   # rows of very different magnitude: every row against its own scale
+            scale = want.abs().amax(1, keepdim=True).clamp(min=1e-30)
+            got, ref, want = got / scale, ref / scale, want / scale
+        assert torch.isfinite(got).all(), what
         assert_close(got, want, what, 1e-5, grad_atol(want))
         assert (got - want).abs().max() <= 2.0 * (ref - want).abs().max() + 1e-7, what
-    assert torch.equal(ga.gin.GinMlpFunction.apply(ad, layer), y)     # bitwise repeatable
+    assert torch.equal(fn.apply(ad, layer), y)     # bitwise repeatable
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["tiny_rows", "huge_rows", "mixed_rows", "zero_rows", "big_bias", "big_weights",
+                                  "one_hot_rows"])
+def test_gin_mlp_f16x2_scaling_holds_over_the_fp32_range(dev, case):
+    """The fp16 pair lives on its power-of-two scaling (one exponent per activation row, one per weight
+    matrix, the hidden activation's from a bound): rows of magnitude 1e-12 .. 1e12 (gradients are tiny, some
+    backbones' activations are not), rows that are exactly zero, a bias or weights far larger than the
+    inputs — every row accurate relative to ITS OWN scale, nothing overflows fp16's 65504."""
+    n, d = 640, 300
+    gen = torch.Generator().manual_seed(len(case))
+    layer = ga.MolecularGINConv(d).to(dev)
+    for p in layer.parameters():
+        p.requires_grad_(False)
+    a = torch.randn(n, d, generator=gen)
+    g = torch.randn(n, d, generator=gen)
+    mag = torch.ones(n, 1)
+    if case == "tiny_rows":
+        mag = torch.full((n, 1), 1e-9)
+    elif case == "huge_rows":
+        mag = torch.full((n, 1), 1e9)
+    elif case == "mixed_rows":
+        mag = 10.0 ** torch.randint(-12, 13, (n, 1), generator=gen).float()
+    elif case == "zero_rows":
+        mag[::3] = 0.0
+    elif case == "one_hot_rows":
+        a = torch.zeros(n, d)
+        a[torch.arange(n), torch.randint(0, d, (n,), generator=gen)] = 3.0
+    with torch.no_grad():
+        if case == "big_bias":
+            layer.mlp[0].bias.mul_(1e4)
+            layer.mlp[2].bias.mul_(1e4)
+        if case == "big_weights":
+            layer.mlp[0].weight.mul_(300.0)
+            layer.mlp[2].weight.mul_(1e-3)
+    layer.invalidate_mlp_split()
+    # the forward's rows scale with `mag`; the gradient's rows get an independent spread
+    gmag = 10.0 ** torch.randint(-10, 3, (n, 1), generator=gen).float() if case == "mixed_rows" else torch.ones(n, 1) * 1e-6
+    _mlp_case(dev, layer, a * mag, g * gmag, "f16x2", row_scaled=True)
 
 
 @pytest.mark.gpu
@@ -290,3 +345,37 @@ def test_relational_bias_matches_restatement(dev, heads, d, trans, kind):
     close(got, want.detach(), "out")
     close(xd.grad, x64.grad, "dx")
     close(bd.grad, b64.grad, "db", atol=1e-5 * max(1.0, float(b64.grad.abs().max())))
+
+
+@pytest.mark.gpu
+def test_frozen_weight_images_follow_the_weights(dev):
+    """The frozen MLP multiplies cached fp16 / bf16 images of its weights. `load_state_dict` and `.to()`
+    rebuild them (hooks); a write through `.data`, which no version counter sees, needs
+    `invalidate_mlp_split()` (round-3 advisor finding: it silently kept the stale images)."""
+    batch, cfg = ga.synth.make_workload("esol")
+    d = cfg["d"]
+    ei = batch.edge_index.to(dev)
+    ea = _bond_attr(ei.shape[1], 11).to(dev)
+    layer = ga.MolecularGINConv(d).to(dev)
+    for p in layer.parameters():
+        p.requires_grad_(False)
+    x = batch.x.to(dev)
+
+    def want():
+        agg = ga.gin.GinAggregateFunction.apply(x, layer.edge_embedding_type.weight, layer.edge_embedding_direction.weight,
+                                                ga.get_plan(ei, x.shape[0], False), ga.gin.edge_code_counts(ei, ea, x.shape[0]))
+        return layer.mlp(agg)
+
+    def close(a, b):
+        return torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
+    y1 = layer(x, ei, ea)
+    assert close(y1, want())
+    other = ga.MolecularGINConv(d).state_dict()
+    layer.load_state_dict(other)                      # hook: images rebuilt
+    y2 = layer(x, ei, ea)
+    assert close(y2, want()) and not close(y2, y1)
+    layer.mlp[0].weight.data.mul_(2.0)                # invisible to the cache key ...
+    assert torch.equal(layer(x, ei, ea), y2)          # ... so the stale images are still in use
+    layer.invalidate_mlp_split()
+    y3 = layer(x, ei, ea)
+    assert close(y3, want()) and not close(y3, y2)
