@@ -40,10 +40,6 @@ __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; 
 // T / 4 (T / 2 .. T / 6: 39.2 .. 40.1); 4096 molecules 156.3 -> 154.7 at T = 101 (4 tiles per workgroup,
 // slack T) against 170.7 at T = 58 / slack T / 4 (7 per workgroup, a third of them with a halo);
 // 32 molecules 24.6 -> 23.6 at T = 16.
-// CUs the fused tile kernels spread over (the grid of their persistent workgroups, and the divisor of the
-// tile size rule): all of them, unless GCONV_TILE_CUS leaves some to a CU-masked prefetch stream
-// (graph.py, GCONV_PREFETCH_CUS — lab knob of round 4).
-int tile_cus();                                // graph_prep.hip
 int tile_nominal(int n);                       // graph_prep.hip (reads GCONV_TILE_NODES_OVERRIDE / _MAX)
 int tile_slack(int T, int n);                  // how far below its nominal position a cut may sit
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

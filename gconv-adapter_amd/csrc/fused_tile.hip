@@ -1070,7 +1070,7 @@ GCONV_TILE_DEFINE_FP(GCONV_TILE_ONLY_FP)
   }
 
 int tile_grid(int n_tiles) {  // persistent: one workgroup per CU
-  const int kMax = tile_cus() * (GCONV_TILE_WGPC >= 2 ? 2 : 1);
+  constexpr int kMax = kNumCU * (GCONV_TILE_WGPC >= 2 ? 2 : 1);
   return n_tiles < kMax ? (n_tiles > 0 ? n_tiles : 1) : kMax;
 }
 

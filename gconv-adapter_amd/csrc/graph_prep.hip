@@ -26,15 +26,6 @@
 
 namespace gconv {
 
-int tile_cus() {
-  static const int v = [] {
-    const char* e = std::getenv("GCONV_TILE_CUS");
-    const int k = e ? std::atoi(e) : 0;
-    return k >= 16 && k <= kNumCU ? k : kNumCU;
-  }();
-  return v;
-}
-
 int tile_nominal(int n) {
   static const int forced = [] {
     const char* v = std::getenv("GCONV_TILE_NODES_OVERRIDE");
@@ -47,9 +38,9 @@ int tile_nominal(int n) {
     return k >= GCONV_TILE_NODES ? k : GCONV_TILE_NODES_MAX;
   }();
   if (n <= 0) return GCONV_TILE_NODES;
-  const int per_wg = ceil_div(n, tile_cus());
+  const int per_wg = ceil_div(n, kNumCU);
   const int k = ceil_div(per_wg, tmax);             // tiles per workgroup
-  const int t = ceil_div(n, tile_cus() * k);
+  const int t = ceil_div(n, kNumCU * k);
   return t < GCONV_TILE_NODES ? GCONV_TILE_NODES : t;
 }
 
@@ -66,7 +57,7 @@ int tile_slack(int T, int n) {
     const char* v = std::getenv("GCONV_TILE_SLACK_DIV");
     return v ? std::atoi(v) : 0;
   }();
-  const bool one_per_workgroup = ceil_div(n > 0 ? n : 1, T) <= tile_cus();
+  const bool one_per_workgroup = ceil_div(n > 0 ? n : 1, T) <= kNumCU;
   const int s = div > 0 ? T / div : (one_per_workgroup ? T / 4 : T);
   return s < 1 ? 1 : (s > 64 ? 64 : s);
 }

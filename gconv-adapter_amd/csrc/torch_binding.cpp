@@ -725,21 +725,6 @@ PlanWorker& worker() {
   return *w;
 }
 
-// A stream whose kernels only run on the first `n_cus` CUs of the device's CU mask (hipExtStreamCreateWithCUMask;
-// the mask's bits go round the XCDs, so 8 bits = one CU per XCD): graph.py puts the prefetch worker's builds
-// there (GCONV_PREFETCH_CUS) while the fused tile kernels leave as many CUs alone (GCONV_TILE_CUS), so that a
-// build next to the step never takes a CU a tile workgroup is waiting for. The stream is never destroyed.
-int64_t masked_stream(int64_t device, int64_t n_cus) {
-  TORCH_CHECK(n_cus >= 1 && n_cus <= 256, "masked_stream: 1 .. 256 CUs");
-  uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int i = 0; i < n_cus; ++i) mask[i / 32] |= 1u << (i % 32);
-  hipStream_t s = nullptr;
-  on_device(static_cast<int>(device), [&] {
-    TORCH_CHECK(hipExtStreamCreateWithCUMask(&s, 8, mask) == hipSuccess, "hipExtStreamCreateWithCUMask failed");
-  });
-  return reinterpret_cast<int64_t>(s);
-}
-
 int64_t plan_submit(at::Tensor edge_index, int64_t num_nodes, bool normalize, int64_t main_stream,
                     int64_t side_stream) {
   return worker().submit(std::move(edge_index), num_nodes, normalize, main_stream, side_stream);
@@ -1059,6 +1044,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         pybind11::arg("only_if") = c10::optional<at::Tensor>());
   m.def("plan_submit", &plan_submit);
   m.def("plan_take", &plan_take);
-  m.def("masked_stream", &masked_stream);
   m.def("layer_norm_scale", &layer_norm_scale);
 }

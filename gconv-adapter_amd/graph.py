@@ -262,7 +262,7 @@ class PlanCache:
                 self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="gconv-plan")
             side = self._side_streams.get(dev)
             if side is None:
-                side = self._side_streams[dev] = _prefetch_stream(dev, ext)
+                side = self._side_streams[dev] = torch.cuda.Stream(device=dev)
         if ext is not None:
             ei = edge_index if edge_index.is_contiguous() else edge_index.contiguous()
             with torch.cuda.device(dev):
@@ -293,16 +293,6 @@ class PlanCache:
                 fut.result()
         self._pending.clear()
         self._entries.clear()
-
-
-def _prefetch_stream(dev, ext):
-    """The side stream the next batch's plan is built on. ``GCONV_PREFETCH_CUS=k`` (with the C++ binding):
-    a stream confined to k CUs (``masked_stream``); together with ``GCONV_TILE_CUS=256-k`` the build then
-    never sits on a CU that one of the step's one-workgroup-per-CU tile kernels is waiting for."""
-    k = int(os.environ.get("GCONV_PREFETCH_CUS", "0") or 0)
-    if k > 0 and ext is not None and hasattr(ext, "masked_stream"):
-        return torch.cuda.ExternalStream(ext.masked_stream(dev.index, k), device=dev)
-    return torch.cuda.Stream(device=dev)
 
 
 #: process-wide cache shared by every GConvAdapter instance
