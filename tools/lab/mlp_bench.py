@@ -1,5 +1,6 @@
-"""The frozen GIN layer's MLP: bf16x3 MFMA kernel (csrc/mlp.hip) against nn.Linear (rocBLAS fp32),
-forward + input gradient, HIP events. python tools/lab/mlp_bench.py [n] [d]"""
+"""The frozen GIN layer's MLP: the f16x2 (csrc/mlp_f16.hip) and bf16x3 (csrc/mlp.hip) MFMA kernels against
+nn.Linear (rocBLAS fp32), forward + input gradient, HIP events; and the whole frozen layer (aggregation + MLP)
+as one node against the round-3 composition. python tools/lab/mlp_bench.py [n] [d]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -27,6 +28,25 @@ def run(fn):
         fn(a).backward(g)
     return ev(step)
 flop = 2 * 2 * 2.0 * n * d * 2 * d
+pair = run(lambda t: ga.gin.GinPairMlpFunction.apply(t, layer))
 mine = run(lambda t: ga.gin.GinMlpFunction.apply(t, layer))
 ref = run(lambda t: layer.mlp(t))
-print(f"n={n} d={d}: bf16x3 {mine:.1f} us ({flop / mine / 1e6:.1f} TFLOP/s fp32-equivalent), nn.Linear {ref:.1f} us ({flop / ref / 1e6:.1f} TFLOP/s)")
+print(f"n={n} d={d}: f16x2 {pair:.1f} us ({flop / pair / 1e6:.1f} TFLOP/s fp32-equivalent), bf16x3 {mine:.1f} us "
+      f"({flop / mine / 1e6:.1f}), nn.Linear {ref:.1f} us ({flop / ref / 1e6:.1f} TFLOP/s)")
+if d == 300:   # the whole frozen layer on a molecule batch of about n nodes
+    batch, cfg = ga.synth.make_workload("hiv", graphs=max(1, round(n / 25.6)))
+    ei = batch.edge_index.to(dev)
+    e = ei.shape[1]
+    gen = torch.Generator().manual_seed(0)
+    ea = torch.stack([torch.randint(0, 4, (e,), generator=gen), torch.randint(0, 3, (e,), generator=gen)], 1).to(dev)
+    x = batch.x.to(dev).requires_grad_(True)
+    gg = torch.randn_like(x)
+    def layer_step():
+        x.grad = None
+        layer(x, ei, ea).backward(gg)
+    one = ev(layer_step)
+    ga.gin.MLP_BF16X3 = True
+    old = ev(layer_step)
+    ga.gin.MLP_BF16X3 = False
+    print(f"frozen layer on {batch.num_nodes} nodes, fwd + bwd: one node (aggregate -> pair, f16x2) {one:.1f} us; "
+          f"round 3 (aggregate fp32, split, bf16x3) {old:.1f} us")
