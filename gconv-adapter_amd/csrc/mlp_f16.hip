@@ -13,15 +13,17 @@
 // are dominated by the fp32 accumulation (emulation over K = 300, N(0, 1) data: max error 1.3e-6 here,
 // 1.5e-6 for the bf16 triple, 3.7e-6 for a plain fp32 GEMM; parity gate: tests/test_gin.py at 1e-5 vs fp64
 // and <= 2x torch's fp32 error). What the scaling needs:
-//   weights   exponent from max |W| (scaled into [16, 32)); max row 1-norm and max |bias| are kept beside the
+//   weights   exponent from max |W| (scaled into [2^13, 2^14)); max row 1-norm and max |bias| are kept beside the
 //             pair: they bound the hidden activation without looking at it
 //   inputs    exponent from the row's max (row-split pass; or the producer: the GIN aggregation writes the pair)
-//   hidden    |h[r, :]| <= 2^-e(r) 32 L1max + bmax — every column tile of row r derives the SAME exponent from
+//   hidden    |h[r, :]| <= 2^-e(r) 2^14 L1max + bmax — every column tile of row r derives the SAME exponent from
 //             that bound; un-scaling happens in the epilogue in true units, so a GEMM's output row is exact in
 //             the exponent bookkeeping whatever the tiles were
 // Kernel shape as in round 3: 128 nodes x 80 features per workgroup of 4 waves, k-steps of 32, six (here: four)
 // images by LDS-DMA into two XOR-swizzled LDS buffers, one barrier per k-step, XCD-aware tile order — but
 // 26 KB per stage instead of 39: THREE workgroups per CU.
+#include <cstdlib>
+
 #include "mlp_split.h"
 
 namespace gconv {
@@ -154,8 +156,12 @@ __global__ __launch_bounds__(256) void mlp_split_rows_f16_kernel(const float* __
 //   EPI 0: none, 1: ReLU, 2: multiply by [mask_hi > 0] (mask_hi: the hi image of a ReLU output, [N][Mq])
 // Staging and fragment layout: see csrc/mlp.hip (the same LDS-DMA double buffer with XOR-swizzled 64-byte
 // rows; 2 images per operand instead of 3).
-template <int EPI, bool OUT_SPLIT>
-__global__ __launch_bounds__(kThreads, 3) void mlp_gemm_f16x2_kernel(const _Float16* __restrict__ A2,
+// S = LDS stages: S - 1 k-steps of operands are in flight while one is multiplied. A workgroup's k-steps are
+// sequential round trips to L2 (1 - 2 us each against 0.2 us of MFMAs); with the 400 - 800 workgroups of a
+// 512-molecule batch a CU holds one to three of them, so the depth of each workgroup's own pipeline, not the
+// number of co-resident workgroups, is what keeps requests in flight (S = 3: 78 KB, two workgroups per CU).
+template <int EPI, bool OUT_SPLIT, int S>
+__global__ __launch_bounds__(kThreads, S >= 3 ? 2 : 3) void mlp_gemm_f16x2_kernel(const _Float16* __restrict__ A2,
                                                                      const int32_t* __restrict__ a_exp,
                                                                      const _Float16* __restrict__ W2,
                                                                      const float* __restrict__ wtail,
@@ -177,16 +183,20 @@ __global__ __launch_bounds__(kThreads, 3) void mlp_gemm_f16x2_kernel(const _Floa
 
   const int crow = lane >> 2;
   const int cq = (lane & 3) ^ ((4 - (crow >> 2)) & 3);   // the 16-byte piece that belongs in this lane's LDS slot
+  // every wave issues exactly kChunksPerWave DMA instructions per stage (the last two slots of waves 2 / 3
+  // repeat their previous chunk: same bytes, same place), so that "all but the newest stage have landed"
+  // is one vmcnt value for all waves
   auto dma = [&](int buf, int k0) {
     char* base = smem + buf * kBufB;
 #pragma unroll
     for (int j = 0; j < kChunksPerWave; ++j) {
-      const int c = wave + 4 * j;
+      int c = wave + 4 * j;
+      if (c >= kAChunks + kBChunks) c -= 4;
       if (c < kAChunks) {                     // wave-uniform
         const int s = c / (kBM / 16), r16 = c % (kBM / 16);
         const int row = min(row0 + 16 * r16 + crow, N - 1);   // (rows past N: a valid row, never stored)
         lds_dma16(A2 + s * aimg + static_cast<size_t>(row) * Kp + k0 + 8 * cq, base + c * 1024);
-      } else if (c < kAChunks + kBChunks) {
+      } else {
         const int cb = c - kAChunks, s = cb / (kBN / 16), r16 = cb % (kBN / 16);
         lds_dma16(W2 + s * wimg + static_cast<size_t>(col0 + 16 * r16 + crow) * Kp + k0 + 8 * cq, base + c * 1024);
       }
@@ -204,17 +214,23 @@ __global__ __launch_bounds__(kThreads, 3) void mlp_gemm_f16x2_kernel(const _Floa
   const int f_off = frow * 64 + 16 * fslot;
   const int a_off = 2 * wave * 1024 + f_off;            // this wave's 32 nodes = chunks 2 wave, 2 wave + 1 of an image
 
-  dma(0, 0);
+  const int nk = Kp / kBK;
+#pragma unroll
+  for (int st = 0; st < S - 1; ++st)
+    if (st < nk) dma(st, st * kBK);                      // (wave-uniform)
   // epilogue operands that do not depend on the products: requested now, used after the k loop
   int ea[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) ea[i] = a_exp[min(row0 + 32 * wave + 16 * i + (lane & 15), N - 1)];
   const float winv = wtail[0], l1max = wtail[1], bmax = wtail[2];
-  int buf = 0;
-  for (int k0 = 0; k0 < Kp; k0 += kBK, buf ^= 1) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of step k0 have landed ...
-    lds_only_barrier();                                  // ... and so have everybody else's; step k0 - 1 is read out
-    if (k0 + kBK < Kp) dma(buf ^ 1, k0 + kBK);           // (wave-uniform) under the MFMAs below
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the first stages and these few words; then the count is the stages')
+  int buf = 0, nbuf = (S - 1) % S;
+  for (int k = 0; k < nk; ++k) {
+    // this wave's pieces of step k have landed (newer stages may still be in flight) ...
+    if (S >= 3 && k + 1 < nk && k > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kChunksPerWave * (S - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_only_barrier();                                  // ... and so have everybody else's; step k - 1 is read out
+    if (k + S - 1 < nk) dma(nbuf, (k + S - 1) * kBK);    // (wave-uniform) into the buffer step k - 1 has just left
     const char* la = smem + buf * kBufB;
     const char* lb = la + kAChunks * 1024;
     f16x8 af[2][2];
@@ -238,6 +254,8 @@ __global__ __launch_bounds__(kThreads, 3) void mlp_gemm_f16x2_kernel(const _Floa
         acc[i][j] = c;
       }
     }
+    buf = buf + 1 == S ? 0 : buf + 1;
+    nbuf = nbuf + 1 == S ? 0 : nbuf + 1;
   }
 
   // epilogue: lane l holds features f0 .. f0 + 3 (f0 = col0 + 16 j + 4 (l >> 4)) of node row0 + 32 wave + 16 i + (l & 15)
@@ -247,7 +265,7 @@ __global__ __launch_bounds__(kThreads, 3) void mlp_gemm_f16x2_kernel(const _Floa
   for (int i = 0; i < 2; ++i) {
     sc[i] = ldexpf(winv, -ea[i]);                        // products of scaled operands -> true units
     // the output row's exponent from a bound every column tile agrees on (file header)
-    eh[i] = scale_exp(ldexpf(32.f * l1max, -ea[i]) + (EPI == 1 ? bmax : 0.f));
+    eh[i] = scale_exp(ldexpf(kPairTop * l1max, -ea[i]) + (EPI == 1 ? bmax : 0.f));
   }
 #pragma unroll
   for (int j = 0; j < kNT; ++j) {
@@ -362,7 +380,9 @@ extern "C" gconv_status_t gconv_mlp_gemm_f16x2(const void* a_pair, const void* w
   const int Kp = mlp_pad_k(in_features), Mp = pad_m(out_features), Mq = mlp_pad_k(out_features);
   const int row_tiles = (num_rows + kBM - 1) / kBM;
   const dim3 grid(((row_tiles + 7) / 8) * (Mp / kBN) * 8);   // 1-D: the kernel maps it to tiles XCD-aware
-  const size_t lds = 2 * kBufB;
+  // pipeline depth (kernel comment): three stages unless GCONV_MLP_STAGES=2 asks for round 3's two
+  static const int stages = [] { const char* v = getenv("GCONV_MLP_STAGES"); return v && v[0] == '2' ? 2 : 3; }();
+  const size_t lds = static_cast<size_t>(stages) * kBufB;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const _Float16* a = static_cast<const _Float16*>(a_pair);
   const int32_t* aexp = reinterpret_cast<const int32_t*>(static_cast<const char*>(a_pair) +
@@ -374,16 +394,22 @@ extern "C" gconv_status_t gconv_mlp_gemm_f16x2(const void* a_pair, const void* w
   int32_t* cexp = c_pair ? reinterpret_cast<int32_t*>(static_cast<char*>(c_pair) +
                                                       mlp_pair_exp_offset(num_rows, out_features))
                          : nullptr;
-#define GCONV_MLP_LAUNCH(EPI_, SPLIT_)                                                                             \
+#define GCONV_MLP_LAUNCH_S(EPI_, SPLIT_, S_)                                                                       \
   do {                                                                                                             \
-    static bool opted_in = false; /* (two 26 KB buffers of dynamic LDS: above the 48 KB default; once per kernel) */ \
+    static bool opted_in = false; /* (dynamic LDS above the 48 KB default; once per kernel) */                      \
     if (!opted_in) {                                                                                               \
-      GCONV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_gemm_f16x2_kernel<EPI_, SPLIT_>),           \
+      GCONV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_gemm_f16x2_kernel<EPI_, SPLIT_, S_>),       \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));           \
       opted_in = true;                                                                                             \
     }                                                                                                              \
-    mlp_gemm_f16x2_kernel<EPI_, SPLIT_><<<grid, kThreads, lds, stream>>>(a, aexp, w, wtail, bias, mk, c_f32, c2,   \
-                                                                        cexp, num_rows, Kp, out_features, Mp, Mq); \
+    mlp_gemm_f16x2_kernel<EPI_, SPLIT_, S_><<<grid, kThreads, lds, stream>>>(a, aexp, w, wtail, bias, mk, c_f32,   \
+                                                                            c2, cexp, num_rows, Kp, out_features, \
+                                                                            Mp, Mq);                               \
+  } while (0)
+#define GCONV_MLP_LAUNCH(EPI_, SPLIT_)               \
+  do {                                               \
+    if (stages == 3) GCONV_MLP_LAUNCH_S(EPI_, SPLIT_, 3); \
+    else GCONV_MLP_LAUNCH_S(EPI_, SPLIT_, 2);        \
   } while (0)
   if (c_pair) {
     switch (epilogue) {
@@ -399,6 +425,7 @@ extern "C" gconv_status_t gconv_mlp_gemm_f16x2(const void* a_pair, const void* w
     }
   }
 #undef GCONV_MLP_LAUNCH
+#undef GCONV_MLP_LAUNCH_S
   GCONV_LAUNCH_CHECK();
   return GCONV_OK;
 }

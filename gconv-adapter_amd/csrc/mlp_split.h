@@ -3,12 +3,16 @@
 // GIN aggregation that writes the MLP's input directly (csrc/gin.hip).
 //
 // An fp32 value x is carried as  x * 2^e = hi + lo  with hi = fp16(x 2^e), lo = fp16(x 2^e - hi): 11 + 11
-// mantissa bits, a relative error of 2^-22 — provided the scaled values sit well inside fp16's range
-// (max 65504, normal above 6.1e-5). `e` is ONE exponent per matrix row (activations, gradients: a node's
-// row; weights: one for the whole matrix), chosen so that the row's largest magnitude (or a bound of it)
-// lands in [16, 32): entries down to 2^-9 of the row's scale still have a normal lo, smaller ones lose
-// only bits that are below fp32's own resolution of the row's sums. Powers of two: scaling and un-scaling
-// are exact.
+// mantissa bits, a relative error of 2^-22 — provided the scaled values sit inside fp16's range (max
+// 65504 = 2^16, normal above 2^-14). `e` is ONE exponent per matrix row (activations, gradients: a node's
+// row; weights: one for the whole matrix), chosen so that the row's largest magnitude — or, for the hidden
+// activation, an upper BOUND of it — lands in [2^13, 2^14): as high as fp16 allows with a factor 4 to spare.
+// An entry's lo is a normal fp16 number while the entry is above 2^-17 of the row's scale (2^-3 scaled);
+// smaller entries keep an absolute error of 2^-25 scaled = 2^-38 of the row's scale, far below fp32's own
+// resolution of the row's sums. The headroom matters for the hidden activation, whose bound (row maximum x
+// largest weight-row 1-norm + largest bias) overestimates the typical entry by one to three orders of
+// magnitude. Powers of two: scaling and un-scaling are exact; a row of zeros takes the largest exponent
+// (its contribution to any bound vanishes).
 #pragma once
 
 #include "common.h"
@@ -21,12 +25,16 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 constexpr int kMlpBK = 32;                       // contraction step of the GEMM = padding unit of a row
 __host__ __device__ inline int mlp_pad_k(int k) { return (k + kMlpBK - 1) / kMlpBK * kMlpBK; }
 
-// exponent e with bound * 2^e in [16, 32) (0 for bound == 0); clamped so that 2^e and 2^-e are finite
+constexpr int kPairTopExp = 14;                  // scaled row maximum (or bound) in [2^13, 2^14)
+constexpr float kPairTop = 16384.f;              // 2^kPairTopExp: what a row's scaled entries stay below
+
+// exponent e with bound * 2^e in [2^13, 2^14) (the largest, 100, for bound == 0); clamped so that 2^e and
+// 2^-e are finite
 __device__ __forceinline__ int scale_exp(float bound) {
-  if (!(bound > 0.f)) return 0;
+  if (!(bound > 0.f)) return 100;
   int e;
   (void)frexpf(bound, &e);                       // bound = f 2^e, f in [0.5, 1)
-  e = 5 - e;
+  e = kPairTopExp - e;
   return e < -100 ? -100 : (e > 100 ? 100 : e);
 }
 

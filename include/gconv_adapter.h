@@ -576,7 +576,7 @@ gconv_status_t gconv_mlp_gemm_bf16x3(const void* a_split, const void* w_split, c
  * replaces the same reference lines as the bf16 triple above (`gin_conv.py:24-28,85`); half the matrix
  * work, two thirds of the operand bytes, the same fp32 accuracy (`csrc/mlp_f16.hip`). An fp32 matrix
  * travels as a "scaled pair": x 2^e = hi + lo in fp16 (11 + 11 mantissa bits), with ONE exponent e per row
- * of an activation / gradient matrix (the row's largest magnitude, or a bound of it, lands in [16, 32))
+ * of an activation / gradient matrix (the row's largest magnitude, or a bound of it, lands in [2^13, 2^14))
  * and one per weight matrix; |x| < 2^100.
  *   row pair    [2][N][Fp] fp16 images (Fp = F rounded up to 32, padding zero) followed, 16-byte aligned,
  *               by int32 e[N]: gconv_mlp_rows_pair_bytes(N, F) bytes
