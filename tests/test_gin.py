@@ -134,12 +134,15 @@ def test_gin_layer_hiv_shard(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("frozen", [False, True])
 @pytest.mark.parametrize("n,e,d", [(1, 0, 4), (9, 0, 8), (200, 1500, 64), (50, 4000, 128), (300, 900, 1024)])
-def test_gin_layer_directed_graphs_with_duplicates_and_loops(dev, n, e, d):
+def test_gin_layer_directed_graphs_with_duplicates_and_loops(dev, n, e, d, frozen):
+    """frozen = True: the whole layer as ONE node (aggregation -> fp16 operand pair -> two GEMMs), at the
+    widths where a row is narrower than one k-step of the GEMM (d = 4, 8) and at the widest supported."""
     g = torch.Generator().manual_seed(n + e)
     ei = torch.stack([torch.randint(n, (e,), generator=g), torch.randint(n, (e,), generator=g)])
     x = torch.randn(n, d, generator=g)
-    _check(dev, x, ei, _bond_attr(e, 7), d, 2, frozen=False)
+    _check(dev, x, ei, _bond_attr(e, 7), d, 2, frozen=frozen)
 
 
 def _mlp_fn(scheme):
