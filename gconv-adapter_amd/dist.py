@@ -155,9 +155,9 @@ class FlatGradBucket:
         divide by the GLOBAL count (see ``global_count``) and use ``average=False``.
         ``average=True`` with ``async_op=True`` divides in ``wait()``."""
         self.wait()           # (a collective still in flight from the previous step)
-        self.gather_stragglers()
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-            return None
+            return None       # nothing to exchange: gradients stay where autograd / the sinks put them
+        self.gather_stragglers()
         work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
         if async_op:
             self._work = work
