@@ -293,7 +293,13 @@ def _pair_gemm(a2: torch.Tensor, n: int, k: int, w2: torch.Tensor, bias, mask2, 
     return out
 
 
+def _on_device(t: torch.Tensor) -> None:
+    if t.device.index != torch.cuda.current_device():   # launches go to the current device's stream
+        torch.cuda.set_device(t.device)
+
+
 def _pair_mlp_forward(a2, n, mod):
+    _on_device(a2)
     l1, l2 = mod.mlp[0], mod.mlp[2]
     pw = mod._mlp_pair
     h2 = _pair_gemm(a2, n, l1.in_features, pw[0].get(l1.weight, l1.bias, False), l1.bias, None, l1.out_features, 1, True)
@@ -302,6 +308,7 @@ def _pair_mlp_forward(a2, n, mod):
 
 
 def _pair_mlp_backward(gy, h2, mod):
+    _on_device(gy)
     l1, l2 = mod.mlp[0], mod.mlp[2]
     pw = mod._mlp_pair
     n = gy.shape[0]
@@ -319,6 +326,7 @@ class GinPairMlpFunction(torch.autograd.Function):
     def forward(ctx, agg, mod):
         _require_hip_f32(agg, "agg")
         agg = agg.contiguous()
+        _on_device(agg)
         h2, y = _pair_mlp_forward(_rows_pair(agg), agg.shape[0], mod)
         ctx.mod = mod
         ctx.save_for_backward(h2)
