@@ -12,7 +12,6 @@ struct TileFwdArgs {
   const float* w_down; const float* b_down; const float* w_up; const float* b_up;
   const float* scalar;
   int d, r, fp, act, skip, cap, n_tiles, n;   // n = nodes of the graph (rows of x)
-  int xoff;            // byte offset of the tile's X copy in LDS (kernels built with XL; 0: none)
   long long* stamps;   // diagnostic build only (-DGCONV_TILE_STAMPS, tools/tilestamps.py)
 };
 
@@ -27,7 +26,6 @@ struct TileBwdArgs {
   float* part_wd; float* part_wu; float* part_cs; float* part_bd;
   float* part_ds;   // complete scalar-gradient partial: (G Wu).P + [skip] G.X + b_up.colsum(G)
   int d, r, fp, act, skip, cap, want_ds, n_tiles, n;
-  int xoff;            // byte offset of the tile's G copy in LDS (kernels built with XL; 0: none)
   long long* stamps;   // diagnostic build only
 };
 

@@ -179,18 +179,13 @@ __device__ __forceinline__ int tile_node(const TileView& tv, int lr) {
 // compiler can count vmcnt exactly and never waits for more than it needs). `mid` runs once,
 // right after the first block's requests are in flight: the caller's small dependent loads
 // (CSR slice, dis) ride under the X / G tile latency instead of in front of it.
-// XL (round 4): the tile's OWN rows of M are also parked in LDS (`xs`: [nt][d] floats + a 1 KB dump for
-// the lanes that have nothing to park), straight out of the register ring, so that phase 4 reads them
-// from there instead of from L2 — on a whole 4096-molecule batch the 32 tiles an XCD's CUs stream at a
-// time (32 x 121 KB) do not survive in its 4 MB L2 until phase 4, and the second read went to memory
-// again: 54 MB of 178 fetched per forward, ~100 of 349 per backward (tools/lab/tile_traffic.sh).
-template <int FP, int NQ, bool HAS_DIS, bool WANT_P, bool XL, class Mid>
+template <int FP, int NQ, bool HAS_DIS, bool WANT_P, class Mid>
 __device__ __forceinline__ float tile_rowsA(rsrc_t rm, const float* __restrict__ anyrow,
                                             const f32x4* wl, float* dst,
                                             const float* __restrict__ dis,
                                             const float* __restrict__ Pmat, float sval,
                                             const TileView& tv, int d, int rowb, int nwaves, int wave,
-                                            int lane, char* xs, Mid&& mid) {
+                                            int lane, Mid&& mid) {
   constexpr int NCB = FP >= 16 ? FP / 16 : 1;
   const int node = lane & 15, kq = lane >> 4;
   const int ts = tv.ts, nt = tv.nt, n0 = tv.n0;
@@ -251,9 +246,6 @@ __device__ __forceinline__ float tile_rowsA(rsrc_t rm, const float* __restrict__
     int rn = 0;
     if constexpr (REFILL) rn = rowoff(blk + nwaves);
     const int kqv = launder(kq);
-    // LDS copy of the own rows: this lane's row, or its slot of the dump (halo / padding rows)
-    int xrow = 0;
-    if constexpr (XL) xrow = 16 * blk + node < nt ? (16 * blk + node) * rowb + 16 * kqv : nt * rowb + 16 * lane;
     f32x4 acc[NCB][2];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) acc[cb][0] = acc[cb][1] = zero4f();
@@ -268,9 +260,6 @@ __device__ __forceinline__ float tile_rowsA(rsrc_t rm, const float* __restrict__
       // second set of ring registers (and copies the whole ring at the loop head)
       f32x4 xv = x[q % R];
       asm volatile("" : "+v"(xv));
-      if constexpr (XL)   // (a k-step past the row end goes to the dump as well)
-        *reinterpret_cast<f32x4*>(xs + ((16 * blk + node < nt && 16 * q + 4 * kqv < d) ? xrow + 64 * q
-                                                                                       : nt * rowb + 16 * lane)) = xv;
       if (q + 1 < NQ) {
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) wn[cb] = wl[((q + 1) * NCB + cb) * 64 + lane];
@@ -389,7 +378,7 @@ struct TileCsrStage {
 // ===========================================================================
 // forward — persistent workgroups walk the tiles (weights staged / loaded once)
 // ===========================================================================
-template <int FP, int NQ, bool NORM, bool XL>
+template <int FP, int NQ, bool NORM>
 #if GCONV_TILE_WGPC >= 2
 __global__ __launch_bounds__(320, 3) void tile_fwd_kernel(TileFwdArgs a) {
 #else
@@ -497,9 +486,8 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
     // ---- phase 1: H0' -> bufA, n0 rows (the tile's local CSR and dis land in LDS meanwhile)
     TileCsrStage<NORM> csr{a.rowptr, a.lcol, a.dis, rp, cl, dl, tv};
     csr.request();
-    char* xs = reinterpret_cast<char*>(lds4) + a.xoff;   // (XL) the tile's own rows of X, for phase 4
-    tile_rowsA<FP, NQ, NORM, false, XL>(rxa, a.x, wl, bufA, a.dis, nullptr, 1.f, tv, a.d, rowb, nwaves, wave,
-                                        lane, xs, [&]() { csr.advance(); });
+    tile_rowsA<FP, NQ, NORM, false>(rxa, a.x, wl, bufA, a.dis, nullptr, 1.f, tv, a.d, rowb, nwaves, wave,
+                                    lane, [&]() { csr.advance(); });
     csr.finish();
     lds_barrier();
     TILE_STAMP(2);
@@ -509,14 +497,8 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
     // block past the tile lies outside the buffer and costs no traffic.
     const int nb4 = ceil_div(nt, 16);
     auto load_x = [&](int blk, f32x4 (&xq)[4]) {
-      if constexpr (XL) {   // out of LDS (rows / columns past the tile: any parked value, never stored)
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-          xq[m] = *reinterpret_cast<const f32x4*>(xs + min(16 * blk + 4 * t + m, nt - 1) * rowb + 4 * colc);
-      } else {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) xq[m] = buf_ld4_last(rx, voff4 + (16 * blk + m) * rowb);
-      }
+      for (int m = 0; m < 4; ++m) xq[m] = buf_ld4_last(rx, voff4 + (16 * blk + m) * rowb);
     };
     f32x4 xa[4], xb[4];
     load_x(slot, xa);
@@ -590,7 +572,7 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
 // scalar-gradient pieces stay in registers across all tiles of a workgroup, so ONE
 // partial row per workgroup reaches HBM and B5 is a single launch.
 // ===========================================================================
-template <int FP, int NQ, bool NORM, bool NEED_DX, bool XL>
+template <int FP, int NQ, bool NORM, bool NEED_DX>
 #if GCONV_TILE_WGPC >= 2
 __global__ __launch_bounds__(320, 3) void tile_bwd_kernel(TileBwdArgs a) {
 #else
@@ -719,9 +701,8 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
     const int np4 = nt * LPR;  // the P tile: np4 float4, the first blockDim of them via registers
     const f32x4 pfirst =
         ldg4(a.saved_p + static_cast<size_t>(ts) * FP + 4 * min(static_cast<int>(threadIdx.x), np4 - 1));
-    char* xs = reinterpret_cast<char*>(lds4) + a.xoff;   // (XL) the tile's own rows of G, for phase 4
-    ds1 += tile_rowsA<FP, NQ, NORM, true, XL>(rga, a.g, wl, bufA, a.dis, a.want_ds ? a.saved_p : nullptr, sval, tv,
-                                          a.d, rowb, nwaves, wave, lane, xs, [&]() {
+    ds1 += tile_rowsA<FP, NQ, NORM, true>(rga, a.g, wl, bufA, a.dis, a.want_ds ? a.saved_p : nullptr, sval, tv,
+                                          a.d, rowb, nwaves, wave, lane, [&]() {
                                             csr.advance();
                                             const int gfirst = lr_first < nt ? ts + lr_first : hid_first;
                                             hfirst = ldg4(hsel + static_cast<size_t>(gfirst) * FP + 4 * sub);
@@ -748,12 +729,7 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
 #pragma unroll
       for (int n = 0; n < 16; ++n) {
         const int off = voff1 + (16 * blk + n) * rowb;
-        if constexpr (XL) {   // G out of LDS; rows / columns past the tile must read as zeros (they are summed)
-          const float gl = *reinterpret_cast<const float*>(xs + min(16 * blk + n, nt - 1) * rowb + 4 * colc);
-          gq[n] = (16 * blk + n < nt && colvalid) ? gl : 0.f;
-        } else {
-          gq[n] = buf_ld1(rg, off);
-        }
+        gq[n] = buf_ld1(rg, off);
         xq[n] = buf_ld1(rx, off);
       }
     };
@@ -975,17 +951,6 @@ static int tile_threads_bwd(int d) {
 }
 
 constexpr size_t kTileMaxLds = (GCONV_TILE_WGPC >= 2 ? 72 : 144) * 1024;
-constexpr size_t kLdsPerWorkgroup = 160 * 1024;   // gfx950: what ONE workgroup may allocate
-
-// LDS copy of a tile's own X / G rows for phase 4 (kernels built with XL): [tile_nodes_max][d] floats + a
-// 1 KB dump for lanes with nothing to park. 0 when it does not fit beside the tile state (the second read
-// then comes from L2 / memory as before) or GCONV_NO_TILE_XLDS asks for the A/B.
-static size_t tile_xlds_bytes(int d, int tile_nodes_max, size_t state_bytes) {
-  static const bool off = getenv("GCONV_NO_TILE_XLDS") != nullptr;
-  if (off || GCONV_TILE_WGPC >= 2) return 0;
-  const size_t need = static_cast<size_t>(tile_nodes_max > 0 ? tile_nodes_max : 1) * d * sizeof(float) + 1024;
-  return align_up(state_bytes, 16) + need <= kLdsPerWorkgroup ? need : 0;
-}
 
 size_t tile_lds_bytes(int d, int fp, int tile_nodes_max, int tile_edges_max) {
   const int nq = tile_nq(d), ncb = fp >= 16 ? fp / 16 : 1;
@@ -1025,22 +990,15 @@ bool tile_path_ok(const gconv_graph_t* g, int d, int fp) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds))); \
   } while (0)
 
-#define GCONV_TILE_LAUNCH(KERNEL)                               \
-  do {                                                          \
-    GCONV_TILE_LDS_OPT_IN((KERNEL));                            \
-    KERNEL<<<grid, threads, lds, stream>>>(a);                  \
-  } while (0)
-
 template <int FP, int NQ>
 static gconv_status_t launch_tile_fwd_t(const TileFwdArgs& a, int grid, int threads, size_t lds,
                                         hipStream_t stream) {
-  const bool xl = a.xoff != 0;   // the tile's own X rows are parked in LDS for phase 4
   if (a.dis) {
-    if (xl) GCONV_TILE_LAUNCH((tile_fwd_kernel<FP, NQ, true, true>));
-    else GCONV_TILE_LAUNCH((tile_fwd_kernel<FP, NQ, true, false>));
+    GCONV_TILE_LDS_OPT_IN((tile_fwd_kernel<FP, NQ, true>));
+    tile_fwd_kernel<FP, NQ, true><<<grid, threads, lds, stream>>>(a);
   } else {
-    if (xl) GCONV_TILE_LAUNCH((tile_fwd_kernel<FP, NQ, false, true>));
-    else GCONV_TILE_LAUNCH((tile_fwd_kernel<FP, NQ, false, false>));
+    GCONV_TILE_LDS_OPT_IN((tile_fwd_kernel<FP, NQ, false>));
+    tile_fwd_kernel<FP, NQ, false><<<grid, threads, lds, stream>>>(a);
   }
   GCONV_LAUNCH_CHECK();
   return GCONV_OK;
@@ -1049,20 +1007,23 @@ static gconv_status_t launch_tile_fwd_t(const TileFwdArgs& a, int grid, int thre
 template <int FP, int NQ>
 static gconv_status_t launch_tile_bwd_t(const TileBwdArgs& a, int grid, int threads, size_t lds,
                                         hipStream_t stream) {
-  const bool xl = a.xoff != 0;   // the tile's own G rows are parked in LDS for phase 4
-#define GCONV_TILE_BWD(NORM_, DX_)                                                  \
-  do {                                                                              \
-    if (xl) GCONV_TILE_LAUNCH((tile_bwd_kernel<FP, NQ, NORM_, DX_, true>));          \
-    else GCONV_TILE_LAUNCH((tile_bwd_kernel<FP, NQ, NORM_, DX_, false>));            \
-  } while (0)
   if (a.dis) {
-    if (a.dx) GCONV_TILE_BWD(true, true);
-    else GCONV_TILE_BWD(true, false);
+    if (a.dx) {
+      GCONV_TILE_LDS_OPT_IN((tile_bwd_kernel<FP, NQ, true, true>));
+      tile_bwd_kernel<FP, NQ, true, true><<<grid, threads, lds, stream>>>(a);
+    } else {
+      GCONV_TILE_LDS_OPT_IN((tile_bwd_kernel<FP, NQ, true, false>));
+      tile_bwd_kernel<FP, NQ, true, false><<<grid, threads, lds, stream>>>(a);
+    }
   } else {
-    if (a.dx) GCONV_TILE_BWD(false, true);
-    else GCONV_TILE_BWD(false, false);
+    if (a.dx) {
+      GCONV_TILE_LDS_OPT_IN((tile_bwd_kernel<FP, NQ, false, true>));
+      tile_bwd_kernel<FP, NQ, false, true><<<grid, threads, lds, stream>>>(a);
+    } else {
+      GCONV_TILE_LDS_OPT_IN((tile_bwd_kernel<FP, NQ, false, false>));
+      tile_bwd_kernel<FP, NQ, false, false><<<grid, threads, lds, stream>>>(a);
+    }
   }
-#undef GCONV_TILE_BWD
   GCONV_LAUNCH_CHECK();
   return GCONV_OK;
 }
@@ -1119,10 +1080,7 @@ gconv_status_t launch_tile_fwd(TileFwdArgs a, int n_tiles, int tile_nodes_max,
   a.n_tiles = n_tiles;
   n_tiles = tile_grid(n_tiles);
   a.cap = ceil_div(tile_nodes_max > 0 ? tile_nodes_max : 1, 16) * 16;
-  size_t lds = tile_lds_bytes(a.d, a.fp, tile_nodes_max, tile_edges_max);
-  const size_t xb = a.skip ? tile_xlds_bytes(a.d, tile_nodes_max, lds) : 0;   // (no residual: X is not read again)
-  a.xoff = xb ? static_cast<int>(align_up(lds, 16)) : 0;
-  if (xb) lds = a.xoff + xb;
+  const size_t lds = tile_lds_bytes(a.d, a.fp, tile_nodes_max, tile_edges_max);
   const int threads = tile_threads_fwd(a.d, a.fp);
   GCONV_TILE_DISPATCH(launch_tile_fwd_fp, (a, nq, n_tiles, threads, lds, stream))
 }
@@ -1133,10 +1091,7 @@ gconv_status_t launch_tile_bwd(TileBwdArgs a, int n_tiles, int tile_nodes_max,
   a.n_tiles = n_tiles;
   n_tiles = tile_grid(n_tiles);
   a.cap = ceil_div(tile_nodes_max > 0 ? tile_nodes_max : 1, 16) * 16;
-  size_t lds = tile_lds_bytes(a.d, a.fp, tile_nodes_max, tile_edges_max);
-  const size_t xb = tile_xlds_bytes(a.d, tile_nodes_max, lds);
-  a.xoff = xb ? static_cast<int>(align_up(lds, 16)) : 0;
-  if (xb) lds = a.xoff + xb;
+  const size_t lds = tile_lds_bytes(a.d, a.fp, tile_nodes_max, tile_edges_max);
   const int threads = tile_threads_bwd(a.d);
   GCONV_TILE_DISPATCH(launch_tile_bwd_fp, (a, nq, n_tiles, threads, lds, stream))
 }
