@@ -94,9 +94,59 @@ class FusedAdam(torch.optim.Optimizer):
             if src:
                 torch._foreach_copy_(dst, src)
 
+    # ------------------------------------------------------------------ data parallelism
+    def all_reduce_grads(self, average: bool = False, async_op: bool = False, group=None):
+        """The step's gradient exchange when the parameters live in this optimizer (the flat
+        buffer Adam reads IS the all-reduce bucket): gradients that are not in the flat buffers yet are
+        packed (``gather_grads``: one multi-tensor copy per group; the adapters' arrive in place through the
+        gradient sinks), then ONE collective per parameter group on its flat gradient buffer. A parameter
+        WITHOUT a gradient on this rank (an unused branch) contributes zeros and gets the other ranks' sum
+        — every rank must make the same call. ``async_op``: returns at once; ``wait()`` (``step()`` calls
+        it) orders the current stream behind the collectives and applies ``average``. No-op without an
+        initialised process group or with one rank."""
+        import torch.distributed as dist
+        self.wait()
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return None
+        self.gather_grads()
+        works = []
+        with torch.no_grad():
+            for fl in self._flat:
+                if not fl.get("params"):
+                    continue
+                for p, gv in zip(fl["params"], fl["grad_views"]):
+                    if p.grad is None:            # (the flat buffer may still hold an older step's values there)
+                        gv.zero_()
+                        p.grad = gv
+                works.append(dist.all_reduce(fl["grad"], op=dist.ReduceOp.SUM, group=group, async_op=async_op))
+        world = dist.get_world_size(group)
+        if async_op:
+            self._pending = (works, world if average else 0)
+            return works
+        if average:
+            for fl in self._flat:
+                if fl.get("params"):
+                    fl["grad"].div_(world)
+        return works
+
+    def wait(self) -> None:
+        """Orders the current stream behind an ``all_reduce_grads(async_op=True)`` (and divides for
+        ``average=True``)."""
+        pending = self.__dict__.pop("_pending", None)
+        if pending is None:
+            return
+        works, div = pending
+        for w in works:
+            w.wait()
+        if div:
+            for fl in self._flat:
+                if fl.get("params"):
+                    fl["grad"].div_(div)
+
     # ------------------------------------------------------------------ step
     @torch.no_grad()
     def step(self, closure=None):
+        self.wait()
         loss = None
         if closure is not None:
             with torch.enable_grad():

@@ -224,6 +224,57 @@ def test_two_ranks_with_sync_batch_norm_equal_the_whole_batch_step(dev, tmp_path
         assert_close(got["grads"][k].double(), want, f"grad {k}", 1e-5, grad_atol(want))
 
 
+# ---------------------------------------------------------------------------
+# the whole loop body over several steps: sync BatchNorm + FusedAdam whose flat gradient buffer is the
+# all-reduce bucket — the parameters after k steps equal the single-process run's
+# ---------------------------------------------------------------------------
+STEPS = 3
+
+
+def _train(model, b, ea, y, dev, count_fn, reduce):
+    opt = ga.FusedAdam([p for p in model.parameters() if p.requires_grad], lr=1e-2)
+    for _ in range(STEPS):
+        opt.zero_grad(set_to_none=True)
+        _step(model, b, ea, y, dev, count_fn())
+        if reduce:
+            opt.all_reduce_grads(async_op=True)      # step() waits for it
+        opt.step()
+    return {k: p.detach().cpu() for k, p in model.named_parameters() if p.requires_grad}
+
+
+def _train_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    b, ea, y, model = _problem()
+    model = ga.sync_batch_norm(model.to(dev)).train()
+    shard = ga.synth.shard_graphs(b, rank, world)
+    lo, hi = (b.num_graphs * rank) // world, (b.num_graphs * (rank + 1)) // world
+    n0, n1 = int(b.graph_ptr[lo]), int(b.graph_ptr[hi])
+    keep = (b.edge_index[1] >= n0) & (b.edge_index[1] < n1)
+    ys = y[lo:hi]
+    got = _train(model, shard, ea[keep], ys, dev,
+                 lambda: ga.dist.global_count((~torch.isnan(ys)).sum().to(dev)), reduce=True)
+    if rank == 0:
+        torch.save(got, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_train_like_one_process(dev, tmp_path):
+    out_path = str(tmp_path / "r0.pt")
+    mp.start_processes(_train_worker, args=(2, _free_port(), out_path), nprocs=2, join=True, start_method="spawn")
+    got = torch.load(out_path)
+    b, ea, y, model = _problem()
+    want = _train(model.to(dev).train(), b, ea, y, dev, lambda: (~torch.isnan(y)).sum().to(dev), reduce=False)
+    for k, w in want.items():
+        # Adam divides by sqrt(v): a gradient entry near zero amplifies its 1e-5-level differences in the first
+        # steps, so the parameters are compared at lr-scale absolute tolerance (lr = 1e-2, 3 steps)
+        assert_close(got[k].double(), w.double(), f"param {k} after {STEPS} steps", 1e-4, 1e-4 * 1e-2 * STEPS + 1e-6 * float(w.abs().max()))
+
+
 def test_without_a_process_group_the_layer_is_local(dev):
     m = ga.BatchNorm1d(32).to(dev)
     assert m.process_group is None
