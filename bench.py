@@ -489,10 +489,20 @@ def measure_tile_kernels(device, name: str = "hiv4096") -> dict:
     bwd_ms = event_time_ms(bwd, 30)
     fb, bb = adapter_algorithmic_bytes(n, plan.fwd.nnz, d, r)
     ga.PLAN_CACHE.clear()
-    return {f"{name}_adapter_fwd_us": round(fwd_ms * 1e3, 1), f"{name}_adapter_bwd_us": round(bwd_ms * 1e3, 1),
-            f"{name}_adapter_fwd_GBs": round(fb / (fwd_ms * 1e-3) / 1e9, 1),
-            f"{name}_adapter_bwd_GBs": round(bb / (bwd_ms * 1e-3) / 1e9, 1),
-            f"{name}_adapter_frac_of_hbm_peak": round((fb + bb) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)}
+    res = {f"{name}_adapter_fwd_us": round(fwd_ms * 1e3, 1), f"{name}_adapter_bwd_us": round(bwd_ms * 1e3, 1),
+           f"{name}_adapter_fwd_GBs": round(fb / (fwd_ms * 1e-3) / 1e9, 1),
+           f"{name}_adapter_bwd_GBs": round(bb / (bwd_ms * 1e-3) / 1e9, 1),
+           f"{name}_adapter_frac_of_hbm_peak": round((fb + bb) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)}
+    pmc = os.path.join(ROOT, "profiles", f"r04_tile_traffic_{name}.json")
+    if os.path.exists(pmc):   # what the two kernels REALLY move per launch (committed rocprofv3 --pmc passes), at the live times
+        with open(pmc) as fh:
+            tt = json.load(fh)
+        tf, tb = tt["tile_fwd"]["traffic_bytes_per_launch"], tt["tile_bwd"]["traffic_bytes_per_launch"]
+        res[f"{name}_adapter_traffic_MB"] = [round(tf / 1e6, 1), round(tb / 1e6, 1)]
+        res[f"{name}_adapter_traffic_frac_of_measured_copy_peak"] = round(
+            (tf + tb) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9 / HBM_MEASURED_GBS, 3)
+        res[f"{name}_adapter_traffic_source"] = f"profiles/{os.path.basename(pmc)} (commit {tt.get('commit', 'n/a')})"
+    return res
 
 
 def measure_gin(device, name: str = "hiv4096") -> dict:
