@@ -1310,7 +1310,7 @@ extern "C" gconv_status_t gconv_graph_build_ex(const int64_t* edge_index, int64_
   const bool k32 = 2 * b <= 32;
   // more than 65535 nodes: 32-bit LOCAL keys (KeyOps) when the list looks like a collated batch of small
   // graphs (few edges per node; at least +-256 of offset room) — the kernels find out whether it is
-  const bool no_local = std::getenv("GCONV_NO_LOCAL_KEYS") != nullptr;   // A/B knob (per call: the tests compare both)
+  static const bool no_local = std::getenv("GCONV_NO_LOCAL_KEYS") != nullptr;   // A/B knob
   int local_shift = (!k32 && !no_local && b <= 23 && E <= 4 * static_cast<int64_t>(n)) ? 32 - b : 0;
   gconv_status_t st = GCONV_OK;
   for (;;) {

@@ -1412,44 +1412,3 @@ def test_cooperative_launch_of_the_counting_build(dev, monkeypatch):
     monkeypatch.setenv("GCONV_COUNT_COOPERATIVE", "1")
     for _ in range(3):
         _same(want, _plan_arrays(ga.GraphPlan(ei, b.num_nodes, True)))
-
-
-
-@pytest.mark.parametrize("kind", ["hiv4096", "hiv4096_directed", "far_edge", "dense_local", "bad"])
-def test_local_sort_keys_of_large_collated_batches(dev, kind, monkeypatch):
-    """More than 65535 nodes used to mean 64-bit sort keys. A collated batch of small graphs (few edges per node,
-    every |col - row| small) now sorts 32-bit LOCAL keys (row, col - row); one far edge — a graph that only looks
-    like a batch — makes the kernels say so and the build repeats with 64-bit keys. Same plan either way
-    (`GCONV_NO_LOCAL_KEYS=1` = the 64-bit build), radix pipeline in both (`GCONV_NO_COUNTING_BUILD=1`)."""
-    monkeypatch.setenv("GCONV_NO_COUNTING_BUILD", "1")
-    b, _ = ga.synth.make_workload("hiv4096")
-    ei, n = b.edge_index.clone(), b.num_nodes
-    assert n > 65535
-    if kind == "hiv4096_directed":
-        ei = ei[:, torch.randperm(ei.shape[1], generator=torch.Generator().manual_seed(1))[: ei.shape[1] * 2 // 3]]
-    elif kind == "far_edge":
-        ei = torch.cat([ei, torch.tensor([[5, n - 7], [n - 7, 5]])], dim=1)            # spans the whole batch
-    elif kind == "dense_local":   # offsets right at the edge of the field (32 - 17 = 15 bits: +-16384)
-        extra = torch.tensor([[100, 100 + 16383, 40000, 40000 - 16384], [100 + 16383, 100, 40000 - 16384, 40000]])
-        ei = torch.cat([ei, extra], dim=1)
-    elif kind == "bad":
-        ei[0, 11] = n + 5
-    eid = ei.to(dev)
-    if kind == "bad":
-        with pytest.raises(RuntimeError, match="outside"):
-            ga.GraphPlan(eid, n, True)
-        return
-    got = _plan_arrays(ga.GraphPlan(eid, n, True))
-    bg = _plan_arrays(ga.GraphPlan(eid, n, True, background=True))       # (what the prefetch worker runs)
-    monkeypatch.setenv("GCONV_NO_LOCAL_KEYS", "1")
-    want = _plan_arrays(ga.GraphPlan(eid, n, True))
-    _same(want, got)
-    _same(want, bg)
-    rp, col = _numpy_csr(ei.numpy(), n, True, False)
-    np.testing.assert_array_equal(got["fwd"]["rowptr"].numpy(), rp)
-    np.testing.assert_array_equal(got["fwd"]["col"].numpy()[:rp[-1]], col)
-    if kind == "hiv4096_directed":
-        assert not got["symmetric"]
-        rpt, colt = _numpy_csr(ei.numpy(), n, True, True)
-        np.testing.assert_array_equal(got["bwd"]["rowptr"].numpy(), rpt)
-        np.testing.assert_array_equal(got["bwd"]["col"].numpy()[:rpt[-1]], colt)
