@@ -49,8 +49,7 @@ constexpr int kSmallMaxEdges = 4096, kSmallMaxNodes = 4096;   // the single-work
 enum {
   INFO_NNZ = 0, INFO_NLONG = 1, INFO_NSEG = 2, INFO_MAXDEG = 3, INFO_BAD = 4,
   INFO_ASYM = 5, INFO_NOTILE = 6, INFO_TILEMAX = 7, INFO_TILEEDGES = 8, INFO_WORDS = 9,
-  INFO_DONE = 10,  // completion mark of the one-launch builders (pinned host copy only)
-  INFO_NOTLOCAL = 11   // radix pipeline, local keys: an edge's |col - row| did not fit the offset field
+  INFO_DONE = 10   // completion mark of the one-launch builders (pinned host copy only)
 };
 
 int tile_slack(int T, int n) {
@@ -63,28 +62,15 @@ int tile_slack(int T, int n) {
   return s < 1 ? 1 : (s > 64 ? 64 : s);
 }
 
-// Sort key of an edge = (row, col), row in the high bits. Plain form: col in the low `shift` bits (32-bit keys
-// up to 65535 nodes, 64-bit beyond). LOCAL form (bias != 0, round 4): the low bits hold col - row + bias — for
-// edge lists whose endpoints are close (collated molecule batches: |col - row| < the largest molecule) a
-// 32-bit key then reaches 4 M nodes, and a 4096-molecule batch (103 k nodes, 215 k edges) sorts as 32-bit keys
-// (one block sort + 8 merge passes of 215 k words) instead of 64-bit ones — the merge passes are most of what
-// the background build of such a batch runs beside the step. Same order: bias is a constant. An edge that does
-// not fit makes make_keys set INFO_NOTLOCAL and the host repeats the build with plain 64-bit keys.
 template <typename K>
 struct KeyOps {
   int shift;
-  int bias = 0;
   __host__ __device__ K make(uint32_t row, uint32_t col) const {
-    return (static_cast<K>(row) << shift) | static_cast<K>(bias ? col - row + static_cast<uint32_t>(bias) : col);
-  }
-  __host__ __device__ K sentinel(uint32_t row) const { return static_cast<K>(row) << shift; }   // sorts behind every edge of rows < row
-  __host__ __device__ bool fits(uint32_t row, uint32_t col) const {
-    return !bias || (col - row + static_cast<uint32_t>(bias)) < (static_cast<uint32_t>(bias) << 1);
+    return (static_cast<K>(row) << shift) | static_cast<K>(col);
   }
   __host__ __device__ uint32_t row(K k) const { return static_cast<uint32_t>(k >> shift); }
   __host__ __device__ uint32_t col(K k) const {
-    const uint32_t low = static_cast<uint32_t>(k & ((static_cast<K>(1) << shift) - 1));
-    return bias ? row(k) + low - static_cast<uint32_t>(bias) : low;
+    return static_cast<uint32_t>(k & ((static_cast<K>(1) << shift) - 1));
   }
 };
 
@@ -104,17 +90,12 @@ __global__ void make_keys_kernel(const int64_t* __restrict__ ei, int64_t E, int3
   K key;
   if (s < 0 || s >= n || d < 0 || d >= n) {
     atomicOr(&info[INFO_BAD], 1);
-    key = ko.sentinel(n);
+    key = ko.make(n, 0);
   } else if (normalize && s == d) {
-    key = ko.sentinel(n);  // add_remaining_self_loops drops it
+    key = ko.make(n, 0);  // add_remaining_self_loops drops it
   } else {
-    const uint32_t r = static_cast<uint32_t>(transpose ? s : d), c = static_cast<uint32_t>(transpose ? d : s);
-    if (!ko.fits(r, c)) {   // (local keys only) the host repeats the build with plain 64-bit keys
-      atomicOr(&info[INFO_NOTLOCAL], 1);
-      key = ko.sentinel(n);
-    } else {
-      key = ko.make(r, c);
-    }
+    key = transpose ? ko.make(static_cast<uint32_t>(s), static_cast<uint32_t>(d))
+                    : ko.make(static_cast<uint32_t>(d), static_cast<uint32_t>(s));
   }
   keys[e] = key;
 }
@@ -279,10 +260,8 @@ template <typename K>
 static gconv_status_t build_direction(const int64_t* ei, int64_t E, int32_t n, int normalize,
                                       int transpose, int shift, char* arena, const BuildLayout& L,
                                       const CsrOut& o, float* dis, int32_t* info, int base,
-                                      hipStream_t stream, int local_shift = 0) {
-  // local_shift != 0: `shift` = bits of a row index, the offset field takes local_shift bits
-  KeyOps<K> ko{local_shift ? local_shift : shift, local_shift ? 1 << (local_shift - 1) : 0};
-  const int key_bits = local_shift ? local_shift + shift : 2 * shift;
+                                      hipStream_t stream) {
+  KeyOps<K> ko{shift};
   K* keys_a = reinterpret_cast<K*>(arena + L.keys_a);
   K* keys_b = reinterpret_cast<K*>(arena + L.keys_b);
   const int T = 256;
@@ -293,7 +272,7 @@ static gconv_status_t build_direction(const int64_t* ei, int64_t E, int32_t n, i
     GCONV_LAUNCH_CHECK();
     size_t cub_bytes = L.cub_bytes;
     GCONV_HIP(hipcub::DeviceRadixSort::SortKeys(arena + L.cub, cub_bytes, keys_a, keys_b,
-                                                static_cast<int>(E), 0, key_bits, stream));
+                                                static_cast<int>(E), 0, 2 * shift, stream));
     sorted = keys_b;
   }
   build_csr_kernel<K><<<static_cast<unsigned>((E + 1 + T - 1) / T), T, 0, stream>>>(
@@ -1306,38 +1285,29 @@ extern "C" gconv_status_t gconv_graph_build_ex(const int64_t* edge_index, int64_
     }
   }
 
+  GCONV_HIP(hipMemsetAsync(info, 0, 64 * sizeof(int32_t), stream));
   const int b = index_bits(n);
   const bool k32 = 2 * b <= 32;
-  // more than 65535 nodes: 32-bit LOCAL keys (KeyOps) when the list looks like a collated batch of small
-  // graphs (few edges per node; at least +-256 of offset room) — the kernels find out whether it is
-  static const bool no_local = std::getenv("GCONV_NO_LOCAL_KEYS") != nullptr;   // A/B knob
-  int local_shift = (!k32 && !no_local && b <= 23 && E <= 4 * static_cast<int64_t>(n)) ? 32 - b : 0;
-  gconv_status_t st = GCONV_OK;
-  for (;;) {
-    GCONV_HIP(hipMemsetAsync(info, 0, 64 * sizeof(int32_t), stream));
-    st = (k32 || local_shift)
-             ? build_direction<uint32_t>(edge_index, E, n, normalize, 0, b, arena, L, of, dis, info, FWD, stream, local_shift)
-             : build_direction<uint64_t>(edge_index, E, n, normalize, 0, b, arena, L, of, dis, info, FWD, stream);
-    if (st != GCONV_OK) return st;
+  gconv_status_t st =
+      k32 ? build_direction<uint32_t>(edge_index, E, n, normalize, 0, b, arena, L, of, dis, info, FWD, stream)
+          : build_direction<uint64_t>(edge_index, E, n, normalize, 0, b, arena, L, of, dis, info, FWD, stream);
+  if (st != GCONV_OK) return st;
 
-    if (E > 0) {
-      sym_check_kernel<<<static_cast<unsigned>((E + T - 1) / T), T, 0, stream>>>(
-          of.rowptr, of.col, n, info + FWD, info + INFO_ASYM);
-      GCONV_LAUNCH_CHECK();
-    }
-    if (n > 0) {   // tiles of the forward CSR: cuts, halos, local columns (one wave per tile)
-      tile_build_kernel<true><<<(L.ntiles + 3) / 4, 256, 0, stream>>>(of.rowptr, of.col, dis, n, L.ntiles, L.T, slack,
-                                                                      tile_ptr, tf.lcol, tf.halo, tf.recs, info, is);
-      GCONV_LAUNCH_CHECK();
-    }
-    GCONV_HIP(hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, stream));
-    GCONV_HIP(hipStreamSynchronize(stream));
-    if (h[INFO_BAD]) {
-      g->bad_index = 1;
-      return GCONV_E_BAD_INDEX;
-    }
-    if (!local_shift || !h[INFO_NOTLOCAL]) break;
-    local_shift = 0;   // an edge spans more than the offset field: once more, with plain 64-bit keys
+  if (E > 0) {
+    sym_check_kernel<<<static_cast<unsigned>((E + T - 1) / T), T, 0, stream>>>(
+        of.rowptr, of.col, n, info + FWD, info + INFO_ASYM);
+    GCONV_LAUNCH_CHECK();
+  }
+  if (n > 0) {   // tiles of the forward CSR: cuts, halos, local columns (one wave per tile)
+    tile_build_kernel<true><<<(L.ntiles + 3) / 4, 256, 0, stream>>>(of.rowptr, of.col, dis, n, L.ntiles, L.T, slack,
+                                                                    tile_ptr, tf.lcol, tf.halo, tf.recs, info, is);
+    GCONV_LAUNCH_CHECK();
+  }
+  GCONV_HIP(hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, stream));
+  GCONV_HIP(hipStreamSynchronize(stream));
+  if (h[INFO_BAD]) {
+    g->bad_index = 1;
+    return GCONV_E_BAD_INDEX;
   }
 
   fill(g->fwd, of, h + FWD);
@@ -1346,8 +1316,7 @@ extern "C" gconv_status_t gconv_graph_build_ex(const int64_t* edge_index, int64_
   if (g->symmetric) {
     g->bwd = g->fwd;
   } else {  // rare path (directed edge lists): second sort for S^T, its tiles on the same cuts, second sync
-    st = (k32 || local_shift)
-             ? build_direction<uint32_t>(edge_index, E, n, normalize, 1, b, arena, L, ob, nullptr, info, BWD, stream, local_shift)
+    st = k32 ? build_direction<uint32_t>(edge_index, E, n, normalize, 1, b, arena, L, ob, nullptr, info, BWD, stream)
              : build_direction<uint64_t>(edge_index, E, n, normalize, 1, b, arena, L, ob, nullptr, info, BWD, stream);
     if (st != GCONV_OK) return st;
     if (n > 0) {
