@@ -349,3 +349,15 @@ def test_bench_rank_role_is_not_a_launcher():
                          capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and "launcher_cmd" not in out.stdout
     assert "WORLD_SIZE=2" in out.stderr
+
+
+def test_header_is_plain_c_and_a_c_program_links_the_library():
+    """`include/gconv_adapter.h` compiles as C11 (-Wall -Werror) and `tools/cabi_spmm_bench.c` — graph build +
+    SpMM from plain C, no torch, no C++ — links against the library (a C ABI usable without Python)."""
+    import __graft_entry__ as ge
+    out = ge.build_c_consumer(force=True)
+    assert os.path.exists(out)
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", out], capture_output=True, text=True).stdout
+    assert "libgconv_adapter.so" in needed and "libtorch" not in needed and "libpython" not in needed
+    assert "libstdc++" not in needed        # (a C program: the C++ runtime comes in only through the library itself)
