@@ -15,4 +15,4 @@ def test_c_program_builds_a_plan_and_runs_the_spmm(dev, args):
     exe = ge.build_c_consumer()
     out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "gconv_spmm_csr_f32:" in out.stdout and "GB/s" in out.stdout
+    assert "gconv_spmm_csr_f32, plain call:" in out.stdout and "pre-scaled operands" in out.stdout and "GB/s" in out.stdout
