@@ -21,7 +21,8 @@
 //             the exponent bookkeeping whatever the tiles were
 // Kernel shape as in round 3: 128 nodes x 80 features per workgroup of 4 waves, k-steps of 32, six (here: four)
 // images by LDS-DMA into two XOR-swizzled LDS buffers, one barrier per k-step, XCD-aware tile order — but
-// 26 KB per stage instead of 39: THREE workgroups per CU.
+// 26 KB per stage instead of 39 (three stages: two workgroups per CU). Shapes the W-stationary kernel at the
+// end of this file takes (K = 300 / 600 of the d = 300 GIN MLP) do not come here.
 #include <cstdlib>
 
 #include "mlp_split.h"
@@ -311,6 +312,280 @@ __global__ __launch_bounds__(kThreads, S >= 3 ? 2 : 3) void mlp_gemm_f16x2_kerne
   }
 }
 
+
+// ---- the same product with the WEIGHTS stationary in registers (round 4, second half) -------------------------
+// The tiled kernel above lives between barriers: ten (K = 300) or nineteen (K = 600) k-steps per workgroup, each
+// a 0.2 us burst of MFMAs behind a 1 - 2 us LDS-DMA round trip with two steps in flight, and the 400 - 800
+// workgroups of a 512-molecule batch fill the chip's 512 slots unevenly. Here a workgroup keeps ITS columns of W
+// — 64 NT features x the whole K, as MFMA fragments — in registers (NT KS 8 VGPRs per lane: 160 at K = 320 with
+// 32 features per wave, 152 at K = 608 with 16) and walks a contiguous range of 16-node row blocks: per block ONE
+// barrier, 3 NT KS MFMAs per wave (60 / 57), an epilogue, and R - 1 blocks of A (20 / 38 KB each: every k-step
+// of both images, the 16 row exponents and, for EPI 2, the block's piece of the ReLU mask) in flight by LDS-DMA.
+// Four LOADER waves issue and await that DMA: vmcnt is per wave and counts stores too — the compute waves' output
+// stores would otherwise sit in the queue the next block's loads are awaited on — and the LDS-DMA rate of a CU
+// grows with the number of waves issuing it (DMA alone, 103 k rows, K = 600: 141 us with two loader waves, 103
+// with four). The compute waves read everything through LDS and wait for no vector-memory instruction inside
+// the loop. Column groups (Mp / (64 NT) = 5 for both shapes) x as many row ranges as fill the chip once = 240
+// workgroups of equal length; the groups of a range sit on one XCD, so A is fetched from memory once and read
+// from L2 five times. Pair outputs at NT = 2 leave as 16-byte stores (v_permlane16_swap pairs the two tiles'
+// 4-feature pieces of neighbouring row groups: 64 contiguous bytes per node and instruction instead of 32).
+// The arithmetic per output element is the tiled kernel's, product for product: the two agree bit for bit
+// (tests/test_gin.py). Measured (tools/lab/ws_gemm.py, one GEMM, 13104 / 102952 rows): K = 300 with ReLU, pair
+// out 35.4 -> 26.3 / 249 -> 155 us; K = 600, fp32 out 27.4 -> 24.1 / 204 -> 161 us. Leave-one-out builds
+// (GCONV_MLP_WS_LAB) at 102952 rows, K = 300: no DMA after the prologue 131, no output stores 114, no epilogue
+// 98, DMA and barriers alone 70 us — the streams add up more than they overlap; the 250 MB of pair output and
+// the 5 x 132 MB of A through L2 are what the kernel waits for, not the 50 us of MFMAs.
+#ifndef GCONV_MLP_WS_LAB
+#define GCONV_MLP_WS_LAB 0   // leave-one-out builds (results wrong by construction): 1 no MFMAs, 2 no epilogue,
+#endif                       // 4 no stores, 8 no DMA after the prologue, 16 no LDS fragment reads
+constexpr int kWsComputeWaves = 4, kWsLoaderWaves = 4;
+constexpr int kWsThreads = 64 * (kWsComputeWaves + kWsLoaderWaves);
+constexpr int ws_ring(int KS) { return KS <= 10 ? 6 : 4; }                   // row blocks of A in LDS
+// one ring slot: the block's A chunks (16 rows x 64 B each: 2 images x KS k-steps), its 16 row exponents (one
+// 256-byte dword DMA), and for EPI 2 the block's piece of the ReLU mask (16 rows x 64 NT features, fp16)
+constexpr int ws_mask_chunks(int NT, int EPI) { return EPI == 2 ? 2 * NT : 0; }
+constexpr int ws_slot_bytes(int KS, int NT, int EPI) { return (2 * KS + ws_mask_chunks(NT, EPI)) * 1024 + 256; }
+constexpr int ws_items(int KS, int NT, int EPI) { return 2 * KS + 1 + ws_mask_chunks(NT, EPI); }
+constexpr int ws_items_per_loader(int KS, int NT, int EPI) {
+  return (ws_items(KS, NT, EPI) + kWsLoaderWaves - 1) / kWsLoaderWaves;
+}
+constexpr bool ws_supported(int KS, int NT, int EPI) {
+  return ws_ring(KS) * ws_slot_bytes(KS, NT, EPI) <= 160 * 1024 &&
+         ws_items_per_loader(KS, NT, EPI) * (ws_ring(KS) - 2) <= 63;          // (vmcnt is a 6-bit count)
+}
+
+template <int KS, int NT, int EPI, bool OUT_SPLIT>
+__global__ __launch_bounds__(kWsThreads, 1) void mlp_gemm_f16x2_ws_kernel(const _Float16* __restrict__ A2,
+                                                                         const int32_t* __restrict__ a_exp,
+                                                                         const _Float16* __restrict__ W2,
+                                                                         const float* __restrict__ wtail,
+                                                                         const float* __restrict__ bias,
+                                                                         const _Float16* __restrict__ mask_hi,
+                                                                         float* __restrict__ C,
+                                                                         _Float16* __restrict__ C2,
+                                                                         int32_t* __restrict__ c_exp, int N, int M,
+                                                                         int Mp, int Mq, int CG, int rr_per_xcd) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int Kp = KS * kBK, R = ws_ring(KS), kSlotB = ws_slot_bytes(KS, NT, EPI);
+  constexpr int kMaskOff = 2 * KS * 1024, kMaskChunks = ws_mask_chunks(NT, EPI), kExpOff = kMaskOff + kMaskChunks * 1024;
+  constexpr int kItems = ws_items(KS, NT, EPI), kDma = ws_items_per_loader(KS, NT, EPI);
+  static_assert(ws_supported(KS, NT, EPI), "ring does not fit LDS / vmcnt");
+  const int lane = threadIdx.x & 63, wave = wave_id();
+  // the column groups of one row range on consecutive workgroups of ONE XCD: A comes from memory once per range
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int cg = slot % CG, rr = xcd * rr_per_xcd + slot / CG, RR = 8 * rr_per_xcd;
+  const int nb_total = (N + 15) >> 4;
+  const int b0 = static_cast<int>(static_cast<long long>(rr) * nb_total / RR);
+  const int nb = static_cast<int>(static_cast<long long>(rr + 1) * nb_total / RR) - b0;
+  if (nb <= 0) return;                                     // (workgroup-uniform, before any barrier)
+  const size_t aimg = static_cast<size_t>(N) * Kp;
+
+  if (wave >= kWsComputeWaves) {   // ---- loader waves: items [lw kDma, (lw + 1) kDma) of every block ----------
+    const int lw = wave - kWsComputeWaves;
+    const int crow = lane >> 2;
+    const int cq = (lane & 3) ^ ((4 - (crow >> 2)) & 3);   // the 16-byte piece that belongs in this lane's LDS slot
+    auto dma = [&](int blk) {
+      char* base = smem + (blk % R) * kSlotB;
+      const int row0 = (b0 + blk) * 16;
+      const int row = min(row0 + crow, N - 1);             // (rows past N: a valid row, never stored)
+      const _Float16* src = A2 + static_cast<size_t>(row) * Kp + 8 * cq;
+#pragma unroll
+      for (int j = 0; j < kDma; ++j) {
+        const int c = min(lw * kDma + j, kItems - 1);      // (the odd item out is issued twice: same bytes, same place)
+        if (c < 2 * KS) {                                  // A: image c / KS, k-step c % KS
+          lds_dma16(src + (c / KS) * aimg + (c % KS) * kBK, base + c * 1024);
+        } else if (c < 2 * KS + kMaskChunks) {             // mask: LDS piece p = 64 m + lane <- (row p / (8 NT), 16-byte
+          const int pp = (c - 2 * KS) * 64 + lane;         // piece (p % (8 NT)) ^ (row % (8 NT)) of the row's 128 NT bytes)
+          const int mrow = pp / (8 * NT), piece = (pp % (8 * NT)) ^ (mrow % (8 * NT));
+          const int col = min(cg * (64 * NT) + 8 * piece, Mq - 8);   // (past the padded row: any valid piece, never used)
+          lds_dma16(mask_hi + static_cast<size_t>(min(row0 + mrow, N - 1)) * Mq + col, base + c * 1024);
+        } else {                                           // the 16 row exponents (lanes 16 .. 63: repeats)
+          __builtin_amdgcn_global_load_lds(
+              reinterpret_cast<const __attribute__((address_space(1))) void*>(
+                  reinterpret_cast<uintptr_t>(a_exp + min(row0 + (lane & 15), N - 1))),
+              reinterpret_cast<__attribute__((address_space(3))) void*>(
+                  static_cast<uint32_t>(reinterpret_cast<uintptr_t>(base + kExpOff))),
+              4, 0, 0);
+        }
+      }
+    };
+    for (int j = 0; j < R - 1; ++j)
+      if (j < nb) dma(j);
+    for (int i = 0; i < nb; ++i) {
+      // block i has landed (R - 2 newer ones may be in flight; towards the end fewer were issued: wait for all)
+      if (i + R - 2 < nb) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma * (R - 2)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                        // ... and block i - 1 is read out:
+      if (i + R - 1 < nb && !(GCONV_MLP_WS_LAB & 8)) dma(i + R - 1);   // its slot takes block i + R - 1
+    }
+    return;
+  }
+
+  // ---- compute waves: features colbase .. colbase + 16 NT of every row block ---------------------------------
+  // (their only vector-memory instructions inside the loop are the output stores: everything they read arrives
+  // through LDS, so nothing in the loop waits for a store to be acknowledged)
+  const int colbase = cg * (64 * NT) + wave * (16 * NT);
+  const int frow = lane & 15, fgrp = lane >> 4;
+  f16x8 wf[NT][KS][2];
+  {
+    const size_t wimg = static_cast<size_t>(Mp) * Kp;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int k = 0; k < KS; ++k)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+          wf[t][k][s] = *reinterpret_cast<const f16x8*>(W2 + s * wimg + static_cast<size_t>(colbase + 16 * t + frow) * Kp +
+                                                         k * kBK + 8 * fgrp);
+  }
+  const float winv = wtail[0], l1max = wtail[1], bmax = wtail[2];
+  f32x4 bc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int f0 = colbase + 16 * t + 4 * fgrp;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) bc[t][v] = bias && f0 + v < M ? bias[f0 + v] : 0.f;
+  }
+  // the fragments are in their registers before the loop starts (an opaque use: the compiler waits for the loads
+  // HERE, once, instead of counting them down inside the loop, and cannot re-load them per block)
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      asm volatile("" : "+v"(wf[t][k][0]), "+v"(wf[t][k][1]));
+    }
+    asm volatile("" : "+v"(bc[t]));
+  }
+  const int f_off = frow * 64 + 16 * (fgrp ^ ((4 - (frow >> 2)) & 3));
+  // this lane's 8 bytes of the mask piece: features 16 (NT wave + t) + 4 fgrp .. + 3 of the group's 64 NT
+  int mk_off[NT > 0 ? NT : 1];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int piece = (2 * (NT * wave + t)) + (fgrp >> 1);
+    mk_off[t] = kMaskOff + (frow * (8 * NT) + (piece ^ (frow % (8 * NT)))) * 16 + 8 * (fgrp & 1);
+  }
+  int slot_b = 0;
+  for (int i = 0; i < nb; ++i) {
+    __builtin_amdgcn_s_barrier();                          // block i is in LDS
+    const char* sb = smem + slot_b * kSlotB;
+    const char* la = sb + f_off;
+    slot_b = slot_b + 1 == R ? 0 : slot_b + 1;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+#if GCONV_MLP_WS_LAB & 16
+      f16x8 ah = wf[0][k][0], al = wf[0][k][1];
+      asm volatile("" : "+v"(ah), "+v"(al));
+#else
+      const f16x8 ah = *reinterpret_cast<const f16x8*>(la + k * 1024);
+      const f16x8 al = *reinterpret_cast<const f16x8*>(la + (KS + k) * 1024);
+#endif
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        f32x4 c = acc[t];   // smallest terms first (as in the tiled kernel)
+#if GCONV_MLP_WS_LAB & 1
+        c[0] += static_cast<float>(al[0]) + static_cast<float>(ah[1]) + static_cast<float>(wf[t][k][0][0]) +
+                static_cast<float>(wf[t][k][1][0]);
+#else
+        c = mfma_f16(wf[t][k][0], al, c);   // W hi * A lo
+        c = mfma_f16(wf[t][k][1], ah, c);   // W lo * A hi
+        c = mfma_f16(wf[t][k][0], ah, c);   // hi * hi
+#endif
+        acc[t] = c;
+      }
+    }
+#if GCONV_MLP_WS_LAB & 2
+    asm volatile("" ::"v"(acc[0]), "v"(acc[NT - 1]));
+    if (N >= 0) continue;
+#endif
+    // epilogue: lane l holds features f0 .. f0 + 3 (f0 = colbase + 16 t + 4 (l >> 4)) of node r
+    const int r = (b0 + i) * 16 + frow;
+    const int ea = *reinterpret_cast<const int*>(sb + kExpOff + 4 * frow);
+    const float sc = ldexpf(winv, -ea);                    // products of scaled operands -> true units
+    const int eh = scale_exp(ldexpf(kPairTop * l1max, -ea) + (EPI == 1 ? bmax : 0.f));
+    f16x4 ph[NT], pl[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int f0 = colbase + 16 * t + 4 * fgrp;
+      f32x4 y = acc[t] * sc + bc[t];
+      if (EPI == 1) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) y[v] = y[v] > 0.f ? y[v] : 0.f;
+      }
+      if (EPI == 2) {
+        const f16x4 mk = *reinterpret_cast<const f16x4*>(sb + mk_off[t]);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) y[v] = mk[v] > static_cast<_Float16>(0.f) ? y[v] : 0.f;
+      }
+      const bool live = r < N;                             // (the last block's rows past N are not stored)
+#if GCONV_MLP_WS_LAB & 4
+      if (OUT_SPLIT) {
+        f16x4 h, l;
+        split2x4(y, eh, h, l);
+        asm volatile("" ::"v"(h), "v"(l));
+      } else {
+        asm volatile("" ::"v"(y));
+      }
+      ph[t] = pl[t] = f16x4{0, 0, 0, 0};
+      if (N >= 0) continue;
+#endif
+      if (!OUT_SPLIT) {
+        if (live && f0 + 3 < M) {
+          stg4(C + static_cast<size_t>(r) * M + f0, y);
+        } else if (live) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            if (f0 + v < M) C[static_cast<size_t>(r) * M + f0 + v] = y[v];
+        }
+      } else if (NT == 2) {
+        // both tiles first: below, a lane trades one tile's 4 features for its neighbour row group's 4 of the
+        // other tile and stores 8 consecutive features (16 bytes) per image
+#pragma unroll
+        for (int v = 0; v < 4; ++v) y[v] = f0 + v < M ? y[v] : 0.f;
+        split2x4(y, eh, ph[t], pl[t]);
+      } else if (live && f0 < Mq) {   // (Mq is a multiple of 4: the 4 features are inside the padded row or outside it)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) y[v] = f0 + v < M ? y[v] : 0.f;
+        f16x4 h, l;
+        split2x4(y, eh, h, l);
+        const size_t img = static_cast<size_t>(N) * Mq, o = static_cast<size_t>(r) * Mq + f0;
+        *reinterpret_cast<f16x4*>(C2 + o) = h;
+        *reinterpret_cast<f16x4*>(C2 + img + o) = l;
+        if (colbase == 0 && t == 0 && fgrp == 0) c_exp[r] = eh;
+      }
+    }
+    if (OUT_SPLIT && NT == 2) {
+      // v_permlane16_swap: the odd 16-lane rows of the first operand <-> the even rows of the second. With
+      // (tile 0, tile 1) as the operands, row groups 0 / 2 end up with features 4 g .. 4 g + 7 of tile 0 and row
+      // groups 1 / 3 with features 4 (g - 1) .. 4 (g - 1) + 7 of tile 1: every store instruction writes 64
+      // contiguous bytes per node instead of 32
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 out[2];
+#pragma unroll
+      for (int img = 0; img < 2; ++img) {
+        const u32x2 a = __builtin_bit_cast(u32x2, img ? pl[0] : ph[0]);
+        const u32x2 b = __builtin_bit_cast(u32x2, img ? pl[NT - 1] : ph[NT - 1]);
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const auto sw = __builtin_amdgcn_permlane16_swap(a[w], b[w], false, false);
+          out[img][w] = sw[0];
+          out[img][2 + w] = sw[1];
+        }
+      }
+      const int f8 = colbase + ((fgrp & 1) ? 16 + 4 * (fgrp - 1) : 4 * fgrp);
+      if (r < N && f8 < Mq && !(GCONV_MLP_WS_LAB & 4)) {   // (Mq is a multiple of 8: the 8 features are inside the padded row or not)
+        const size_t img = static_cast<size_t>(N) * Mq, o = static_cast<size_t>(r) * Mq + f8;
+        *reinterpret_cast<u32x4*>(C2 + o) = out[0];
+        *reinterpret_cast<u32x4*>(C2 + img + o) = out[1];
+        if (colbase == 0 && fgrp == 0) c_exp[r] = eh;
+      }
+    }
+  }
+}
+
 }  // namespace gconv
 
 using namespace gconv;
@@ -394,6 +669,58 @@ extern "C" gconv_status_t gconv_mlp_gemm_f16x2(const void* a_pair, const void* w
   int32_t* cexp = c_pair ? reinterpret_cast<int32_t*>(static_cast<char*>(c_pair) +
                                                       mlp_pair_exp_offset(num_rows, out_features))
                          : nullptr;
+  // weights stationary in registers (kernel comment) for the two contraction lengths of the GIN MLP (d = 300:
+  // K = 300 with 32 features per wave, K = 600 with 16) when the chip holds a row range per column group;
+  // GCONV_MLP_WS=0: the tiled kernel for everything (A/B)
+  static const bool ws_on = [] { const char* v = getenv("GCONV_MLP_WS"); return !(v && v[0] == '0'); }();
+  const int KS = Kp / kBK, NT = KS == 10 ? 2 : 1;
+  if (ws_on && (KS == 10 || (KS == 19 && epilogue != 2)) && Mp % (64 * NT) == 0) {
+    static const int cus = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        n = 0;
+      return n;
+    }();
+    const int CG = Mp / (64 * NT), rr_per_xcd = (cus / 8) / CG;
+    if (rr_per_xcd >= 1) {
+      const dim3 wgrid(8 * rr_per_xcd * CG);
+#define GCONV_MLP_WS_LAUNCH_K(KS_, NT_, EPI_, SPLIT_)                                                              \
+  do {                                                                                                             \
+    constexpr int ws_lds = ws_ring(KS_) * ws_slot_bytes(KS_, NT_, EPI_);                                                   \
+    static bool opted_in = false;                                                                                  \
+    if (!opted_in) {                                                                                               \
+      GCONV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_gemm_f16x2_ws_kernel<KS_, NT_, EPI_, SPLIT_>), \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, ws_lds));                          \
+      opted_in = true;                                                                                             \
+    }                                                                                                              \
+    mlp_gemm_f16x2_ws_kernel<KS_, NT_, EPI_, SPLIT_><<<wgrid, kWsThreads, ws_lds, stream>>>(                       \
+        a, aexp, w, wtail, bias, mk, c_f32, c2, cexp, num_rows, out_features, Mp, Mq, CG, rr_per_xcd);             \
+  } while (0)
+#define GCONV_MLP_WS_LAUNCH(EPI_, SPLIT_)                      \
+  do {                                                         \
+    if (KS == 10) GCONV_MLP_WS_LAUNCH_K(10, 2, EPI_, SPLIT_);  \
+    else if (EPI_ != 2) GCONV_MLP_WS_LAUNCH_K(19, 1, (EPI_ == 2 ? 0 : EPI_), SPLIT_); \
+  } while (0)
+      if (c_pair) {
+        switch (epilogue) {
+          case 0: GCONV_MLP_WS_LAUNCH(0, true); break;
+          case 1: GCONV_MLP_WS_LAUNCH(1, true); break;
+          default: GCONV_MLP_WS_LAUNCH(2, true); break;
+        }
+      } else {
+        switch (epilogue) {
+          case 0: GCONV_MLP_WS_LAUNCH(0, false); break;
+          case 1: GCONV_MLP_WS_LAUNCH(1, false); break;
+          default: GCONV_MLP_WS_LAUNCH(2, false); break;
+        }
+      }
+#undef GCONV_MLP_WS_LAUNCH
+#undef GCONV_MLP_WS_LAUNCH_K
+      GCONV_LAUNCH_CHECK();
+      return GCONV_OK;
+    }
+  }
 #define GCONV_MLP_LAUNCH_S(EPI_, SPLIT_, S_)                                                                       \
   do {                                                                                                             \
     static bool opted_in = false; /* (dynamic LDS above the 48 KB default; once per kernel) */                      \
