@@ -330,11 +330,19 @@ __global__ __launch_bounds__(kThreads, S >= 3 ? 2 : 3) void mlp_gemm_f16x2_kerne
 // from L2 five times. Pair outputs at NT = 2 leave as 16-byte stores (v_permlane16_swap pairs the two tiles'
 // 4-feature pieces of neighbouring row groups: 64 contiguous bytes per node and instruction instead of 32).
 // The arithmetic per output element is the tiled kernel's, product for product: the two agree bit for bit
-// (tests/test_gin.py). Measured (tools/lab/ws_gemm.py, one GEMM, 13104 / 102952 rows): K = 300 with ReLU, pair
-// out 35.4 -> 26.3 / 249 -> 155 us; K = 600, fp32 out 27.4 -> 24.1 / 204 -> 161 us. Leave-one-out builds
-// (GCONV_MLP_WS_LAB) at 102952 rows, K = 300: no DMA after the prologue 131, no output stores 114, no epilogue
-// 98, DMA and barriers alone 70 us — the streams add up more than they overlap; the 250 MB of pair output and
-// the 5 x 132 MB of A through L2 are what the kernel waits for, not the 50 us of MFMAs.
+// (tests/test_gin.py). The previous block's epilogue is part of the current block's instruction stream (buffer
+// stores that drop what lies past the row / the matrix: no branches), so its VALU work sits in the MFMAs' issue
+// shadows, and the A fragments are read two k-steps ahead of their MFMAs (GCONV_MLP_WS_SCHED; hipcc's own order
+// keeps them one step ahead: K = 600 at 13104 rows 24.7 -> 20.0 us).
+// Measured (tools/lab/ws_gemm.py, one GEMM, 13104 / 102952 rows): K = 300 with ReLU, pair out 35.7 -> 25.9 /
+// 237 -> 154 us; K = 600, fp32 out 27.4 -> 20.0 / 204 -> 159 us. Leave-one-out builds (GCONV_MLP_WS_LAB) at
+// 13104 rows, K = 300: DMA, barriers and LDS reads alone 12.0, with the MFMAs 19.9, with the epilogue's
+// arithmetic 23.2, with its stores 25.6 us — the streams add up more than they overlap; the 5 x 16 MB of A
+// through L2 at the 40 - 70 GB/s per CU that LDS-DMA delivers and the 31 MB of pair output are what the kernel
+// waits for, not the 6 us of MFMAs.
+#ifndef GCONV_MLP_WS_SCHED
+#define GCONV_MLP_WS_SCHED 2   // A fragments this many k-steps ahead (0: the compiler's own order)
+#endif
 #ifndef GCONV_MLP_WS_LAB
 #define GCONV_MLP_WS_LAB 0   // leave-one-out builds (results wrong by construction): 1 no MFMAs, 2 no epilogue,
 #endif                       // 4 no stores, 8 no DMA after the prologue, 16 no LDS fragment reads
@@ -464,45 +472,20 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_gemm_f16x2_ws_kernel(const 
     const int piece = (2 * (NT * wave + t)) + (fgrp >> 1);
     mk_off[t] = kMaskOff + (frow * (8 * NT) + (piece ^ (frow % (8 * NT)))) * 16 + 8 * (fgrp & 1);
   }
-  int slot_b = 0;
-  for (int i = 0; i < nb; ++i) {
-    __builtin_amdgcn_s_barrier();                          // block i is in LDS
-    const char* sb = smem + slot_b * kSlotB;
-    const char* la = sb + f_off;
-    slot_b = slot_b + 1 == R ? 0 : slot_b + 1;
-    f32x4 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < KS; ++k) {
-#if GCONV_MLP_WS_LAB & 16
-      f16x8 ah = wf[0][k][0], al = wf[0][k][1];
-      asm volatile("" : "+v"(ah), "+v"(al));
-#else
-      const f16x8 ah = *reinterpret_cast<const f16x8*>(la + k * 1024);
-      const f16x8 al = *reinterpret_cast<const f16x8*>(la + (KS + k) * 1024);
-#endif
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        f32x4 c = acc[t];   // smallest terms first (as in the tiled kernel)
-#if GCONV_MLP_WS_LAB & 1
-        c[0] += static_cast<float>(al[0]) + static_cast<float>(ah[1]) + static_cast<float>(wf[t][k][0][0]) +
-                static_cast<float>(wf[t][k][1][0]);
-#else
-        c = mfma_f16(wf[t][k][0], al, c);   // W hi * A lo
-        c = mfma_f16(wf[t][k][1], ah, c);   // W lo * A hi
-        c = mfma_f16(wf[t][k][0], ah, c);   // hi * hi
-#endif
-        acc[t] = c;
-      }
-    }
-#if GCONV_MLP_WS_LAB & 2
-    asm volatile("" ::"v"(acc[0]), "v"(acc[NT - 1]));
-    if (N >= 0) continue;
-#endif
-    // epilogue: lane l holds features f0 .. f0 + 3 (f0 = colbase + 16 t + 4 (l >> 4)) of node r
-    const int r = (b0 + i) * 16 + frow;
-    const int ea = *reinterpret_cast<const int*>(sb + kExpOff + 4 * frow);
+  // Outputs through buffer descriptors: a row past N, a feature past the padded row or "no block yet" is an
+  // offset beyond the descriptor and the store is dropped — the epilogue has no branches, so it shares one basic
+  // block with the NEXT block's MFMAs and the scheduler can put its VALU and store instructions into their
+  // issue gaps (an MFMA holds the vector issue for 8 of its 16 cycles). One wave per SIMD computes: nothing
+  // else would fill those gaps.
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const rsrc_t rc = OUT_SPLIT ? make_rsrc(C2, static_cast<uint32_t>(static_cast<size_t>(4) * N * Mq))
+                              : make_rsrc(C, static_cast<uint32_t>(static_cast<size_t>(4) * N * M));
+  const rsrc_t re = make_rsrc(c_exp, OUT_SPLIT ? 4u * N : 0u);
+  const int img_b = 2 * N * Mq;                              // bytes of one fp16 image
+  auto epilogue = [&](const f32x4 (&acc)[NT], int r, int ea, const f16x4 (&mk)[NT]) {
+    // lane l holds features f0 .. f0 + 3 (f0 = colbase + 16 t + 4 (l >> 4)) of node r (r < 0: nothing yet)
+    const bool live = static_cast<unsigned>(r) < static_cast<unsigned>(N);
     const float sc = ldexpf(winv, -ea);                    // products of scaled operands -> true units
     const int eh = scale_exp(ldexpf(kPairTop * l1max, -ea) + (EPI == 1 ? bmax : 0.f));
     f16x4 ph[NT], pl[NT];
@@ -515,45 +498,23 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_gemm_f16x2_ws_kernel(const 
         for (int v = 0; v < 4; ++v) y[v] = y[v] > 0.f ? y[v] : 0.f;
       }
       if (EPI == 2) {
-        const f16x4 mk = *reinterpret_cast<const f16x4*>(sb + mk_off[t]);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) y[v] = mk[v] > static_cast<_Float16>(0.f) ? y[v] : 0.f;
+        for (int v = 0; v < 4; ++v) y[v] = mk[t][v] > static_cast<_Float16>(0.f) ? y[v] : 0.f;
       }
-      const bool live = r < N;                             // (the last block's rows past N are not stored)
-#if GCONV_MLP_WS_LAB & 4
-      if (OUT_SPLIT) {
-        f16x4 h, l;
-        split2x4(y, eh, h, l);
-        asm volatile("" ::"v"(h), "v"(l));
+      if (!OUT_SPLIT) {   // (M is a multiple of 4: the 4 features are inside the row or outside it)
+        int off = live && f0 < M && !(GCONV_MLP_WS_LAB & 4) ? (r * M + f0) * 4 : kBufOob;
+        asm volatile("" : "+v"(off));   // (opaque: a select, not a branch around the store)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, y), rc, off, 0, 0);
       } else {
-        asm volatile("" ::"v"(y));
-      }
-      ph[t] = pl[t] = f16x4{0, 0, 0, 0};
-      if (N >= 0) continue;
-#endif
-      if (!OUT_SPLIT) {
-        if (live && f0 + 3 < M) {
-          stg4(C + static_cast<size_t>(r) * M + f0, y);
-        } else if (live) {
-#pragma unroll
-          for (int v = 0; v < 4; ++v)
-            if (f0 + v < M) C[static_cast<size_t>(r) * M + f0 + v] = y[v];
-        }
-      } else if (NT == 2) {
-        // both tiles first: below, a lane trades one tile's 4 features for its neighbour row group's 4 of the
-        // other tile and stores 8 consecutive features (16 bytes) per image
 #pragma unroll
         for (int v = 0; v < 4; ++v) y[v] = f0 + v < M ? y[v] : 0.f;
         split2x4(y, eh, ph[t], pl[t]);
-      } else if (live && f0 < Mq) {   // (Mq is a multiple of 4: the 4 features are inside the padded row or outside it)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) y[v] = f0 + v < M ? y[v] : 0.f;
-        f16x4 h, l;
-        split2x4(y, eh, h, l);
-        const size_t img = static_cast<size_t>(N) * Mq, o = static_cast<size_t>(r) * Mq + f0;
-        *reinterpret_cast<f16x4*>(C2 + o) = h;
-        *reinterpret_cast<f16x4*>(C2 + img + o) = l;
-        if (colbase == 0 && t == 0 && fgrp == 0) c_exp[r] = eh;
+        if (NT == 1) {    // (Mq is a multiple of 4)
+          int off = live && f0 < Mq && !(GCONV_MLP_WS_LAB & 4) ? (r * Mq + f0) * 2 : kBufOob;
+          asm volatile("" : "+v"(off));
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ph[t]), rc, off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pl[t]), rc, off + img_b, 0, 0);
+        }
       }
     }
     if (OUT_SPLIT && NT == 2) {
@@ -561,8 +522,6 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_gemm_f16x2_ws_kernel(const 
       // (tile 0, tile 1) as the operands, row groups 0 / 2 end up with features 4 g .. 4 g + 7 of tile 0 and row
       // groups 1 / 3 with features 4 (g - 1) .. 4 (g - 1) + 7 of tile 1: every store instruction writes 64
       // contiguous bytes per node instead of 32
-      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
       u32x4 out[2];
 #pragma unroll
       for (int img = 0; img < 2; ++img) {
@@ -575,15 +534,88 @@ __global__ __launch_bounds__(kWsThreads, 1) void mlp_gemm_f16x2_ws_kernel(const 
           out[img][2 + w] = sw[1];
         }
       }
-      const int f8 = colbase + ((fgrp & 1) ? 16 + 4 * (fgrp - 1) : 4 * fgrp);
-      if (r < N && f8 < Mq && !(GCONV_MLP_WS_LAB & 4)) {   // (Mq is a multiple of 8: the 8 features are inside the padded row or not)
-        const size_t img = static_cast<size_t>(N) * Mq, o = static_cast<size_t>(r) * Mq + f8;
-        *reinterpret_cast<u32x4*>(C2 + o) = out[0];
-        *reinterpret_cast<u32x4*>(C2 + img + o) = out[1];
-        if (colbase == 0 && fgrp == 0) c_exp[r] = eh;
+      const int f8 = colbase + ((fgrp & 1) ? 16 + 4 * (fgrp - 1) : 4 * fgrp);   // (Mq is a multiple of 8)
+      int off = live && f8 < Mq && !(GCONV_MLP_WS_LAB & 4) ? (r * Mq + f8) * 2 : kBufOob;
+      asm volatile("" : "+v"(off));
+      __builtin_amdgcn_raw_buffer_store_b128(out[0], rc, off, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(out[1], rc, off + img_b, 0, 0);
+    }
+    if (OUT_SPLIT) {
+      int off = live && colbase == 0 && fgrp == 0 ? 4 * r : kBufOob;
+      asm volatile("" : "+v"(off));
+      __builtin_amdgcn_raw_buffer_store_b32(eh, re, off, 0, 0);
+    }
+  };
+
+  f32x4 pacc[NT];                                          // the previous block's sums, exponents and mask:
+  f16x4 pmk[NT];                                           // its epilogue runs inside this block's MFMAs
+  int pr = -1, pea = 0, slot_b = 0;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    pacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    pmk[t] = f16x4{0, 0, 0, 0};
+  }
+  for (int i = 0; i < nb; ++i) {
+    __builtin_amdgcn_s_barrier();                          // block i is in LDS
+    const char* sb = smem + slot_b * kSlotB;
+    const char* la = sb + f_off;
+    slot_b = slot_b + 1 == R ? 0 : slot_b + 1;
+    const int ea = *reinterpret_cast<const int*>(sb + kExpOff + 4 * frow);
+    f16x4 mk[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      mk[t] = EPI == 2 ? *reinterpret_cast<const f16x4*>(sb + mk_off[t]) : f16x4{0, 0, 0, 0};
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // A fragments kAhead k-steps ahead of their MFMAs; the fences keep LDS reads and MFMAs in this order and let
+    // everything else (the previous block's epilogue) move into the MFMAs' issue shadows
+    constexpr int kAhead = GCONV_MLP_WS_SCHED;
+    constexpr int kFence = 0x2 | 0x4 | 0x10;               // VALU, SALU and vector memory may cross
+    f16x8 ah[KS], al[KS];
+#pragma unroll
+    for (int k = 0; k < kAhead && k < KS; ++k) {
+      ah[k] = *reinterpret_cast<const f16x8*>(la + k * 1024);
+      al[k] = *reinterpret_cast<const f16x8*>(la + (KS + k) * 1024);
+    }
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      if (k + kAhead < KS) {
+        ah[k + kAhead] = *reinterpret_cast<const f16x8*>(la + (k + kAhead) * 1024);
+        al[k + kAhead] = *reinterpret_cast<const f16x8*>(la + (KS + k + kAhead) * 1024);
       }
+      if (kAhead > 0) __builtin_amdgcn_sched_barrier(kFence);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        f32x4 c = acc[t];   // smallest terms first (as in the tiled kernel)
+#if GCONV_MLP_WS_LAB & 1
+        c[0] += static_cast<float>(al[k][0]) + static_cast<float>(ah[k][1]) + static_cast<float>(wf[t][k][0][0]) +
+                static_cast<float>(wf[t][k][1][0]);
+#else
+        c = mfma_f16(wf[t][k][0], al[k], c);   // W hi * A lo
+        c = mfma_f16(wf[t][k][1], ah[k], c);   // W lo * A hi
+        c = mfma_f16(wf[t][k][0], ah[k], c);   // hi * hi
+#endif
+        acc[t] = c;
+      }
+      if (kAhead > 0) __builtin_amdgcn_sched_barrier(kFence);
+    }
+#if !(GCONV_MLP_WS_LAB & 2)
+    epilogue(pacc, pr, pea, pmk);
+#endif
+    pr = (b0 + i) * 16 + frow;
+    pea = ea;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      pacc[t] = acc[t];
+      pmk[t] = mk[t];
     }
   }
+#if GCONV_MLP_WS_LAB & 2
+  asm volatile("" ::"v"(pacc[0]), "v"(pacc[NT - 1]), "v"(pea), "v"(pmk[0]));
+#else
+  epilogue(pacc, pr, pea, pmk);
+#endif
 }
 
 }  // namespace gconv

@@ -8,9 +8,13 @@ sys.path.insert(0, ROOT)
 LAB = {"noepi": 2, "nostore": 4, "nodma": 8, "nomfma_noepi": 3}
 if "--build" in sys.argv:
     import __graft_entry__ as g
-    for name, bits in LAB.items():
-        g.build_library(out=os.path.join(ROOT, "gconv-adapter_amd", "lib", f"libgconv_adapter_ws_{name}.so"),
-                        defines=[f"-DGCONV_MLP_WS_LAB={bits}"])
+    lib = lambda name: os.path.join(ROOT, "gconv-adapter_amd", "lib", f"libgconv_adapter_ws_{name}.so")
+    if "--sched" in sys.argv:     # fragment-read distance variants instead of the leave-one-out set
+        for ahead in (0, 1, 3):
+            g.build_library(out=lib(f"ahead{ahead}"), defines=[f"-DGCONV_MLP_WS_SCHED={ahead}"])
+    else:
+        for name, bits in LAB.items():
+            g.build_library(out=lib(name), defines=[f"-DGCONV_MLP_WS_LAB={bits}"])
     sys.exit(0)
 import torch
 import gconv_adapter_amd as ga
