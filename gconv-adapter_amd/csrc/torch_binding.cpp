@@ -61,8 +61,31 @@ using spmm_ws_fn_t = size_t (*)(const gconv_csr_t*, int32_t);
 using spmm_fn_t = gconv_status_t (*)(const gconv_csr_t*, const float*, const float*, float*, int32_t, const float*,
                                      int32_t, uint32_t, void*, size_t, gconv_stream_t);
 
+using bn_bytes_fn_t = size_t (*)(int32_t, int32_t);
+using bn_fwd_fn_t = gconv_status_t (*)(const float*, const float*, const float*, float*, float*, float, float, int32_t,
+                                       float*, float*, float*, int32_t, int32_t, void*, size_t, gconv_stream_t);
+using bn_bwd_fn_t = gconv_status_t (*)(const float*, const float*, const float*, const float*, const float*,
+                                       const float*, float*, float*, float*, int32_t, int32_t, void*, size_t,
+                                       gconv_stream_t);
+using pair_bytes_fn_t = size_t (*)(int32_t, int32_t);
+using split_rows_fn_t = gconv_status_t (*)(const float*, int32_t, int32_t, void*, gconv_stream_t);
+using pair_gemm_fn_t = gconv_status_t (*)(const void*, const void*, const float*, const void*, float*, void*, int32_t,
+                                          int32_t, int32_t, int32_t, gconv_stream_t);
+using gin_agg_fn_t = gconv_status_t (*)(const gconv_csr_t*, const float*, const int32_t*, const float*, const float*,
+                                        float*, int32_t, gconv_stream_t);
+using gin_agg_pair_fn_t = gconv_status_t (*)(const gconv_csr_t*, const float*, const int32_t*, const float*,
+                                             const float*, void*, int32_t, gconv_stream_t);
+
 struct Lib {
   void* handle = nullptr;
+  bn_bytes_fn_t bn_bytes = nullptr;
+  bn_fwd_fn_t bn_fwd = nullptr;
+  bn_bwd_fn_t bn_bwd = nullptr;
+  pair_bytes_fn_t pair_bytes = nullptr;
+  split_rows_fn_t split_rows = nullptr;
+  pair_gemm_fn_t pair_gemm = nullptr;
+  gin_agg_fn_t gin_agg = nullptr;
+  gin_agg_pair_fn_t gin_agg_pair = nullptr;
   fwd_fn_t fwd = nullptr;
   bwd_fn_t bwd = nullptr;
   str_fn_t str = nullptr;
@@ -101,6 +124,17 @@ void load_library(const std::string& path) {
   g_lib.ws_bwd = reinterpret_cast<ws_fn_t>(dlsym(h, "gconv_adapter_bwd_workspace_bytes"));
   g_lib.spmm_ws = reinterpret_cast<spmm_ws_fn_t>(dlsym(h, "gconv_spmm_workspace_bytes"));
   g_lib.spmm = reinterpret_cast<spmm_fn_t>(dlsym(h, "gconv_spmm_csr_f32"));
+  g_lib.bn_bytes = reinterpret_cast<bn_bytes_fn_t>(dlsym(h, "gconv_batch_norm_workspace_bytes"));
+  g_lib.bn_fwd = reinterpret_cast<bn_fwd_fn_t>(dlsym(h, "gconv_batch_norm_fwd_f32"));
+  g_lib.bn_bwd = reinterpret_cast<bn_bwd_fn_t>(dlsym(h, "gconv_batch_norm_bwd_f32"));
+  g_lib.pair_bytes = reinterpret_cast<pair_bytes_fn_t>(dlsym(h, "gconv_mlp_rows_pair_bytes"));
+  g_lib.split_rows = reinterpret_cast<split_rows_fn_t>(dlsym(h, "gconv_mlp_split_rows_f16x2"));
+  g_lib.pair_gemm = reinterpret_cast<pair_gemm_fn_t>(dlsym(h, "gconv_mlp_gemm_f16x2"));
+  g_lib.gin_agg = reinterpret_cast<gin_agg_fn_t>(dlsym(h, "gconv_gin_aggregate_f32"));
+  g_lib.gin_agg_pair = reinterpret_cast<gin_agg_pair_fn_t>(dlsym(h, "gconv_gin_aggregate_f16x2"));
+  TORCH_CHECK(g_lib.bn_bytes && g_lib.bn_fwd && g_lib.bn_bwd && g_lib.pair_bytes && g_lib.split_rows &&
+                  g_lib.pair_gemm && g_lib.gin_agg && g_lib.gin_agg_pair,
+              "gconv_adapter_amd: C ABI symbols of the fine-tune surroundings missing in ", path);
   TORCH_CHECK(g_lib.fwd && g_lib.bwd && g_lib.str && g_lib.build_bytes && g_lib.build && g_lib.bwd_partial &&
                   g_lib.bwd_finalize && g_lib.ln_fwd && g_lib.ln_bwd && g_lib.ln_bytes && g_lib.padded_rank &&
                   g_lib.ws_fwd && g_lib.ws_bwd && g_lib.spmm_ws && g_lib.spmm && g_lib.build_ex,
@@ -786,6 +820,156 @@ at::Tensor layer_norm_scale(at::Tensor z, c10::optional<at::Tensor> gamma, c10::
   return LayerNormScaleFn::apply(std::move(z), std::move(gamma), std::move(beta), std::move(scalar), eps, stream);
 }
 
+// ---- the adapters' surroundings in the fine-tune step as C++ autograd nodes ----------------------
+// On a 512-molecule shard the step is host-bound once the kernels are fused (~80 launches per step): the Python
+// bindings of BatchNorm (norm.BatchNormFunction) and of the frozen GIN layer (gin.GinFrozenLayerFunction) cost
+// 31 + 43 us of Python per layer forward and as much again on the autograd thread. The same C ABI calls in the
+// same order from here: one host call forward, none from Python backward.
+
+// y = [relu](gamma (x - mean_batch) rstd_batch + beta), running statistics updated in place
+// (/root/reference/src/models/inductive/gnn.py:108-110 with the ReLU of :127-128 folded in)
+struct BatchNormFn : public torch::autograd::Function<BatchNormFn> {
+  static at::Tensor forward(torch::autograd::AutogradContext* ctx, at::Tensor x, c10::optional<at::Tensor> gamma_,
+                            c10::optional<at::Tensor> beta_, c10::optional<at::Tensor> rmean_,
+                            c10::optional<at::Tensor> rvar_, double momentum, double eps, bool relu, int64_t stream) {
+    at::Tensor gamma = gamma_.value_or(at::Tensor()), beta = beta_.value_or(at::Tensor()),
+               rmean = rmean_.value_or(at::Tensor()), rvar = rvar_.value_or(at::Tensor());
+    TORCH_CHECK(g_lib.handle, "gconv_adapter_amd: library not loaded");
+    TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.dim() == 2,
+                "gconv_adapter_amd.BatchNorm1d takes [N, d] fp32 node features on a HIP device");
+    if (!x.is_contiguous()) x = x.contiguous();
+    const int32_t n = static_cast<int32_t>(x.size(0)), d = static_cast<int32_t>(x.size(1));
+    at::Tensor y = at::empty_like(x);
+    at::Tensor stats = at::empty({2, d}, x.options());
+    const size_t bytes = g_lib.bn_bytes(n, d);
+    at::Tensor ws = at::empty({static_cast<int64_t>(bytes > 16 ? bytes : 16)}, x.options().dtype(at::kByte));
+    check(g_lib.bn_fwd(x.data_ptr<float>(), fptr(gamma), fptr(beta), fptr_mut(rmean), fptr_mut(rvar),
+                       static_cast<float>(momentum), static_cast<float>(eps), relu ? 1 : 0, y.data_ptr<float>(),
+                       stats.data_ptr<float>(), stats.data_ptr<float>() + d, n, d, ws.data_ptr(),
+                       static_cast<size_t>(ws.numel()), reinterpret_cast<void*>(stream)),
+          "batch_norm_fwd");
+    ctx->save_for_backward({x, relu ? y : at::Tensor(), stats, gamma});
+    ctx->saved_data["has_beta"] = beta.defined();
+    ctx->saved_data["stream"] = stream;
+    return y;
+  }
+
+  static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx,
+                                                 torch::autograd::variable_list grads) {
+    auto sv = ctx->get_saved_variables();
+    at::Tensor x = sv[0], y = sv[1], stats = sv[2], gamma = sv[3];
+    at::Tensor g = grads[0];
+    if (!g.is_contiguous()) g = g.contiguous();
+    const int32_t n = static_cast<int32_t>(x.size(0)), d = static_cast<int32_t>(x.size(1));
+    at::Tensor gx, gg, gb;
+    if (ctx->needs_input_grad(0)) gx = at::empty_like(x);
+    if (gamma.defined()) gg = at::empty({d}, x.options());
+    if (ctx->saved_data["has_beta"].toBool()) gb = at::empty({d}, x.options());
+    const size_t bytes = g_lib.bn_bytes(n, d);
+    at::Tensor ws = at::empty({static_cast<int64_t>(bytes > 16 ? bytes : 16)}, x.options().dtype(at::kByte));
+    check(g_lib.bn_bwd(g.data_ptr<float>(), x.data_ptr<float>(), fptr(y), stats.data_ptr<float>(),
+                       stats.data_ptr<float>() + d, fptr(gamma), fptr_mut(gx), fptr_mut(gg), fptr_mut(gb), n, d,
+                       ws.data_ptr(), static_cast<size_t>(ws.numel()),
+                       reinterpret_cast<void*>(ctx->saved_data["stream"].toInt())),
+          "batch_norm_bwd");
+    return {gx, gg, gb, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+  }
+};
+
+at::Tensor batch_norm(at::Tensor x, c10::optional<at::Tensor> gamma, c10::optional<at::Tensor> beta,
+                      c10::optional<at::Tensor> running_mean, c10::optional<at::Tensor> running_var,
+                      double momentum, double eps, bool relu, int64_t stream) {
+  return BatchNormFn::apply(std::move(x), std::move(gamma), std::move(beta), std::move(running_mean),
+                            std::move(running_var), momentum, eps, relu, stream);
+}
+
+// The whole frozen GIN layer (/root/reference/src/layers/inductive/gin_conv.py:38-85 with every parameter
+// frozen, the adapter recipe of gnn.py:230-241) as one node, mirroring gin.GinFrozenLayerFunction: aggregation
+// -> the MLP's operand pair -> two GEMMs; backward: split of dY, two GEMMs, the aggregation on the transposed
+// CSR. The CSR structs are copied by value (their arrays live in `arena`, which the node keeps alive); the
+// weights arrive as the scaled fp16 pairs gin._PairWeights caches.
+struct GinFrozenLayerFn : public torch::autograd::Function<GinFrozenLayerFn> {
+  static at::Tensor pair_buffer(const at::Tensor& like, int64_t rows, int64_t features) {
+    const size_t bytes = g_lib.pair_bytes(static_cast<int32_t>(rows), static_cast<int32_t>(features));
+    return at::empty({static_cast<int64_t>(bytes)}, like.options().dtype(at::kByte));
+  }
+
+  static at::Tensor forward(torch::autograd::AutogradContext* ctx, at::Tensor x, at::Tensor arena, int64_t fwd_csr,
+                            int64_t bwd_csr, at::Tensor counts, at::Tensor emb_type, at::Tensor emb_dir,
+                            at::Tensor w1_pair, c10::optional<at::Tensor> b1_, at::Tensor w2_pair,
+                            c10::optional<at::Tensor> b2_, at::Tensor w2t_pair, at::Tensor w1t_pair, int64_t hidden,
+                            int64_t out_features, int64_t stream) {
+    at::Tensor b1 = b1_.value_or(at::Tensor()), b2 = b2_.value_or(at::Tensor());
+    TORCH_CHECK(g_lib.handle, "gconv_adapter_amd: library not loaded");
+    TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.dim() == 2,
+                "gconv_adapter_amd.MolecularGINConv takes [N, d] fp32 node features on a HIP device");
+    TORCH_CHECK(fwd_csr != 0 && bwd_csr != 0 && arena.defined(), "gin_frozen_layer: no graph plan");
+    if (!x.is_contiguous()) x = x.contiguous();
+    const int32_t n = static_cast<int32_t>(x.size(0)), d = static_cast<int32_t>(x.size(1));
+    const gconv_csr_t fwd = *reinterpret_cast<const gconv_csr_t*>(fwd_csr);
+    void* st = reinterpret_cast<void*>(stream);
+    at::Tensor a2 = pair_buffer(x, n, d);
+    check(g_lib.gin_agg_pair(&fwd, x.data_ptr<float>(), static_cast<const int32_t*>(counts.data_ptr()), emb_type.data_ptr<float>(),
+                             emb_dir.data_ptr<float>(), a2.data_ptr(), d, st),
+          "gin_aggregate_f16x2");
+    at::Tensor h2 = pair_buffer(x, n, hidden);
+    check(g_lib.pair_gemm(a2.data_ptr(), w1_pair.data_ptr(), fptr(b1), nullptr, nullptr, h2.data_ptr(), n, d,
+                          static_cast<int32_t>(hidden), 1, st),
+          "mlp_gemm_f16x2");
+    at::Tensor y = at::empty({n, out_features}, x.options());
+    check(g_lib.pair_gemm(h2.data_ptr(), w2_pair.data_ptr(), fptr(b2), nullptr, y.data_ptr<float>(), nullptr, n,
+                          static_cast<int32_t>(hidden), static_cast<int32_t>(out_features), 0, st),
+          "mlp_gemm_f16x2");
+    ctx->save_for_backward({h2, arena, w2t_pair, w1t_pair});
+    ctx->saved_data["bwd_csr"] = std::string(reinterpret_cast<const char*>(bwd_csr), sizeof(gconv_csr_t));
+    ctx->saved_data["dims"] = std::vector<int64_t>{n, d, hidden, out_features};
+    ctx->saved_data["stream"] = stream;
+    return y;
+  }
+
+  static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx,
+                                                 torch::autograd::variable_list grads) {
+    torch::autograd::variable_list out(16);
+    if (!ctx->needs_input_grad(0)) return out;
+    auto sv = ctx->get_saved_variables();
+    at::Tensor h2 = sv[0], w2t = sv[2], w1t = sv[3];
+    at::Tensor gy = grads[0];
+    if (!gy.is_contiguous()) gy = gy.contiguous();
+    const auto dims = ctx->saved_data["dims"].toIntVector();
+    const int32_t n = static_cast<int32_t>(dims[0]), d = static_cast<int32_t>(dims[1]),
+                  hidden = static_cast<int32_t>(dims[2]), outf = static_cast<int32_t>(dims[3]);
+    gconv_csr_t bwd;
+    const std::string& raw = ctx->saved_data["bwd_csr"].toStringRef();
+    std::memcpy(&bwd, raw.data(), sizeof(bwd));
+    void* st = reinterpret_cast<void*>(ctx->saved_data["stream"].toInt());
+    at::Tensor g2 = pair_buffer(gy, n, outf);
+    check(g_lib.split_rows(gy.data_ptr<float>(), n, outf, g2.data_ptr(), st), "mlp_split_rows_f16x2");
+    at::Tensor gh2 = pair_buffer(gy, n, hidden);
+    check(g_lib.pair_gemm(g2.data_ptr(), w2t.data_ptr(), nullptr, h2.data_ptr(), nullptr, gh2.data_ptr(), n, outf,
+                          hidden, 2, st),
+          "mlp_gemm_f16x2");
+    at::Tensor ga = at::empty({n, d}, gy.options());
+    check(g_lib.pair_gemm(gh2.data_ptr(), w1t.data_ptr(), nullptr, nullptr, ga.data_ptr<float>(), nullptr, n, hidden,
+                          d, 0, st),
+          "mlp_gemm_f16x2");
+    at::Tensor gx = at::empty({n, d}, gy.options());
+    check(g_lib.gin_agg(&bwd, ga.data_ptr<float>(), nullptr, nullptr, nullptr, gx.data_ptr<float>(), d, st),
+          "gin_aggregate");
+    out[0] = gx;
+    return out;
+  }
+};
+
+at::Tensor gin_frozen_layer(at::Tensor x, at::Tensor arena, int64_t fwd_csr, int64_t bwd_csr, at::Tensor counts,
+                            at::Tensor emb_type, at::Tensor emb_dir, at::Tensor w1_pair, c10::optional<at::Tensor> b1,
+                            at::Tensor w2_pair, c10::optional<at::Tensor> b2, at::Tensor w2t_pair,
+                            at::Tensor w1t_pair, int64_t hidden, int64_t out_features, int64_t stream) {
+  return GinFrozenLayerFn::apply(std::move(x), std::move(arena), fwd_csr, bwd_csr, std::move(counts),
+                                 std::move(emb_type), std::move(emb_dir), std::move(w1_pair), std::move(b1),
+                                 std::move(w2_pair), std::move(b2), std::move(w2t_pair), std::move(w1t_pair), hidden,
+                                 out_features, stream);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------
@@ -1045,4 +1229,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("plan_submit", &plan_submit);
   m.def("plan_take", &plan_take);
   m.def("layer_norm_scale", &layer_norm_scale);
+  m.def("batch_norm", &batch_norm);
+  m.def("gin_frozen_layer", &gin_frozen_layer);
 }

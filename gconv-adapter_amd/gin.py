@@ -37,7 +37,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, _torch_ext
 from .functional import _require_hip_f32, _stream
 from .graph import GraphPlan, get_plan
 
@@ -405,8 +405,11 @@ class MolecularGINConv(nn.Module):
         state["_mlp_pair"] = [_PairWeights() for _ in range(4)]
         return state
 
-    def _mlp_is_frozen(self) -> bool:
-        return not any(p.requires_grad for p in self.mlp.parameters())
+    def _mlp_is_frozen(self) -> bool:   # (asked every forward: no generator over .parameters())
+        l1, l2 = self.mlp[0], self.mlp[2]
+        return not (l1.weight.requires_grad or l2.weight.requires_grad
+                    or (l1.bias is not None and l1.bias.requires_grad)
+                    or (l2.bias is not None and l2.bias.requires_grad))
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_attr: torch.Tensor) -> torch.Tensor:
         if not x.is_cuda:
@@ -419,8 +422,22 @@ class MolecularGINConv(nn.Module):
         tables_frozen = not (self.edge_embedding_type.weight.requires_grad
                              or self.edge_embedding_direction.weight.requires_grad)
         if native_mlp and tables_frozen and not MLP_BF16X3:
-            # every parameter frozen (the adapter recipe, gnn.py:230-241): ONE node for the whole layer
-            return GinFrozenLayerFunction.apply(x, plan, counts, self)
+            # every parameter frozen (the adapter recipe, gnn.py:230-241): ONE node for the whole layer — in C++
+            # when the binding is built (csrc/torch_binding.cpp GinFrozenLayerFn: one host call forward, none
+            # from Python backward), else the Python node; the same C ABI calls in the same order
+            ext = _torch_ext.get()
+            if ext is None:
+                return GinFrozenLayerFunction.apply(x, plan, counts, self)
+            if x.dim() != 2 or n != plan.num_nodes:
+                raise RuntimeError(f"x must be [{plan.num_nodes}, d], got {tuple(x.shape)}")
+            _on_device(x)
+            l1, l2, pw = self.mlp[0], self.mlp[2], self._mlp_pair
+            return ext.gin_frozen_layer(x, plan.arena, plan.fwd.addr, plan.bwd.addr, counts,
+                                        self.edge_embedding_type.weight, self.edge_embedding_direction.weight,
+                                        pw[0].get(l1.weight, l1.bias, False), l1.bias,
+                                        pw[1].get(l2.weight, l2.bias, False), l2.bias,
+                                        pw[2].get(l2.weight, None, True), pw[3].get(l1.weight, None, True),
+                                        l1.out_features, l2.out_features, _stream(x.device.index))
         agg = GinAggregateFunction.apply(x, self.edge_embedding_type.weight, self.edge_embedding_direction.weight,
                                          plan, counts)
         # frozen MLP: the MFMA kernels, input gradient only; a backbone that trains its MLP keeps nn.Linear

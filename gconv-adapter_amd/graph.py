@@ -43,6 +43,7 @@ class CsrView:
         # training loop that builds a plan per batch would keep allocating fresh arenas
         self._plan, self.struct = weakref.proxy(plan), struct
         self.nnz, self.n_long, self.n_seg = struct.nnz, struct.n_long, struct.n_seg
+        self.addr = C.addressof(struct)   # (the gconv_csr_t inside the plan's struct: for the C++ binding)
 
     def ref(self):
         return C.byref(self.struct)

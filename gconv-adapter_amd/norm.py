@@ -23,7 +23,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, _torch_ext
 from .functional import _ptr, _require_hip_f32, _stream
 
 
@@ -255,4 +255,12 @@ class BatchNorm1d(nn.BatchNorm1d):
         rv = self.running_var if self.training and self.track_running_stats else None
         if synced:
             return SyncBatchNormFunction.apply(x, gamma, beta, rm, rv, factor, self.eps, self.fused_relu, group)
-        return BatchNormFunction.apply(x, gamma, beta, rm, rv, factor, self.eps, self.fused_relu)
+        ext = _torch_ext.get()
+        if ext is None:
+            return BatchNormFunction.apply(x, gamma, beta, rm, rv, factor, self.eps, self.fused_relu)
+        # the same node in C++ (csrc/torch_binding.cpp BatchNormFn): one host call forward, none from Python backward
+        if x.shape[0] < 2:
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
+        if x.device.index != torch.cuda.current_device():
+            torch.cuda.set_device(x.device)
+        return ext.batch_norm(x, gamma, beta, rm, rv, factor, self.eps, self.fused_relu, _stream(x.device.index))

@@ -288,6 +288,38 @@ def test_gin_mlp_f16x2_scaling_holds_over_the_fp32_range(dev, case):
 
 
 @pytest.mark.gpu
+def test_frozen_layer_cpp_node_equals_the_python_node(dev):
+    """The frozen layer's autograd node exists twice — csrc/torch_binding.cpp GinFrozenLayerFn (what the module
+    uses when the binding is built) and gin.GinFrozenLayerFunction (ctypes) — around the same C ABI calls in
+    the same order: output and input gradient agree bit for bit, also when the Python plan object is gone
+    before the backward pass (the C++ node keeps its own copy of the CSR struct and the arena)."""
+    if ga._torch_ext.get() is None:
+        pytest.skip("the C++ binding is not built (or GCONV_PY_BINDING is set)")
+    batch, cfg = ga.synth.make_workload("hiv", graphs=64)
+    d, n = cfg["d"], batch.num_nodes
+    gen = torch.Generator().manual_seed(3)
+    e = batch.edge_index.shape[1]
+    ea = torch.stack([torch.randint(0, 4, (e,), generator=gen), torch.randint(0, 3, (e,), generator=gen)], 1).to(dev)
+    ei = batch.edge_index.to(dev)
+    layer = ga.MolecularGINConv(d).to(dev)
+    for p in layer.parameters():
+        p.requires_grad_(False)
+    go = torch.randn(n, d, generator=gen).to(dev)
+    x1 = batch.x.to(dev).requires_grad_(True)
+    y1 = layer(x1, ei, ea)                                    # the C++ node
+    ga.PLAN_CACHE.clear()
+    y1.backward(go)
+    x2 = batch.x.to(dev).requires_grad_(True)
+    plan = ga.get_plan(ei, n, False)
+    counts = ga.gin.edge_code_counts(ei, ea, n, True)
+    y2 = ga.gin.GinFrozenLayerFunction.apply(x2, plan, counts, layer)
+    y2.backward(go)
+    assert torch.equal(y1, y2) and torch.equal(x1.grad, x2.grad)
+    with torch.no_grad():                                     # no graph: same numbers
+        assert torch.equal(layer(x1.detach(), ei, ea), y1)
+
+
+@pytest.mark.gpu
 def test_gin_aggregate_alone_is_tight_and_deterministic(dev):
     """Without the MLP the HIP kernel is compared at the adapter's tolerance (1e-5) and bit-for-bit
     against itself; the code counts are exact integers."""

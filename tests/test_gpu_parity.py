@@ -983,6 +983,34 @@ def test_batch_norm_matches_torch_fp64(dev, n, d, relu, shift):
     assert torch.equal(a, b)                      # bitwise repeatable
 
 
+@pytest.mark.parametrize("relu", [False, True])
+def test_batch_norm_cpp_node_equals_the_python_node(dev, relu):
+    """BatchNorm1d's autograd node exists twice — csrc/torch_binding.cpp BatchNormFn (one host call; what the
+    module uses when the binding is built) and norm.BatchNormFunction (ctypes) — around the same C ABI calls:
+    outputs, running statistics and all three gradients agree bit for bit."""
+    if ga._torch_ext.get() is None:
+        pytest.skip("the C++ binding is not built (or GCONV_PY_BINDING is set)")
+    g = torch.Generator().manual_seed(5)
+    n, d = 777, 300
+    x0 = (torch.randn(n, d, generator=g) * 2 + 1).to(dev)
+    go = torch.randn(n, d, generator=g).to(dev)
+    res = []
+    for node in ("cpp", "python"):
+        m = ga.BatchNorm1d(d, fused_relu=relu).to(dev).train()
+        with torch.no_grad():
+            m.weight.copy_(torch.linspace(0.5, 1.5, d)); m.bias.copy_(torch.linspace(-1, 1, d))
+        x = x0.clone().requires_grad_(True)
+        if node == "cpp":
+            y = m(x)
+        else:
+            y = ga.norm.BatchNormFunction.apply(x, m.weight, m.bias, m.running_mean, m.running_var, m.momentum,
+                                                m.eps, relu)
+        y.backward(go)
+        res.append((y.detach(), x.grad, m.weight.grad, m.bias.grad, m.running_mean.clone(), m.running_var.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 def test_batch_norm_other_inputs_take_torchs_path(dev):
     m = ga.BatchNorm1d(6).to(dev)                 # d % 4 != 0 -> nn.BatchNorm1d's own kernels
     x = torch.randn(10, 6, device=dev)
