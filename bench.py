@@ -643,16 +643,19 @@ class _FinetuneModel(torch.nn.Module):
             h = bn(gin(h, edge_index, edge_attr))
             if i != last and not getattr(bn, "fused_relu", False):
                 h = torch.relu(h)
-        pooled = torch.zeros(num_graphs, h.shape[1], device=h.device).index_add_(0, batch, h) * inv_count
+        if os.environ.get("GCONV_TORCH_READOUT"):   # A/B knob: torch's scatter instead of csrc/readout.hip
+            pooled = torch.zeros(num_graphs, h.shape[1], device=h.device).index_add_(0, batch, h) * inv_count
+        else:
+            pooled = ga.global_mean_pool(h, batch, num_graphs)          # `self.pool(h, batch)`, gnn.py:187-195
         return self.graph_pred_linear(pooled)
 
 
 def measure_finetune_step(device, normalize: bool, name: str = "hiv", steps: int = 60) -> dict:
     """The whole fine-tune step of the reference's loop body (`scripts/finetune_inductive_learning.py:43-67`)
     on one 512-molecule batch: model forward (5 x adapter -> frozen GIN -> BatchNorm -> ReLU, mean pool,
-    head), NaN-masked BCE in fp64, backward, FusedAdam — the adapters in their surroundings. The frozen
-    layers' MLP GEMMs (rocBLAS fp32, ~0.3 ms per layer) and the host-side dispatch of the ~150 torch ops
-    around them dominate; reported next to the headline, never as `value`."""
+    head), NaN-masked BCE in fp64, backward, FusedAdam — the adapters in their surroundings, every piece but
+    the head's Linear on this package's kernels (~75 launches per step). Reported next to the headline,
+    never as `value`."""
     batch, cfg = ga.synth.make_workload(name)
     d, r, n, e = cfg["d"], cfg["r"], batch.num_nodes, batch.edge_index.shape[1]
     g = torch.Generator().manual_seed(0)
@@ -673,11 +676,16 @@ def measure_finetune_step(device, normalize: bool, name: str = "hiv", steps: int
     opt = ga.FusedAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3)
     x, ei = batch.x.to(device), batch.edge_index.to(device)
 
+    torch_loss = bool(os.environ.get("GCONV_TORCH_READOUT"))
+
     def step():
         opt.zero_grad(set_to_none=True)
         out = model(x, ei, ea, node_graph, batch.num_graphs, inv_count)
-        loss = torch.nn.functional.binary_cross_entropy_with_logits(out.view(-1)[valid_idx].double(), target,
-                                                                    reduction="none").sum() / count
+        if torch_loss:
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(out.view(-1)[valid_idx].double(), target,
+                                                                        reduction="none").sum() / count
+        else:
+            loss = ga.masked_loss(out, y, "bce")     # the loop's NaN-masked fp64 loss (:55-63), one launch
         loss.backward()
         opt.step()
 
@@ -686,22 +694,6 @@ def measure_finetune_step(device, normalize: bool, name: str = "hiv", steps: int
     ms = best_event_time_ms(step, steps, reps=3, warmup=20)
     res = {f"{name}_finetune_step_ms": round(ms, 4),
            f"{name}_finetune_step_graphs_per_s": round(batch.num_graphs / (ms * 1e-3), 1)}
-    # The frozen layers' MLP GEMMs are library calls (rocBLAS): PyTorch's TunableOp picks their kernel
-    # per shape (60-69 -> 82-92 TFLOP/s fp32 at [13104, 300] x [300, 600]). Scoped to THIS measurement
-    # (round 2 switched it on for the whole process), tuned during a longer warm-up, reported beside
-    # the default — the gain depends on the box (round 2: 1.90 ms on one, no gain on the driver's).
-    try:
-        import torch.cuda.tunable as tunable
-        tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "gconv_bench_tunableop.csv"))
-        tunable.set_max_tuning_duration(100)
-        tunable.enable(True)
-        tunable.tuning_enable(True)
-        tms = best_event_time_ms(step, steps, reps=2, warmup=40)
-        tunable.tuning_enable(False)
-        tunable.enable(False)
-        res[f"{name}_finetune_step_tunableop_ms"] = round(tms, 4)
-    except Exception as exc:   # pragma: no cover - API differences between torch builds
-        res[f"{name}_finetune_step_tunableop_ms"] = f"unavailable: {type(exc).__name__}"
     ga.PLAN_CACHE.clear()
     return res
 

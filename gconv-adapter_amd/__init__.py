@@ -8,13 +8,14 @@ from .adapter import GConvAdapter, GCNConvParams
 from .functional import GConvAdapterFunction, gconv_adapter, spmm, gemm_down, gemm_up_fused
 from .graph import GraphPlan, PlanCache, PLAN_CACHE, get_plan, prefetch_plan
 from .hydra_compat import instantiate, load_finetune_config
-from . import synth, dist, optim, data, partition, gin, norm, relbias, _lib, _torch_ext
+from . import synth, dist, optim, data, partition, gin, norm, relbias, readout, _lib, _torch_ext
 from .data import MoleculeStore
 from .optim import FusedAdam
 from .partition import RowSlabGConvAdapter, RowSlabs
 from .gin import MolecularGINConv
 from .norm import BatchNorm1d, sync_batch_norm
 from .relbias import add_conv_relational_bias
+from .readout import global_mean_pool, global_add_pool, masked_loss
 
 
 
@@ -35,5 +36,5 @@ __all__ = [
     "gemm_down", "gemm_up_fused", "GraphPlan", "PlanCache", "PLAN_CACHE", "get_plan", "prefetch_plan",
     "instantiate", "load_finetune_config", "synth", "dist", "optim", "FusedAdam", "data", "MoleculeStore",
     "partition", "RowSlabGConvAdapter", "RowSlabs", "gin", "MolecularGINConv", "norm", "BatchNorm1d", "sync_batch_norm",
-    "relbias", "add_conv_relational_bias", "register_ops",
+    "relbias", "add_conv_relational_bias", "register_ops", "readout", "global_mean_pool", "global_add_pool", "masked_loss",
 ]

@@ -95,7 +95,7 @@ class PendingFinalize(C.Structure):
 
 FINALIZE_BATCH = 5
 BUILD_BACKGROUND = 1   # GCONV_BUILD_BACKGROUND
-ABI_VERSION = 8   # GCONV_ABI_VERSION of include/gconv_adapter.h this binding was written against
+ABI_VERSION = 9   # GCONV_ABI_VERSION of include/gconv_adapter.h this binding was written against
 
 
 class AdapterParams(C.Structure):
@@ -175,6 +175,8 @@ SIGNATURES = {
     "gconv_batch_norm_workspace_bytes": (_sz, [_i32, _i32]),
     "gconv_batch_norm_fwd_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _i32, _vp, _vp, _vp,
                                         _i32, _i32, _vp, _sz, _vp]),
+    "gconv_batch_norm_fwd_tracked_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _i32, _vp, _vp,
+                                                _vp, _i32, _i32, _vp, _sz, _vp]),
     "gconv_batch_norm_apply_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp]),
     "gconv_batch_norm_bwd_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _sz, _vp]),
     "gconv_batch_norm_sync_words": (_sz, [_i32]),
@@ -183,6 +185,9 @@ SIGNATURES = {
                                              _i32, _i32, _vp, _i32, _vp]),
     "gconv_batch_norm_bwd_local_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _sz, _vp]),
     "gconv_batch_norm_bwd_dx_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "gconv_segment_pool_f32": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "gconv_segment_pool_bwd_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "gconv_masked_loss_f64": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "gconv_adam_step_f32": (_i32, [_vp, _vp, _vp, _vp, C.c_int64, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_float, C.c_int64, _vp]),
 }

@@ -376,7 +376,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float eps, float momentum,
                                                           float* __restrict__ out0, float* __restrict__ out1,
                                                           float* __restrict__ running_mean,
-                                                          float* __restrict__ running_var) {
+                                                          float* __restrict__ running_var,
+                                                          long long* __restrict__ tracked = nullptr) {
   // 4 columns x 64 row groups per block: a thread adds nparts / 64 partial rows with all its loads
   // in flight at once, then a fixed-order tree over the row groups. (Round 1: 16 columns x 16 row
   // groups — 19 blocks for d = 300, each thread walking 32 rows two at a time: 7-8 us of dependent
@@ -425,6 +426,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     const float mu = x_row0[c] + m1;
     out0[c] = mu;
     out1[c] = rsqrtf(var + eps);
+    if (tracked && c == 0) *tracked += 1;   // nn.BatchNorm1d's num_batches_tracked, without a launch of its own
     if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
     if (running_var) {
       const float unbiased = n > 1 ? var * static_cast<float>(n) / static_cast<float>(n - 1) : var;
@@ -579,6 +581,18 @@ extern "C" gconv_status_t gconv_batch_norm_fwd_f32(const float* x, const float* 
                                                    float* save_mean, float* save_rstd,
                                                    int32_t num_nodes, int32_t hidden, void* workspace,
                                                    size_t workspace_bytes, gconv_stream_t stream_) {
+  return gconv_batch_norm_fwd_tracked_f32(x, gamma, beta, running_mean, running_var, nullptr, momentum, eps, relu, y,
+                                          save_mean, save_rstd, num_nodes, hidden, workspace, workspace_bytes,
+                                          stream_);
+}
+
+extern "C" gconv_status_t gconv_batch_norm_fwd_tracked_f32(const float* x, const float* gamma, const float* beta,
+                                                           float* running_mean, float* running_var,
+                                                           int64_t* num_batches_tracked, float momentum, float eps,
+                                                           int32_t relu, float* y, float* save_mean,
+                                                           float* save_rstd, int32_t num_nodes, int32_t hidden,
+                                                           void* workspace, size_t workspace_bytes,
+                                                           gconv_stream_t stream_) {
   const gconv_status_t st = ln_check(num_nodes, hidden);
   if (st != GCONV_OK) return st;
   if (num_nodes < 2) return GCONV_E_INVALID_ARG;   // batch statistics need more than one row
@@ -594,7 +608,8 @@ extern "C" gconv_status_t gconv_batch_norm_fwd_f32(const float* x, const float* 
       x, nullptr, nullptr, nullptr, nullptr, ws.part, num_nodes, hidden)))
   GCONV_LAUNCH_CHECK();
   bn_finalize_kernel<BN_SUMS_STATS><<<ceil_div(hidden, kBnFinCl), 256, 0, stream>>>(
-      ws.part, grid, x, num_nodes, hidden, eps, momentum, save_mean, save_rstd, running_mean, running_var);
+      ws.part, grid, x, num_nodes, hidden, eps, momentum, save_mean, save_rstd, running_mean, running_var,
+      reinterpret_cast<long long*>(num_batches_tracked));
   GCONV_LAUNCH_CHECK();
   GCONV_BN_DISPATCH((bn_apply_kernel<NP><<<ceil_div(num_nodes, 4), 256, 0, stream>>>(
       x, save_mean, save_rstd, gamma, beta, y, num_nodes, hidden, relu)))

@@ -62,8 +62,9 @@ using spmm_fn_t = gconv_status_t (*)(const gconv_csr_t*, const float*, const flo
                                      int32_t, uint32_t, void*, size_t, gconv_stream_t);
 
 using bn_bytes_fn_t = size_t (*)(int32_t, int32_t);
-using bn_fwd_fn_t = gconv_status_t (*)(const float*, const float*, const float*, float*, float*, float, float, int32_t,
-                                       float*, float*, float*, int32_t, int32_t, void*, size_t, gconv_stream_t);
+using bn_fwd_fn_t = gconv_status_t (*)(const float*, const float*, const float*, float*, float*, int64_t*, float, float,
+                                       int32_t, float*, float*, float*, int32_t, int32_t, void*, size_t,
+                                       gconv_stream_t);
 using bn_bwd_fn_t = gconv_status_t (*)(const float*, const float*, const float*, const float*, const float*,
                                        const float*, float*, float*, float*, int32_t, int32_t, void*, size_t,
                                        gconv_stream_t);
@@ -125,7 +126,7 @@ void load_library(const std::string& path) {
   g_lib.spmm_ws = reinterpret_cast<spmm_ws_fn_t>(dlsym(h, "gconv_spmm_workspace_bytes"));
   g_lib.spmm = reinterpret_cast<spmm_fn_t>(dlsym(h, "gconv_spmm_csr_f32"));
   g_lib.bn_bytes = reinterpret_cast<bn_bytes_fn_t>(dlsym(h, "gconv_batch_norm_workspace_bytes"));
-  g_lib.bn_fwd = reinterpret_cast<bn_fwd_fn_t>(dlsym(h, "gconv_batch_norm_fwd_f32"));
+  g_lib.bn_fwd = reinterpret_cast<bn_fwd_fn_t>(dlsym(h, "gconv_batch_norm_fwd_tracked_f32"));
   g_lib.bn_bwd = reinterpret_cast<bn_bwd_fn_t>(dlsym(h, "gconv_batch_norm_bwd_f32"));
   g_lib.pair_bytes = reinterpret_cast<pair_bytes_fn_t>(dlsym(h, "gconv_mlp_rows_pair_bytes"));
   g_lib.split_rows = reinterpret_cast<split_rows_fn_t>(dlsym(h, "gconv_mlp_split_rows_f16x2"));
@@ -831,9 +832,13 @@ at::Tensor layer_norm_scale(at::Tensor z, c10::optional<at::Tensor> gamma, c10::
 struct BatchNormFn : public torch::autograd::Function<BatchNormFn> {
   static at::Tensor forward(torch::autograd::AutogradContext* ctx, at::Tensor x, c10::optional<at::Tensor> gamma_,
                             c10::optional<at::Tensor> beta_, c10::optional<at::Tensor> rmean_,
-                            c10::optional<at::Tensor> rvar_, double momentum, double eps, bool relu, int64_t stream) {
+                            c10::optional<at::Tensor> rvar_, c10::optional<at::Tensor> tracked_, double momentum,
+                            double eps, bool relu, int64_t stream) {
     at::Tensor gamma = gamma_.value_or(at::Tensor()), beta = beta_.value_or(at::Tensor()),
-               rmean = rmean_.value_or(at::Tensor()), rvar = rvar_.value_or(at::Tensor());
+               rmean = rmean_.value_or(at::Tensor()), rvar = rvar_.value_or(at::Tensor()),
+               tracked = tracked_.value_or(at::Tensor());   // num_batches_tracked: counted by the kernel
+    TORCH_CHECK(!tracked.defined() || (tracked.is_cuda() && tracked.scalar_type() == at::kLong),
+                "gconv_adapter_amd.BatchNorm1d: num_batches_tracked must be an int64 tensor on the device");
     TORCH_CHECK(g_lib.handle, "gconv_adapter_amd: library not loaded");
     TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.dim() == 2,
                 "gconv_adapter_amd.BatchNorm1d takes [N, d] fp32 node features on a HIP device");
@@ -844,7 +849,7 @@ struct BatchNormFn : public torch::autograd::Function<BatchNormFn> {
     const size_t bytes = g_lib.bn_bytes(n, d);
     at::Tensor ws = at::empty({static_cast<int64_t>(bytes > 16 ? bytes : 16)}, x.options().dtype(at::kByte));
     check(g_lib.bn_fwd(x.data_ptr<float>(), fptr(gamma), fptr(beta), fptr_mut(rmean), fptr_mut(rvar),
-                       static_cast<float>(momentum), static_cast<float>(eps), relu ? 1 : 0, y.data_ptr<float>(),
+                       tracked.defined() ? tracked.data_ptr<int64_t>() : nullptr, static_cast<float>(momentum), static_cast<float>(eps), relu ? 1 : 0, y.data_ptr<float>(),
                        stats.data_ptr<float>(), stats.data_ptr<float>() + d, n, d, ws.data_ptr(),
                        static_cast<size_t>(ws.numel()), reinterpret_cast<void*>(stream)),
           "batch_norm_fwd");
@@ -872,15 +877,17 @@ struct BatchNormFn : public torch::autograd::Function<BatchNormFn> {
                        ws.data_ptr(), static_cast<size_t>(ws.numel()),
                        reinterpret_cast<void*>(ctx->saved_data["stream"].toInt())),
           "batch_norm_bwd");
-    return {gx, gg, gb, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+    return {gx, gg, gb, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
+            at::Tensor()};
   }
 };
 
 at::Tensor batch_norm(at::Tensor x, c10::optional<at::Tensor> gamma, c10::optional<at::Tensor> beta,
                       c10::optional<at::Tensor> running_mean, c10::optional<at::Tensor> running_var,
-                      double momentum, double eps, bool relu, int64_t stream) {
+                      c10::optional<at::Tensor> num_batches_tracked, double momentum, double eps, bool relu,
+                      int64_t stream) {
   return BatchNormFn::apply(std::move(x), std::move(gamma), std::move(beta), std::move(running_mean),
-                            std::move(running_var), momentum, eps, relu, stream);
+                            std::move(running_var), std::move(num_batches_tracked), momentum, eps, relu, stream);
 }
 
 // The whole frozen GIN layer (/root/reference/src/layers/inductive/gin_conv.py:38-85 with every parameter

@@ -247,15 +247,21 @@ class BatchNorm1d(nn.BatchNorm1d):
         if not use_batch_stats:
             return batch_norm_eval(x, self.running_mean, self.running_var, gamma, beta, self.eps,
                                    self.fused_relu)
+        ext = None if synced else _torch_ext.get()
+        counts = self.training and self.track_running_stats and self.num_batches_tracked is not None
+        # num_batches_tracked += 1: by the C++ node's reduction launch when it can be (a launch of torch's per
+        # layer otherwise); momentum=None (cumulative average) needs the count on the host first
+        in_kernel = (counts and ext is not None and self.momentum is not None and x.shape[0] >= 2
+                     and self.num_batches_tracked.is_cuda)
         factor = 0.0
-        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(1)
+        if counts:
+            if not in_kernel:
+                self.num_batches_tracked.add_(1)
             factor = (1.0 / float(self.num_batches_tracked)) if self.momentum is None else self.momentum
         rm = self.running_mean if self.training and self.track_running_stats else None
         rv = self.running_var if self.training and self.track_running_stats else None
         if synced:
             return SyncBatchNormFunction.apply(x, gamma, beta, rm, rv, factor, self.eps, self.fused_relu, group)
-        ext = _torch_ext.get()
         if ext is None:
             return BatchNormFunction.apply(x, gamma, beta, rm, rv, factor, self.eps, self.fused_relu)
         # the same node in C++ (csrc/torch_binding.cpp BatchNormFn): one host call forward, none from Python backward
@@ -263,4 +269,5 @@ class BatchNorm1d(nn.BatchNorm1d):
             raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
         if x.device.index != torch.cuda.current_device():
             torch.cuda.set_device(x.device)
-        return ext.batch_norm(x, gamma, beta, rm, rv, factor, self.eps, self.fused_relu, _stream(x.device.index))
+        return ext.batch_norm(x, gamma, beta, rm, rv, self.num_batches_tracked if in_kernel else None, factor,
+                              self.eps, self.fused_relu, _stream(x.device.index))

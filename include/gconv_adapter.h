@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GCONV_ABI_VERSION 8
+#define GCONV_ABI_VERSION 9
 
 typedef int32_t gconv_status_t;
 typedef void*   gconv_stream_t; /* hipStream_t */
@@ -380,6 +380,29 @@ gconv_status_t gconv_adapter_slab_bwd_f32(const gconv_graph_t* graph,
                                           float* grad_scalar, void* workspace,
                                           size_t workspace_bytes, gconv_stream_t stream);
 
+/* ---- the end of the fine-tune step's forward pass (ABI 9) ----------------------
+ * replaces: `self.pool(h, batch)` with PyG's global_mean_pool / global_add_pool
+ *   (`src/models/inductive/gnn.py:187-195`) and the loop's NaN-masked loss in fp64
+ *   (`scripts/finetune_inductive_learning.py:55-63`: `criterion(valid_output.double(), valid_target)` summed
+ *   and divided by the number of valid targets; BCEWithLogitsLoss or MSELoss with reduction='none') —
+ *   ~25 small torch launches per step.
+ * gconv_segment_pool_f32: out[g, :] = sum (mean != 0: mean) of x[i, :] over the nodes with batch[i] == g,
+ *   g in [0, num_graphs); `batch` int64, SORTED ascending (PyG's collation order); rows are added in node
+ *   order — no atomics; counts[g] (nullable) = the graph's node count; an empty graph gives zeros.
+ * gconv_segment_pool_bwd_f32: grad_x[i, :] = grad_out[batch[i], :] (/ counts[batch[i]] for the mean).
+ * gconv_masked_loss_f64: logits fp32 [count], target fp64 [count] with NaN = no label; kind 0 = BCE with
+ *   logits, 1 = squared error, both in fp64; loss_and_count[0] = sum over the labelled / their number (0 if
+ *   none), [1] = that number; grad_logits[i] = d loss / d logits[i] (fp32; 0 where there is no label).
+ * hidden a multiple of 4, <= 1024.                                                                     */
+gconv_status_t gconv_segment_pool_f32(const float* x, const int64_t* batch, int32_t num_nodes, int32_t hidden,
+                                      int32_t num_graphs, int32_t mean, float* out, int32_t* counts,
+                                      gconv_stream_t stream);
+gconv_status_t gconv_segment_pool_bwd_f32(const float* grad_out, const int64_t* batch, const int32_t* counts,
+                                          int32_t num_nodes, int32_t hidden, int32_t num_graphs, int32_t mean,
+                                          float* grad_x, gconv_stream_t stream);
+gconv_status_t gconv_masked_loss_f64(const float* logits, const double* target, int64_t count, int32_t kind,
+                                     double* loss_and_count, float* grad_logits, gconv_stream_t stream);
+
 /* ---- next to the path: the optimizer step over the trainable set -------------
  * replaces: `optim.Adam(...)` + `optimizer.step()`
  *   (`scripts/finetune_inductive_learning.py:379,67`, `scripts/finetune_transductive_learning.py:205,230`)
@@ -491,6 +514,14 @@ gconv_status_t gconv_batch_norm_fwd_f32(const float* x, const float* gamma, cons
                                         float* save_rstd, int32_t num_nodes, int32_t hidden,
                                         void* workspace, size_t workspace_bytes,
                                         gconv_stream_t stream);
+/* ABI 9: the same forward that also counts the batch (`num_batches_tracked += 1`, nn.BatchNorm1d's int64
+ * buffer; NULL = do not count) — inside its reduction launch instead of a launch of torch's.          */
+gconv_status_t gconv_batch_norm_fwd_tracked_f32(const float* x, const float* gamma, const float* beta,
+                                                float* running_mean, float* running_var,
+                                                int64_t* num_batches_tracked, float momentum, float eps,
+                                                int32_t relu, float* y, float* save_mean, float* save_rstd,
+                                                int32_t num_nodes, int32_t hidden, void* workspace,
+                                                size_t workspace_bytes, gconv_stream_t stream);
 gconv_status_t gconv_batch_norm_apply_f32(const float* x, const float* mean, const float* rstd,
                                           const float* gamma, const float* beta, int32_t relu,
                                           float* y, int32_t num_nodes, int32_t hidden,

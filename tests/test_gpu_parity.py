@@ -1007,6 +1007,9 @@ def test_batch_norm_cpp_node_equals_the_python_node(dev, relu):
                                                 m.eps, relu)
         y.backward(go)
         res.append((y.detach(), x.grad, m.weight.grad, m.bias.grad, m.running_mean.clone(), m.running_var.clone()))
+        if node == "cpp":   # num_batches_tracked is counted by the kernel (no launch of its own)
+            m(x0); m.eval(); m(x0)
+            assert int(m.num_batches_tracked) == 2 and m.num_batches_tracked.dtype == torch.int64
     for a, b in zip(*res):
         assert torch.equal(a, b)
 

@@ -38,7 +38,7 @@ for it in range(steps + 20):
     t0 = time.perf_counter(); opt.zero_grad(set_to_none=True)
     t1 = time.perf_counter(); out = model(x, ei, ea, node_graph, batch.num_graphs, inv_count)
     t2 = time.perf_counter()
-    loss = torch.nn.functional.binary_cross_entropy_with_logits(out.view(-1).double(), target, reduction="none").sum() / 512
+    loss = ga.masked_loss(out, target.view(out.shape), "bce")
     t3 = time.perf_counter(); loss.backward()
     t4 = time.perf_counter(); opt.step()
     t5 = time.perf_counter()
