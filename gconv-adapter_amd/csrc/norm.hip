@@ -321,24 +321,45 @@ __global__ __launch_bounds__(256) void bn_colsums_kernel(const float* __restrict
     a[p] = f32x4{0.f, 0.f, 0.f, 0.f};
     b[p] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  for (int row = blockIdx.x * 4 + wave; row < n; row += gridDim.x * 4) {   // wave-uniform
+  // a wave's rows are added in row order; kU of them are requested before the first is added (a 512-molecule
+  // batch gives a wave 6 - 7 rows: that many dependent round trips otherwise)
+  constexpr int kU = NP <= 2 ? 4 : 2;
+  const int stride = gridDim.x * 4;
+  const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int row = blockIdx.x * 4 + wave; row < n; row += kU * stride) {   // wave-uniform
+    f32x4 xv[kU][NP], gv[kU][NP], yv[kU][NP];
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int q = lane + 64 * p;
-      if (q < nq) {
-        const size_t off = static_cast<size_t>(row) * d + 4 * q;
-        const f32x4 xc = (ldg4(x + off) - c0[p]) * c1[p];
-        if (MODE == BN_SUMS_STATS) {
-          a[p] += xc;
-          b[p] += xc * xc;
-        } else {
-          f32x4 gv = ldg4(g + off);
-          if (y) {
-            const f32x4 yv = ldg4(y + off);
-            for (int k = 0; k < 4; ++k) gv[k] = yv[k] > 0.f ? gv[k] : 0.f;
+    for (int u = 0; u < kU; ++u) {
+      const int r = row + u * stride;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int q = lane + 64 * p;
+        const bool ok = q < nq && r < n;
+        const size_t off = static_cast<size_t>(ok ? r : 0) * d + 4 * (ok ? q : 0);
+        xv[u][p] = ok ? ldg4(x + off) : zero;
+        if (MODE != BN_SUMS_STATS) {
+          gv[u][p] = ok ? ldg4(g + off) : zero;
+          yv[u][p] = ok && y ? ldg4(y + off) : f32x4{1.f, 1.f, 1.f, 1.f};
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      if (row + u * stride >= n) break;                    // (wave-uniform)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int q = lane + 64 * p;
+        if (q < nq) {
+          const f32x4 xc = (xv[u][p] - c0[p]) * c1[p];
+          if (MODE == BN_SUMS_STATS) {
+            a[p] += xc;
+            b[p] += xc * xc;
+          } else {
+            f32x4 gg = gv[u][p];
+            for (int k = 0; k < 4; ++k) gg[k] = yv[u][p][k] > 0.f ? gg[k] : 0.f;
+            a[p] += gg;
+            b[p] += gg * xc;
           }
-          a[p] += gv;
-          b[p] += gv * xc;
         }
       }
     }

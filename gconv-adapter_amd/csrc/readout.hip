@@ -59,12 +59,23 @@ __global__ __launch_bounds__(256) void segment_pool_kernel(const float* __restri
   f32x4 a[NP];
 #pragma unroll
   for (int p = 0; p < NP; ++p) a[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int row = r0 + wave; row < r1; row += 4) {        // wave w: rows r0 + w, r0 + w + 4, ... (fixed order)
+  // wave w: rows r0 + w, r0 + w + 4, ... added in that order; kU of them are requested before the first is added
+  // (a molecule of 222 atoms would otherwise be 56 dependent round trips for its workgroup — and the kernel)
+  constexpr int kU = 8;
+  for (int row = r0 + wave; row < r1; row += 4 * kU) {
+    f32x4 v[kU][NP];
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int q = lane + 64 * p;
-      if (q < nq) a[p] += ldg4(x + static_cast<size_t>(row) * d + 4 * q);
-    }
+    for (int u = 0; u < kU; ++u)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int q = lane + 64 * p;
+        v[u][p] = q < nq && row + 4 * u < r1 ? ldg4(x + static_cast<size_t>(row + 4 * u) * d + 4 * q)
+                                            : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) a[p] += v[u][p];
   }
   if (wave > 0) {
 #pragma unroll
