@@ -652,7 +652,7 @@ class _FinetuneModel(torch.nn.Module):
 
 def measure_finetune_step(device, normalize: bool, name: str = "hiv", steps: int = 60) -> dict:
     """The whole fine-tune step of the reference's loop body (`scripts/finetune_inductive_learning.py:43-67`)
-    on one 512-molecule batch: model forward (5 x adapter -> frozen GIN -> BatchNorm -> ReLU, mean pool,
+    on one batch of the workload (512 molecules: a GPU's share at N = 8; 4096: the whole batch): model forward (5 x adapter -> frozen GIN -> BatchNorm -> ReLU, mean pool,
     head), NaN-masked BCE in fp64, backward, FusedAdam — the adapters in their surroundings, every piece but
     the head's Linear on this package's kernels (~75 launches per step). Reported next to the headline,
     never as `value`."""
@@ -1007,6 +1007,7 @@ def main() -> None:
             ga.PLAN_CACHE.clear()
             torch.cuda.empty_cache()   # the S-arxiv phases leave ~1 GB of cached blocks of odd sizes behind
             extra.update(measure_finetune_step(device, normalize))   # last: torch layers, allocator churn
+            extra.update(measure_finetune_step(device, normalize, name="hiv4096", steps=30))   # the whole batch
             extra["best_of_3_averages"] = ["arxiv_proj_*", "cora_*", "pubmed_*", "*_graph_build_wall_us",
                                            "*_no_prefetch_*", "*_finetune_step_*"]   # launch-bound extras: see best_event_time_ms
         line["extra"] = extra
