@@ -706,7 +706,10 @@ extern "C" gconv_status_t gconv_mlp_gemm_f16x2(const void* a_pair, const void* w
   // GCONV_MLP_WS=0: the tiled kernel for everything (A/B)
   static const bool ws_on = [] { const char* v = getenv("GCONV_MLP_WS"); return !(v && v[0] == '0'); }();
   const int KS = Kp / kBK, NT = KS == 10 ? 2 : 1;
-  if (ws_on && (KS == 10 || (KS == 19 && epilogue != 2)) && Mp % (64 * NT) == 0) {
+  // (its stores go through buffer descriptors with 32-bit offsets, "dropped" = an offset of 2^30 or more: outputs
+  //  of 1 GiB and beyond take the tiled kernel)
+  const bool ws_fits = static_cast<size_t>(num_rows) * (c_pair ? Mq : out_features) * 4 <= (static_cast<size_t>(1) << 30);
+  if (ws_on && ws_fits && (KS == 10 || (KS == 19 && epilogue != 2)) && Mp % (64 * NT) == 0) {
     static const int cus = [] {
       int dev = 0, n = 0;
       if (hipGetDevice(&dev) != hipSuccess ||
