@@ -567,12 +567,24 @@ gconv_status_t launch_bwd_main(const BwdMainArgs& a, hipStream_t stream) {
 //                | [2 r d + d, 2 r d + d + r) db_down | (+ 1: d(scalar) when complete)
 // block = kFinE consecutive elements x kFinS interleaved partial streams; every stream keeps
 // 4 loads in flight; streams are added in a fixed tree.
-constexpr int kFinE = 16, kFinS = 16;
+constexpr int kFinE = 32, kFinS = 8;   // (32 consecutive floats: whole 128-byte lines per stream; round 1-4a: 16 x 16,
+                                        //  two workgroups — often on two XCDs — fetched every line of the partials)
 
 __device__ __forceinline__ float strided_sum(const float* __restrict__ q, size_t stride, int first,
                                              int count) {
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int p = first;
+  // 16 partials requested before the first is added (256 persistent workgroups = 32 per stream: two round trips
+  // instead of eight); the additions keep the order of the 4-wide loop below
+  for (; p + 15 * kFinS < count; p += 16 * kFinS) {
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = q[(p + k * kFinS) * stride];
+#pragma unroll
+    for (int k = 0; k < 16; k += 4) {
+      s0 += v[k]; s1 += v[k + 1]; s2 += v[k + 2]; s3 += v[k + 3];
+    }
+  }
   for (; p + 3 * kFinS < count; p += 4 * kFinS) {
     s0 += q[p * stride]; s1 += q[(p + kFinS) * stride];
     s2 += q[(p + 2 * kFinS) * stride]; s3 += q[(p + 3 * kFinS) * stride];
