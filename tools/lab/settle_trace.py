@@ -1,0 +1,24 @@
+"""ms/step of the headline workload per chunk of 200 steps from process start (a fresh box, the driver's situation):
+    python tools/lab/settle_trace.py [seconds=12] [workload=hiv4096]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import bench
+import gconv_adapter_amd as ga
+dev = torch.device("cuda:0")
+secs = float(sys.argv[1]) if len(sys.argv) > 1 else 12.0
+name = sys.argv[2] if len(sys.argv) > 2 else "hiv4096"
+stream = bench.BatchStream(name, 0, dev, k=4, fresh=True)
+mods = list(bench.build_adapters(stream.cfg, True, dev))
+params = [p for m in mods for p in m.parameters()]
+bench.pin_host_threads()
+t0 = time.perf_counter()
+out = []
+while time.perf_counter() - t0 < secs:
+    torch.cuda.synchronize()
+    a = time.perf_counter()
+    for _ in range(200):
+        bench.adapter_step(mods, params, stream, True, None)
+    torch.cuda.synchronize()
+    out.append(((time.perf_counter() - a) / 200 * 1e3, time.perf_counter() - t0))
+print(" ".join(f"{ms:.3f}@{t:.1f}s" for ms, t in out))
