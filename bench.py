@@ -187,14 +187,20 @@ def build_adapters(cfg: dict, normalize: bool, device, cls=None) -> torch.nn.Mod
 class BatchStream:
     """K distinct collated batches resident in HBM, served round-robin: what the
     reference's DataLoader hands to the train loop. Every step builds the graph plan of its
-    batch anew (the plan is discarded after the step); the build of the NEXT batch is
+    batch anew (the plan is discarded after the step); the build of the batch two steps ahead is
     started before the current step's adapters run, so it overlaps them — the role the
     DataLoader's prefetching workers play for collation in the reference."""
 
     def __init__(self, name: str, rank: int, device, k: int, fresh: bool, prefetch: bool = True,
-                 shard=None):
+                 shard=None, depth: int = 2):
         self.fresh = fresh
         self.prefetch = prefetch   # False: the plan is built in-stream by the step's first adapter
+        # plans are built `depth` batches ahead — torch's DataLoader keeps prefetch_factor = 2 batches per
+        # worker in flight for the same reason: one batch ahead, a build that takes 0.7 of a step next to the
+        # step's own kernels misses its deadline every few hundred steps and the host then waits for it
+        # (tools/lab/settle_trace.py: a floor of 0.92 ms with seconds-long stretches at 0.95 - 1.2 at depth 1,
+        # 0.925 +- 0.001 at depth 2; GCONV_BENCH_PREFETCH_DEPTH=1 for the A/B)
+        self.depth = max(1, min(int(os.environ.get("GCONV_BENCH_PREFETCH_DEPTH", depth)), k - 1)) if fresh else 1
         self.items = []
         cfg = None
         for i in range(k if fresh else 1):
@@ -215,10 +221,12 @@ class BatchStream:
 
     def next(self, normalize: bool):
         batch, x, ei, gout = self.items[self.pos % len(self.items)]
+        if self.fresh and self.prefetch:  # start the graph build of the batch `depth` steps ahead now
+            ahead = range(1, self.depth + 1) if self.pos == 0 else (self.depth,)
+            for a in ahead:
+                _, nx, nei, _ = self.items[(self.pos + a) % len(self.items)]
+                ga.prefetch_plan(nei, nx.shape[-2], normalize)
         self.pos += 1
-        if self.fresh and self.prefetch:  # start the next batch's graph build now
-            nb, nx, nei, _ = self.items[self.pos % len(self.items)]
-            ga.prefetch_plan(nei, nx.shape[-2], normalize)
         return batch, x, ei, gout
 
 
@@ -931,7 +939,7 @@ def main() -> None:
                                f"({main_res['nodes_per_rank']} nodes, {main_res['edges_per_rank']} edges), "
                                f"d={main_res['cfg']['d']}, r={main_res['cfg']['r']}, "
                                f"{main_res['cfg']['adapters']} adapters fwd+bwd, "
-                               + ("fresh graph plan per step (built on a side stream while the previous step runs)"
+                               + ("fresh graph plan per step (built on a side stream two steps ahead, while the previous steps run)"
                                   if main_res["cfg"]["kind"] == "molecule" else "static graph (plan built once)")
                                + (f" + ONE flat grad all-reduce per step over {'RCCL' if backend == 'nccl' else backend} "
                                   "(gradients deposited in the bucket by the backward kernels, collective "

@@ -1,5 +1,5 @@
 """ms/step of the headline workload per chunk of 200 steps from process start (a fresh box, the driver's situation):
-    python tools/lab/settle_trace.py [seconds=12] [workload=hiv4096]"""
+    [GCONV_BENCH_PREFETCH_DEPTH=1|2|3] python tools/lab/settle_trace.py [seconds=12] [workload=hiv4096]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
