@@ -21,4 +21,9 @@ while time.perf_counter() - t0 < secs:
         bench.adapter_step(mods, params, stream, True, None)
     torch.cuda.synchronize()
     out.append(((time.perf_counter() - a) / 200 * 1e3, time.perf_counter() - t0))
-print(" ".join(f"{ms:.3f}@{t:.1f}s" for ms, t in out))
+if os.environ.get("GCONV_LAB_SUMMARY"):
+    v = sorted(ms for ms, _ in out[1:])
+    print(f"{name} depth={stream.depth} bg={os.environ.get('GCONV_BG_BUILD', 'default')}: min {v[0]:.4f} median {v[len(v) // 2]:.4f} "
+          f"p90 {v[int(len(v) * 0.9)]:.4f} max {v[-1]:.4f} ms/step over {len(v)} chunks of 200")
+else:
+    print(" ".join(f"{ms:.3f}@{t:.1f}s" for ms, t in out))
