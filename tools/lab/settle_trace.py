@@ -8,7 +8,7 @@ import gconv_adapter_amd as ga
 dev = torch.device("cuda:0")
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 12.0
 name = sys.argv[2] if len(sys.argv) > 2 else "hiv4096"
-stream = bench.BatchStream(name, 0, dev, k=4, fresh=True)
+stream = bench.BatchStream(name, 0, dev, k=4, fresh=not os.environ.get("GCONV_LAB_STATIC"))   # STATIC: one cached plan
 mods = list(bench.build_adapters(stream.cfg, True, dev))
 params = [p for m in mods for p in m.parameters()]
 bench.pin_host_threads()
