@@ -167,6 +167,9 @@ def unpin_host_threads() -> None:
 HBM_PEAK_GBS = 8000.0       # MI355X spec (MI355X_MICROARCH.md chip table)
 HBM_MEASURED_GBS = 6290.0   # float4-copy achievable, same table
 FP32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_* dense peak (= fp32 vector peak), same table
+MALL_GATHER_GBS = 8600.0    # uniformly random rows of a 38 MB table out of the Infinity Cache (same guide, "Indexed rows")
+SPMM_ARXIV_FLOOR_BYTES = 130_900_000    # S-arxiv, rank 32: what must cross the fabric with eight private L2s (LAB.md)
+SPMM_GATHER_SUSTAINED_GBS = 6400.0      # what the SpMM's gathers sustain in real traffic (tools/gather_probe, PMC)
 
 
 # --------------------------------------------------------------------------- helpers
@@ -331,6 +334,7 @@ def timed_steps(fn, steps: int, warmup: int, world: int, device) -> float:
     for _ in range(steps):
         fn()
     torch.cuda.synchronize(device)
+    own = time.perf_counter() - t0      # this rank's own K steps (before it waits for the others)
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -338,7 +342,41 @@ def timed_steps(fn, steps: int, warmup: int, world: int, device) -> float:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, own / steps * 1e3)
+        LAST_DIAG["ms_per_step_per_rank"] = [round(v, 4) for v in per_rank]
     return dt
+
+
+LAST_DIAG: dict = {}   # what the last timed_steps / collective probe of an N > 1 run saw (rank 0 prints it)
+
+
+def probe_all_reduce(bucket, world: int, device, samples: int = 10) -> dict:
+    """The step's ONE collective on its own, OUTSIDE the timed region (N > 1 only): `samples` all-reduces of
+    the flat gradient bucket, each behind a barrier (arrival skew is not the collective's time), timed with HIP
+    events on the current stream (RCCL: the events bracket the stream's wait for the collective — its device
+    time; gloo stages through the host: only the wall figure means anything) and with the host clock."""
+    ev, wall = [], []
+    for _ in range(samples + 2):
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        a.record()
+        bucket.all_reduce(async_op=False)
+        b.record()
+        b.synchronize()
+        wall.append((time.perf_counter() - t0) * 1e6)
+        ev.append(a.elapsed_time(b) * 1e3)
+    ev, wall = sorted(ev[2:]), sorted(wall[2:])          # (the first two: connection set-up, clocks)
+    mine = {"event_us_median": round(ev[len(ev) // 2], 1), "event_us_min": round(ev[0], 1),
+            "wall_us_median": round(wall[len(wall) // 2], 1), "bytes": bucket.nbytes}
+    every = [None] * world
+    dist.all_gather_object(every, mine)
+    return {"bytes": bucket.nbytes, "samples": samples,
+            "event_us_median_max_over_ranks": max(e["event_us_median"] for e in every),
+            "event_us_min_min_over_ranks": min(e["event_us_min"] for e in every),
+            "wall_us_median_max_over_ranks": max(e["wall_us_median"] for e in every)}
 
 
 def event_time_ms(fn, iters: int, warmup: int = 5) -> float:
@@ -398,19 +436,33 @@ def measure_arxiv(device, iters: int = 50, banded_control: bool = False) -> dict
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "frac_of_measured_copy_peak": round(achieved / HBM_MEASURED_GBS, 4),
             "algorithmic_bytes": b, "avg_launch_us": round(ms * 1e3, 2), "traffic": None}
-    pmc = next((q for q in (os.path.join(ROOT, "profiles", f"r0{k}_spmm_arxiv_pmc.json") for k in (4, 3, 2, 1))
+    pmc = next((q for q in (os.path.join(ROOT, "profiles", f"r0{k}_spmm_arxiv_pmc.json") for k in (5, 4, 3, 2, 1))
                 if os.path.exists(q)), "")
     if os.path.exists(pmc):   # PMC passes cannot run inside the timed bench: committed rocprofv3 result
         with open(pmc) as fh:
             dv = json.load(fh)["derived"]
         roof["traffic"] = round(dv["traffic_bytes_per_launch"])
-        # the bytes that actually crossed L2 <-> memory per launch, at the live launch time
+        # What the counters count: bytes between the eight L2s and the FABRIC per launch. FETCH_SIZE includes
+        # Infinity-Cache hits (MI355X_MICROARCH.md, HBM), and the 21.8 MB H table is MALL-resident — so this is
+        # fabric / MALL traffic, not HBM traffic, and its yardstick is the guide's rate for uniformly random
+        # rows out of the Infinity Cache (8.6 TB/s, "Indexed rows"), not the 6.29 TB/s HBM copy peak.
+        roof["traffic_kind"] = "L2<->fabric bytes incl. Infinity-Cache hits (H table MALL-resident): not HBM bytes"
         roof["traffic_GBs"] = round(dv["traffic_bytes_per_launch"] / (ms * 1e-3) / 1e9, 1)
-        roof["traffic_frac_of_measured_copy_peak"] = round(roof["traffic_GBs"] / HBM_MEASURED_GBS, 3)
+        roof["traffic_frac_of_mall_gather_rate"] = round(roof["traffic_GBs"] / MALL_GATHER_GBS, 3)
         roof["traffic_source"] = (f"profiles/{os.path.basename(pmc)} (collected at commit "
                                   f"{dv.get('commit', 'n/a')}): 2 x FETCH_SIZE + WRITE_SIZE per launch "
                                   "(separate rocprofv3 --pmc passes, gfx950 x2 fetch correction); L2 hit rate "
                                   f"{dv['l2_hit_rate']:.2f}")
+    # The structural floor of a row-partitioned gather on THIS graph (seeded generator; LAB.md "SpMM floor"):
+    # the rows an XCD processes reference 802,599 distinct (XCD, H-row) pairs -> 102.7 MB must cross the fabric even
+    # with eight infinite L2s (21.8 MB with one), + 21.9 MB of output + 6.3 MB of index data = 130.9 MB, at the
+    # 6.4 TB/s the gathers sustain (tools/gather_probe: 1.12 x below the kernel). north_star's 0.50 is below it.
+    roof["floor_bytes"] = SPMM_ARXIV_FLOOR_BYTES
+    roof["floor_us"] = round(SPMM_ARXIV_FLOOR_BYTES / (SPMM_GATHER_SUSTAINED_GBS * 1e9) * 1e6, 1)
+    roof["floor_frac"] = round(b / (roof["floor_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 3)
+    roof["frac_of_floor"] = round(roof["floor_us"] / (ms * 1e3), 3)
+    roof["target_frac"] = 0.5
+    roof["target_met"] = bool(roof["frac"] >= 0.5)
 
     banded = {}
     if banded_control:
@@ -433,6 +485,25 @@ def measure_arxiv(device, iters: int = 50, banded_control: bool = False) -> dict
              "arxiv_adapter_fwd_GBs": round(fb / (fwd_ms * 1e-3) / 1e9, 1),
              "arxiv_adapter_bwd_GBs": round(bb / (bwd_ms * 1e-3) / 1e9, 1),
              "arxiv_adapter_steps_per_s": round(1e3 / (fwd_ms + bwd_ms), 1)}
+    with torch.no_grad():   # the evaluation pass (finetune_transductive_learning.py:233-260): forward only, nothing saved
+        extra["arxiv_adapter_eval_fwd_us"] = round(event_time_ms(lambda: mod(x, ei), 20) * 1e3, 1)
+    del out
+    # BASELINE configs[4] as ONE step: L = 2 layers x (pre + post) = 4 adapters on the static graph, ONE shared
+    # plan, forward + backward of the chain (what `--workload arxiv` headlines; here next to the default line)
+    mods4 = build_adapters(dict(d=d, r=r, adapters=cfg["adapters"]), True, device)
+    params4 = list(mods4.parameters())
+
+    def step4():
+        for q in params4:
+            q.grad = None
+        x.grad = None
+        h = x
+        for m in mods4:
+            h = m(h, ei)
+        h.backward(gout)
+    step4_ms = best_event_time_ms(step4, 10, reps=3, warmup=3)
+    extra["arxiv_step4_ms"] = round(step4_ms, 4)
+    extra["arxiv_step4_GBs"] = round(cfg["adapters"] * (fb + bb) / (step4_ms * 1e-3) / 1e9, 1)
     extra.update(banded)
     return {"roofline": roof, "extra": extra}
 
@@ -495,13 +566,16 @@ def measure_tile_kernels(device, name: str = "hiv4096") -> dict:
             q.grad = None
         out.backward(gout, retain_graph=True)
     bwd_ms = event_time_ms(bwd, 30)
+    with torch.no_grad():   # the reference's evaluation passes (finetune_inductive_learning.py:95-104): forward only
+        eval_ms = event_time_ms(lambda: mod(x, ei), 30)
     fb, bb = adapter_algorithmic_bytes(n, plan.fwd.nnz, d, r)
     ga.PLAN_CACHE.clear()
     res = {f"{name}_adapter_fwd_us": round(fwd_ms * 1e3, 1), f"{name}_adapter_bwd_us": round(bwd_ms * 1e3, 1),
+           f"{name}_adapter_eval_fwd_us": round(eval_ms * 1e3, 1),
            f"{name}_adapter_fwd_GBs": round(fb / (fwd_ms * 1e-3) / 1e9, 1),
            f"{name}_adapter_bwd_GBs": round(bb / (bwd_ms * 1e-3) / 1e9, 1),
            f"{name}_adapter_frac_of_hbm_peak": round((fb + bb) / ((fwd_ms + bwd_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)}
-    pmc = os.path.join(ROOT, "profiles", f"r04_tile_traffic_{name}.json")
+    pmc = next((q for q in (os.path.join(ROOT, "profiles", f"r0{k}_tile_traffic_{name}.json") for k in (5, 4)) if os.path.exists(q)), "")
     if os.path.exists(pmc):   # what the two kernels REALLY move per launch (committed rocprofv3 --pmc passes), at the live times
         with open(pmc) as fh:
             tt = json.load(fh)
@@ -832,7 +906,17 @@ def run_workload(name: str, normalize: bool, steps: int, warmup: int, rank: int,
 
     settled = settle(step, device, world)
     graphs[0] = 0
+    cfs0 = ga.dist.cpu_throttle_stats()
     dt = timed_steps(step, steps, warmup, world, device)
+    cfs1 = ga.dist.cpu_throttle_stats()
+    if world > 1:   # what a bad scaling point needs to be read: was the container throttled inside the timed region?
+        LAST_DIAG["cfs_throttle_delta_over_timed_region"] = {k: cfs1[k] - cfs0[k] for k in cfs0}
+        if bucket is not None:
+            bucket.wait()
+            LAST_DIAG["all_reduce"] = probe_all_reduce(bucket, world, device)
+        pins = [None] * world
+        dist.all_gather_object(pins, f"{_PINNED[0]}-{_PINNED[-1]}" if _PINNED else "none")
+        LAST_DIAG["pinned_cores_per_rank"] = pins
     ga.PLAN_CACHE.clear()
     if isinstance(stream, StoreStream):
         batch0 = ga.synth.molecule_batch(cfg["mol"], cfg["graphs"], hidden=cfg["d"], seed=rank * 1000)
@@ -958,8 +1042,17 @@ def main() -> None:
                    "settle_steps": main_res["settle_steps"],
                    "host_threads": (f"pinned to cores {_PINNED[0]}-{_PINNED[-1]} (GPU's NUMA node)"
                                     if _PINNED else "not pinned"),
+                   # the container's CFS quota in CPUs (None: none) and what one rank pins itself to under it
+                   # (gconv_adapter_amd.dist.host_core_budget: floor(quota / ranks), at most 8)
+                   "cpu_quota": ga.dist.cpu_quota(),
+                   "cores_per_rank": len(_PINNED) if _PINNED else None,
                    "surface": "GConvAdapter nn.Module -> C ABI -> HIP"},
     }
+    if world > 1 and LAST_DIAG:
+        per = LAST_DIAG.get("ms_per_step_per_rank") or [main_res["ms_per_step"]]
+        line["diagnostics"] = {"ms_per_step_min_over_ranks": min(per), "ms_per_step_max_over_ranks": max(per), **LAST_DIAG,
+                               "note": "per-rank times are each rank's own K steps before the closing barrier; the all-reduce "
+                                       "probe runs after the timed region; cfs = cpu.stat deltas of the container over the timed region"}
     if solo:
         extra = {}
         if "cpu" in main_res:

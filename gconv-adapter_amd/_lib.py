@@ -85,6 +85,7 @@ class GraphStruct(C.Structure):
         ("normalize", C.c_int32),
         ("max_degree", C.c_int32),
         ("bad_index", C.c_int32),
+        ("tile_sync", C.c_void_p),
     ]
 
 
@@ -95,7 +96,7 @@ class PendingFinalize(C.Structure):
 
 FINALIZE_BATCH = 5
 BUILD_BACKGROUND = 1   # GCONV_BUILD_BACKGROUND
-ABI_VERSION = 9   # GCONV_ABI_VERSION of include/gconv_adapter.h this binding was written against
+ABI_VERSION = 10   # GCONV_ABI_VERSION of include/gconv_adapter.h this binding was written against
 
 
 class AdapterParams(C.Structure):
@@ -135,6 +136,8 @@ SIGNATURES = {
     "gconv_adapter_bwd_workspace_bytes": (_sz, [_graph_p, _i32, _i32]),
     "gconv_adapter_fwd_f32": (_i32, [_graph_p, C.POINTER(AdapterParams), _vp, _vp, _vp, _vp,
                                      _vp, _vp, _sz, _vp]),
+    "gconv_adapter_infer_workspace_bytes": (_sz, [_graph_p, _i32, _i32]),
+    "gconv_adapter_infer_f32": (_i32, [_graph_p, C.POINTER(AdapterParams), _vp, _vp, _vp, _sz, _vp]),
     "gconv_adapter_bwd_f32": (_i32, [_graph_p, C.POINTER(AdapterParams), _vp, _vp, _vp, _vp,
                                      _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gconv_adapter_bwd_partial_f32": (_i32, [_graph_p, C.POINTER(AdapterParams), _vp, _vp, _vp, _vp,

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, _torch_ext
-from .functional import GConvAdapterFunction, LayerNormScaleFunction, _stream
+from .functional import GConvAdapterFunction, LayerNormScaleFunction, _stream, adapter_infer
 from .graph import get_plan
 from .norm import BatchNorm1d
 
@@ -141,6 +141,23 @@ class GConvAdapter(nn.Module):
                   self.conv_up._parameters, self._parameters))
             self.__dict__["_flat_params"] = p
         ext = _torch_ext.get()
+        sc = p[4] if fuse_scalar else None
+        # Nothing records a graph (the reference's evaluation passes run under torch.no_grad(),
+        # finetune_inductive_learning.py:95-104; or no input of the call requires a gradient): the
+        # forward-only entry point — same bits in `out`, no saved tensors allocated or written
+        if not torch.is_grad_enabled() or not (x2d.requires_grad or p[0].requires_grad or p[1].requires_grad
+                                               or p[2].requires_grad or p[3].requires_grad
+                                               or (sc is not None and sc.requires_grad)):
+            if ext is None:
+                return adapter_infer(x2d, p[0], p[1], p[2], p[3], sc, plan, p[5], bool(self.skip_connection))
+            dev = x2d.device
+            if dev.index != torch.cuda.current_device():
+                torch.cuda.set_device(dev)
+            lib = _lib.load()
+            plan.sizes(lib, self.hidden_size, self.bottleneck_size)   # (validates the rank)
+            return ext.adapter_infer(x2d, p[0], p[1], p[2], p[3], sc, plan.arena, plan.struct_addr,
+                                     plan.infer_bytes(lib, self.hidden_size, self.bottleneck_size), p[5],
+                                     bool(self.skip_connection), _stream(dev.index))
         if ext is None:   # pure-Python binding of the same C ABI
             return GConvAdapterFunction.apply(x2d, p[0], p[1], p[2], p[3],
                                               p[4] if fuse_scalar else None, plan, p[5],

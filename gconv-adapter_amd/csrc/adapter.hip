@@ -236,11 +236,12 @@ static gconv_status_t fwd_stages(const gconv_graph_t* gr, const gconv_adapter_pa
   return st;
 }
 
-extern "C" gconv_status_t gconv_adapter_fwd_f32(const gconv_graph_t* gr,
-                                                const gconv_adapter_params_t* p, const float* x,
-                                                float* out, float* saved_h, float* saved_h1,
-                                                float* saved_p, void* workspace,
-                                                size_t workspace_bytes, gconv_stream_t stream_) {
+// `keep` = the caller's saved_* buffers are the outputs of a training forward; !keep = forward only
+// (gconv_adapter_infer_f32): the tile path stores nothing but `out`, the general path carves its two or three
+// rank-width intermediates out of the workspace behind the forward's own scratch.
+static gconv_status_t adapter_forward(const gconv_graph_t* gr, const gconv_adapter_params_t* p, const float* x,
+                                      float* out, float* saved_h, float* saved_h1, float* saved_p, bool keep,
+                                      void* workspace, size_t workspace_bytes, gconv_stream_t stream_) {
   if (!gr) return GCONV_E_INVALID_ARG;
   const gconv_csr_t* graph = &gr->fwd;
   const float* dis = gr->dis;
@@ -248,9 +249,10 @@ extern "C" gconv_status_t gconv_adapter_fwd_f32(const gconv_graph_t* gr,
   if (st != GCONV_OK) return st;
   const int n = graph->num_nodes, d = p->hidden, r = p->rank, fp = padded_rank(r);
   if (n == 0) return GCONV_OK;
-  if (!x || !out || !saved_h || !saved_p || !workspace) return GCONV_E_INVALID_ARG;
-  if (p->act == GCONV_ACT_SILU && !saved_h1) return GCONV_E_INVALID_ARG;
-  if (!aligned16(x) || !aligned16(out) || !aligned16(saved_h) || !aligned16(saved_p) ||
+  if (!x || !out || !workspace) return GCONV_E_INVALID_ARG;
+  if (keep && (!saved_h || !saved_p)) return GCONV_E_INVALID_ARG;
+  if (keep && p->act == GCONV_ACT_SILU && !saved_h1) return GCONV_E_INVALID_ARG;
+  if (!aligned16(x) || !aligned16(out) || (saved_h && !aligned16(saved_h)) || (saved_p && !aligned16(saved_p)) ||
       (saved_h1 && !aligned16(saved_h1)) || !aligned16(workspace) ||
       (p->b_up && !aligned16(p->b_up)) || !aligned16(p->w_down))
     return GCONV_E_ALIGNMENT;
@@ -262,14 +264,51 @@ extern "C" gconv_status_t gconv_adapter_fwd_f32(const gconv_graph_t* gr,
     t.x = x; t.out = out; t.saved_h = saved_h; t.saved_h1 = saved_h1; t.saved_p = saved_p;
     t.w_down = p->w_down; t.b_down = p->b_down; t.w_up = p->w_up; t.b_up = p->b_up;
     t.scalar = p->scalar; t.d = d; t.r = r; t.fp = fp; t.act = p->act; t.skip = p->skip;
+    t.sync = gr->tile_sync;   // (word 0: the forward kernel's ticket)
 #ifdef GCONV_TILE_STAMPS
     t.stamps = static_cast<long long*>(workspace);   // diagnostic build: workspace = stamp buffer
 #endif
     return launch_tile_fwd(t, gr->n_tiles, gr->tile_nodes_max, gr->tile_edges_max, stream);
   }
   const FwdWs ws = carve_fwd(workspace, graph, fp);
-  if (workspace_bytes < ws.bytes) return GCONV_E_WORKSPACE;
+  size_t need = ws.bytes;
+  if (!keep) {
+    Carver c(workspace);
+    c.off = ws.bytes;
+    const size_t rows = static_cast<size_t>(n) * fp;
+    saved_h = c.take<float>(rows);
+    saved_p = c.take<float>(rows);
+    saved_h1 = p->act == GCONV_ACT_SILU ? c.take<float>(rows) : nullptr;
+    need = c.off;
+  }
+  if (workspace_bytes < need) return GCONV_E_WORKSPACE;
   return fwd_stages(gr, p, 0, n, 7, x, out, ws.h0, saved_h, saved_h1, saved_p, ws.seg, stream);
+}
+
+extern "C" gconv_status_t gconv_adapter_fwd_f32(const gconv_graph_t* gr,
+                                                const gconv_adapter_params_t* p, const float* x,
+                                                float* out, float* saved_h, float* saved_h1,
+                                                float* saved_p, void* workspace,
+                                                size_t workspace_bytes, gconv_stream_t stream_) {
+  return adapter_forward(gr, p, x, out, saved_h, saved_h1, saved_p, true, workspace, workspace_bytes, stream_);
+}
+
+extern "C" size_t gconv_adapter_infer_workspace_bytes(const gconv_graph_t* graph, int32_t hidden, int32_t rank) {
+  const int fp = padded_rank(rank);
+  if (!graph || fp == 0) return 0;
+  const size_t base = gconv_adapter_fwd_workspace_bytes(graph, hidden, rank);
+  if (tile_path_ok(graph, hidden, fp)) return base;
+  Carver c(nullptr);
+  c.off = base;
+  const size_t rows = static_cast<size_t>(graph->fwd.num_nodes) * fp;
+  for (int i = 0; i < 3; ++i) c.take<float>(rows);   // (the third one: SiLU's pre-activation)
+  return c.off;
+}
+
+extern "C" gconv_status_t gconv_adapter_infer_f32(const gconv_graph_t* gr, const gconv_adapter_params_t* p,
+                                                  const float* x, float* out, void* workspace,
+                                                  size_t workspace_bytes, gconv_stream_t stream_) {
+  return adapter_forward(gr, p, x, out, nullptr, nullptr, nullptr, false, workspace, workspace_bytes, stream_);
 }
 
 static_assert(sizeof(FinalizeArgs) <= sizeof(gconv_pending_finalize_t),

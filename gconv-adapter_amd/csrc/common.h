@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/gconv_adapter.h"
 
 #define GCONV_HIP(expr)                                         \
@@ -19,7 +21,46 @@ namespace gconv {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWave = 64;
+// The tile-plan FORMAT constant: a graph plan is cut for 256 persistent workgroups (tile_nominal below, the
+// node-order rule of the tile list) on every device, so plans do not depend on where they were built. What a
+// LAUNCH sizes by is the current device's compute-unit count, device_cus() — 256 on MI355X.
 constexpr int kNumCU = 256;
+
+// Compute units of the calling thread's current device (hipDeviceAttributeMultiprocessorCount, cached per
+// device; kNumCU when the query fails). Grids of the persistent / capped launches come from here.
+inline int device_cus() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return kNumCU;
+  int n = cache[dev].load(std::memory_order_relaxed);
+  if (n > 0) return n;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    n = kNumCU;
+  }
+  cache[dev].store(n, std::memory_order_relaxed);
+  return n;
+}
+
+// What a persistent launch sizes its grid by: the device's CUs, never more than the plan format's 256 (the
+// backward workspaces hold one partial row per workgroup, sized for at most kNumCU of them).
+inline int launch_cus() { const int n = device_cus(); return n < kNumCU ? n : kNumCU; }
+
+// "Once per device" for per-kernel attributes (hipFuncSetAttribute is a per-device setting; a process-wide
+// `static bool` would opt the kernel in on the first device only — round-4 advisor finding). Racing threads
+// may both run the body: it is idempotent.
+struct DeviceOnce {
+  std::atomic<uint64_t> done{0};
+  bool need() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;   // unknown device: always set
+    return (done.load(std::memory_order_relaxed) & (1ull << d)) == 0;
+  }
+  void mark() {
+    int d = 0;
+    if (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) done.fetch_or(1ull << d, std::memory_order_relaxed);
+  }
+};
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
@@ -40,6 +81,7 @@ __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; 
 // T / 4 (T / 2 .. T / 6: 39.2 .. 40.1); 4096 molecules 156.3 -> 154.7 at T = 101 (4 tiles per workgroup,
 // slack T) against 170.7 at T = 58 / slack T / 4 (7 per workgroup, a third of them with a halo);
 // 32 molecules 24.6 -> 23.6 at T = 16.
+int32_t* tile_sync_take();                     // graph_prep.hip: 16 zeroed ticket words for a new plan (or nullptr)
 int tile_nominal(int n);                       // graph_prep.hip (reads GCONV_TILE_NODES_OVERRIDE / _MAX)
 int tile_slack(int T, int n);                  // how far below its nominal position a cut may sit
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -177,7 +177,7 @@ gconv_status_t launch_up_gather(const UpGatherArgs& a, hipStream_t stream) {
   // persistent: a few workgroups per CU so that one workgroup's gather latency hides behind
   // the others' streams (GCONV_UPG_WGPC: measured at S-arxiv)
   const int wgpc = env_int("GCONV_UPG_WGPC", 3);
-  int grid = nsb < wgpc * kNumCU ? nsb : wgpc * kNumCU;
+  int grid = nsb < wgpc * launch_cus() ? nsb : wgpc * launch_cus();
   const int threads = 64 * nchunks * nslots;
   const size_t lds = static_cast<size_t>(SB) * (u.fp + 4) * sizeof(float);
 #define GCONV_UPG_CASE(FP_)                                                                         \

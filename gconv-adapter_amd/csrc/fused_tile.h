@@ -12,6 +12,9 @@ struct TileFwdArgs {
   const float* w_down; const float* b_down; const float* w_up; const float* b_up;
   const float* scalar;
   int d, r, fp, act, skip, cap, n_tiles, n;   // n = nodes of the graph (rows of x)
+  // the plan's ticket word for the dynamic tile deal (gconv_graph_t::tile_sync, word 0; reads 0 between
+  // launches); the launcher clears it when every workgroup has one tile only (static deal)
+  int* sync;
   long long* stamps;   // diagnostic build only (-DGCONV_TILE_STAMPS, tools/tilestamps.py)
 };
 

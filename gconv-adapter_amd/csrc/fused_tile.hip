@@ -453,20 +453,45 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
   lds_barrier();
 
   TILE_STAMP(0);
-  // tiles are dealt from the size-sorted list boustrophedon: pass 0 gives workgroup w the
-  // w-th largest tile, pass 1 the (2 G - 1 - w)-th, ... — the big tiles end up alone
+  // Which tile comes next. The list is sorted by size, largest first. Up to one tile per workgroup (and
+  // without the plan's ticket word) the deal is STATIC and boustrophedon: pass 0 gives workgroup w the w-th
+  // largest tile, pass 1 the (2 G - 1 - w)-th, ... With more tiles than workgroups only the FIRST tile is
+  // static; every further one is the next unclaimed entry of the list (a.sync: one returning agent-scope
+  // add per tile, asked for at the top of a tile, consumed behind phase 1, the record fetched under phases
+  // 2 - 4): a workgroup that starts late, or shares its CU with a kernel of another stream (the graph
+  // build of the next batch), takes fewer tiles instead of finishing last — round 5, VERDICT r04 item 2.
+  // A tile's rows have one writer and its arithmetic does not depend on who runs it: same bits either way.
+  // Every workgroup draws exactly one ticket beyond the list, so n_tiles tickets are drawn in all and the
+  // workgroup that draws the last one puts the word back to zero for the next launch.
+  const bool dyn = a.sync != nullptr;   // (kernel argument: uniform)
+  int* nextp = rp + a.cap + 8;          // two words of rp's unused tail, alternating per tile
+  int idx = blockIdx.x;
   for (int pass = 0;; ++pass) {
     const int G = gridDim.x;
-    const int idx = (pass & 1) ? (pass + 1) * G - 1 - static_cast<int>(blockIdx.x) : pass * G + static_cast<int>(blockIdx.x);
     if (idx >= a.n_tiles) break;
     const TileView tv = tile_view(a.tiles, idx, rec, a.halo);      // the tile of this pass
     const int ts = tv.ts, nt = tv.nt;
-    {   // the next pass's record is requested now (clamped index: always a valid entry)
-      const int nidx = ((pass + 1) & 1) ? (pass + 2) * G - 1 - static_cast<int>(blockIdx.x)
-                                        : (pass + 1) * G + static_cast<int>(blockIdx.x);
+    int ticket = 0, nidx = 0;
+    if (!dyn) {   // the next pass's record is requested now (clamped index: always a valid entry)
+      nidx = ((pass + 1) & 1) ? (pass + 2) * G - 1 - static_cast<int>(blockIdx.x)
+                              : (pass + 1) * G + static_cast<int>(blockIdx.x);
       rec = tile_rec_load(a.tiles, min(nidx, a.n_tiles - 1));
+    } else if (threadIdx.x == 0) {
+      ticket = __hip_atomic_fetch_add(a.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (nt <= 0) continue;  // uniform
+    if (nt <= 0) {  // uniform: an empty tile only passes the deal on
+      if (dyn) {
+        if (threadIdx.x == 0) {
+          nextp[pass & 1] = G + ticket;
+          if (ticket == a.n_tiles - 1) __hip_atomic_store(a.sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        lds_barrier();
+        nidx = uniform(nextp[pass & 1]);
+        rec = tile_rec_load(a.tiles, min(nidx, a.n_tiles - 1));
+      }
+      idx = nidx;
+      continue;
+    }
     TILE_STAMP_NT(nt);
     TILE_STAMP(1);
     // Row pitch in bytes, re-derived per tile behind an opaque asm: the byte offsets built on
@@ -489,7 +514,15 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
     tile_rowsA<FP, NQ, NORM, false>(rxa, a.x, wl, bufA, a.dis, nullptr, 1.f, tv, a.d, rowb, nwaves, wave,
                                     lane, [&]() { csr.advance(); });
     csr.finish();
+    if (dyn && threadIdx.x == 0) {   // the ticket has had all of phase 1 to come back
+      nextp[pass & 1] = G + ticket;
+      if (ticket == a.n_tiles - 1) __hip_atomic_store(a.sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     lds_barrier();
+    if (dyn) {   // the next tile's record: requested here, needed at the top of the next pass
+      nidx = uniform(nextp[pass & 1]);
+      rec = tile_rec_load(a.tiles, min(nidx, a.n_tiles - 1));
+    }
     TILE_STAMP(2);
 
     // phase 4's first two X tiles are requested now: their latency passes under phases 2 / 3.
@@ -508,7 +541,9 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
     for (int lr = grp; lr < tv.n1; lr += ngrp) {
       f32x4 v = tile_row_sum<FP, NORM>(bufA, rp, cl, dl, lr, sub) + bdv;
       const size_t off = static_cast<size_t>(ts + lr) * FP + 4 * sub;
-      const bool own = lr < nt;   // a halo row's value is stored by the tile that owns it
+      // a halo row's value is stored by the tile that owns it; a forward-only call (saved_h == NULL:
+      // gconv_adapter_infer_f32, evaluation under no_grad) keeps nothing
+      const bool own = lr < nt && a.saved_h != nullptr;
       if (a.act == GCONV_ACT_SILU && own) stg4(a.saved_h1 + off, v);
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = act_fwd(a.act, v[k]);
@@ -523,7 +558,7 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
     for (int lr = grp; lr < nt; lr += ngrp) {
       const f32x4 v = tile_row_sum<FP, NORM>(bufB, rp, cl, dl, lr, sub);
       *reinterpret_cast<f32x4*>(bufA + lr * FP + 4 * sub) = v;
-      stg4(a.saved_p + static_cast<size_t>(ts + lr) * FP + 4 * sub, v);
+      if (a.saved_p) stg4(a.saved_p + static_cast<size_t>(ts + lr) * FP + 4 * sub, v);
     }
     lds_barrier();
 
@@ -564,6 +599,7 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
     }
     lds_barrier();  // bufA / bufB are reused by the next tile
     TILE_STAMP(5);
+    idx = nidx;
   }
 }
 
@@ -1070,7 +1106,7 @@ GCONV_TILE_DEFINE_FP(GCONV_TILE_ONLY_FP)
   }
 
 int tile_grid(int n_tiles) {  // persistent: one workgroup per CU
-  constexpr int kMax = kNumCU * (GCONV_TILE_WGPC >= 2 ? 2 : 1);
+  const int kMax = launch_cus() * (GCONV_TILE_WGPC >= 2 ? 2 : 1);
   return n_tiles < kMax ? (n_tiles > 0 ? n_tiles : 1) : kMax;
 }
 
@@ -1079,6 +1115,9 @@ gconv_status_t launch_tile_fwd(TileFwdArgs a, int n_tiles, int tile_nodes_max,
   const int nq = tile_nq(a.d);
   a.n_tiles = n_tiles;
   n_tiles = tile_grid(n_tiles);
+  // one tile per workgroup: nothing to deal. GCONV_TILE_STATIC_DEAL=1: the static deal everywhere (A/B knob)
+  static const bool static_deal = getenv("GCONV_TILE_STATIC_DEAL") != nullptr;
+  if (a.n_tiles <= n_tiles || static_deal) a.sync = nullptr;
   a.cap = ceil_div(tile_nodes_max > 0 ? tile_nodes_max : 1, 16) * 16;
   const size_t lds = tile_lds_bytes(a.d, a.fp, tile_nodes_max, tile_edges_max);
   const int threads = tile_threads_fwd(a.d, a.fp);

@@ -204,7 +204,7 @@ int rowsA_grid(int n, int d, int fp) {
   static const int wgpc = std::getenv("GCONV_ROWSA_WGPC") ? std::atoi(std::getenv("GCONV_ROWSA_WGPC")) : 2;
   // (a weight table above 80 KB of LDS leaves room for one workgroup per CU)
   const int per_cu = rowsA_lds_bytes(d, fp) > 80 * 1024 ? 1 : wgpc;
-  return g < 1 ? 1 : (g > per_cu * kNumCU ? per_cu * kNumCU : g);   // measured best at S-arxiv: 2 (27 us) vs 3-6 (28-29 us)
+  return g < 1 ? 1 : (g > per_cu * launch_cus() ? per_cu * launch_cus() : g);   // measured best at S-arxiv: 2 (27 us) vs 3-6 (28-29 us)
 }
 
 // Ring depth: 1. A second ring (two block periods for a load to arrive, 123 VGPRs) was measured
@@ -339,7 +339,7 @@ gconv_status_t launch_up_fwd(const UpArgs& a, hipStream_t stream) {
   const int nblk = ceil_div(a.n, 16);
   // persistent: 2 workgroups per CU, each wave slot walks node blocks with a 1-deep prefetch
   int grid = ceil_div(nblk, nslots);
-  if (grid > 2 * kNumCU) grid = 2 * kNumCU;   // measured: 2 per CU 37 us, 4 per CU 41 us, 6 per CU 45 us
+  if (grid > 2 * launch_cus()) grid = 2 * launch_cus();   // measured: 2 per CU 37 us, 4 per CU 41 us, 6 per CU 45 us
   const int threads = 64 * nchunks * nslots;
   switch (a.fp) {
     case 4:  return launch_up_fwd_fp<4>(a, grid, threads, nchunks, nslots, stream);
@@ -370,7 +370,7 @@ BwdMainGeom bwd_main_geom(int n, int d) {
   // write-out it multiplies is a few KB per workgroup
   static const int per_slot = std::getenv("GCONV_B4_BLOCKS_PER_SLOT") ? std::atoi(std::getenv("GCONV_B4_BLOCKS_PER_SLOT")) : 1;
   int grid = ceil_div(nblk, per_slot * g.nslots);
-  if (grid > kNumCU) grid = kNumCU;
+  if (grid > launch_cus()) grid = launch_cus();
   if (grid < 1) grid = 1;
   g.grid = grid;
   g.nparts = grid;

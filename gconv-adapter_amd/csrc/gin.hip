@@ -161,7 +161,7 @@ template <int NP>
 static void launch_gin_aggregate_pair(const gconv_csr_t* csr, const float* x, const int32_t* count,
                                       const float* emb_type, const float* emb_dir, void* out_pair, int d,
                                       hipStream_t stream) {
-  const int grid = min(ceil_div(csr->num_nodes, 4), kNumCU * 4);
+  const int grid = min(ceil_div(csr->num_nodes, 4), launch_cus() * 4);
   _Float16* o = static_cast<_Float16*>(out_pair);
   int32_t* rexp = reinterpret_cast<int32_t*>(static_cast<char*>(out_pair) + mlp_pair_exp_offset(csr->num_nodes, d));
   gin_aggregate_kernel<NP, true, true><<<grid, 256, 0, stream>>>(csr->rowptr, csr->col, x, count, emb_type, emb_dir,
@@ -175,7 +175,7 @@ static void launch_gin_aggregate(const gconv_csr_t* csr, const float* x, const i
   // persistent waves, as many as fit (the rows of a molecule batch are short: what hides their
   // latency is the number of waves, not the work per wave): the bond variant holds 9 x NP table
   // registers per lane (110 VGPRs at NP = 2: 4 workgroups of 4 waves per CU), the plain one 8
-  const int grid = min(ceil_div(csr->num_nodes, 4), kNumCU * (count ? 4 : 8));
+  const int grid = min(ceil_div(csr->num_nodes, 4), launch_cus() * (count ? 4 : 8));
   if (count)
     gin_aggregate_kernel<NP, true><<<grid, 256, 0, stream>>>(csr->rowptr, csr->col, x, count, emb_type, emb_dir,
                                                              out, csr->num_nodes, d);

@@ -355,11 +355,11 @@ extern "C" gconv_status_t gconv_mlp_gemm_bf16x3(const void* a_split, const void*
   unsigned short* c3 = static_cast<unsigned short*>(c_split);
 #define GCONV_MLP_LAUNCH(EPI_, SPLIT_)                                                                             \
   do {                                                                                                             \
-    static bool opted_in = false; /* (two 39 KB buffers of dynamic LDS: above the 48 KB default; once per kernel) */ \
-    if (!opted_in) {                                                                                               \
+    static DeviceOnce opted_in; /* (two 39 KB buffers of dynamic LDS: above the 48 KB default; per kernel and device) */ \
+    if (opted_in.need()) {                                                                                         \
       GCONV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_gemm_bf16x3_kernel<EPI_, SPLIT_>),          \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));           \
-      opted_in = true;                                                                                             \
+      opted_in.mark();                                                                                             \
     }                                                                                                              \
     mlp_gemm_bf16x3_kernel<EPI_, SPLIT_><<<grid, kThreads, lds, stream>>>(a, w, bias, mk, c_f32, c3, num_rows, Kp, \
                                                                          out_features, Mp, Mq);                    \

@@ -710,24 +710,18 @@ extern "C" gconv_status_t gconv_mlp_gemm_f16x2(const void* a_pair, const void* w
   //  of 1 GiB and beyond take the tiled kernel)
   const bool ws_fits = static_cast<size_t>(num_rows) * (c_pair ? Mq : out_features) * 4 <= (static_cast<size_t>(1) << 30);
   if (ws_on && ws_fits && (KS == 10 || (KS == 19 && epilogue != 2)) && Mp % (64 * NT) == 0) {
-    static const int cus = [] {
-      int dev = 0, n = 0;
-      if (hipGetDevice(&dev) != hipSuccess ||
-          hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-        n = 0;
-      return n;
-    }();
+    const int cus = device_cus();   // (per device, common.h)
     const int CG = Mp / (64 * NT), rr_per_xcd = (cus / 8) / CG;
     if (rr_per_xcd >= 1) {
       const dim3 wgrid(8 * rr_per_xcd * CG);
 #define GCONV_MLP_WS_LAUNCH_K(KS_, NT_, EPI_, SPLIT_)                                                              \
   do {                                                                                                             \
     constexpr int ws_lds = ws_ring(KS_) * ws_slot_bytes(KS_, NT_, EPI_);                                                   \
-    static bool opted_in = false;                                                                                  \
-    if (!opted_in) {                                                                                               \
+    static DeviceOnce opted_in; /* (dynamic LDS above the 48 KB default: per kernel AND per device) */              \
+    if (opted_in.need()) {                                                                                         \
       GCONV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_gemm_f16x2_ws_kernel<KS_, NT_, EPI_, SPLIT_>), \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, ws_lds));                          \
-      opted_in = true;                                                                                             \
+      opted_in.mark();                                                                                             \
     }                                                                                                              \
     mlp_gemm_f16x2_ws_kernel<KS_, NT_, EPI_, SPLIT_><<<wgrid, kWsThreads, ws_lds, stream>>>(                       \
         a, aexp, w, wtail, bias, mk, c_f32, c2, cexp, num_rows, out_features, Mp, Mq, CG, rr_per_xcd);             \
@@ -758,11 +752,11 @@ extern "C" gconv_status_t gconv_mlp_gemm_f16x2(const void* a_pair, const void* w
   }
 #define GCONV_MLP_LAUNCH_S(EPI_, SPLIT_, S_)                                                                       \
   do {                                                                                                             \
-    static bool opted_in = false; /* (dynamic LDS above the 48 KB default; once per kernel) */                      \
-    if (!opted_in) {                                                                                               \
+    static DeviceOnce opted_in; /* (dynamic LDS above the 48 KB default; once per kernel and device) */             \
+    if (opted_in.need()) {                                                                                         \
       GCONV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_gemm_f16x2_kernel<EPI_, SPLIT_, S_>),       \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));           \
-      opted_in = true;                                                                                             \
+      opted_in.mark();                                                                                             \
     }                                                                                                              \
     mlp_gemm_f16x2_kernel<EPI_, SPLIT_, S_><<<grid, kThreads, lds, stream>>>(a, aexp, w, wtail, bias, mk, c_f32,   \
                                                                             c2, cexp, num_rows, Kp, out_features, \

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restric
   }
 }
 
-static int ln_bwd_grid(int n) { return min(ceil_div(n > 0 ? n : 1, 4), kNumCU * 2); }
+static int ln_bwd_grid(int n) { return min(ceil_div(n > 0 ? n : 1, 4), launch_cus() * 2); }
 
 }  // namespace gconv
 
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256) void bn_dx_kernel(const float* __restrict__ g,
   }
 }
 
-static int bn_grid(int n) { return min(ceil_div(n > 0 ? n : 1, 4), kNumCU * 2); }
+static int bn_grid(int n) { return min(ceil_div(n > 0 ? n : 1, 4), launch_cus() * 2); }
 
 // workspace: [partials: grid x 2d] [dgamma d] [dbeta d]
 struct BnWs {

@@ -57,6 +57,8 @@ using ln_bwd_fn_t = gconv_status_t (*)(const float*, const float*, const float*,
 using ln_bytes_fn_t = size_t (*)(int32_t, int32_t);
 using rank_fn_t = int32_t (*)(int32_t);
 using ws_fn_t = size_t (*)(const gconv_graph_t*, int32_t, int32_t);
+using infer_fn_t = gconv_status_t (*)(const gconv_graph_t*, const gconv_adapter_params_t*, const float*, float*,
+                                      void*, size_t, gconv_stream_t);
 using spmm_ws_fn_t = size_t (*)(const gconv_csr_t*, int32_t);
 using spmm_fn_t = gconv_status_t (*)(const gconv_csr_t*, const float*, const float*, float*, int32_t, const float*,
                                      int32_t, uint32_t, void*, size_t, gconv_stream_t);
@@ -88,6 +90,7 @@ struct Lib {
   gin_agg_fn_t gin_agg = nullptr;
   gin_agg_pair_fn_t gin_agg_pair = nullptr;
   fwd_fn_t fwd = nullptr;
+  infer_fn_t infer = nullptr;
   bwd_fn_t bwd = nullptr;
   str_fn_t str = nullptr;
   bytes_fn_t build_bytes = nullptr;
@@ -111,6 +114,7 @@ void load_library(const std::string& path) {
   TORCH_CHECK(h != nullptr, "gconv_adapter_amd: cannot dlopen ", path, ": ", dlerror());
   g_lib.fwd = reinterpret_cast<fwd_fn_t>(dlsym(h, "gconv_adapter_fwd_f32"));
   g_lib.bwd = reinterpret_cast<bwd_fn_t>(dlsym(h, "gconv_adapter_bwd_f32"));
+  g_lib.infer = reinterpret_cast<infer_fn_t>(dlsym(h, "gconv_adapter_infer_f32"));
   g_lib.str = reinterpret_cast<str_fn_t>(dlsym(h, "gconv_status_string"));
   g_lib.build_bytes = reinterpret_cast<bytes_fn_t>(dlsym(h, "gconv_graph_build_bytes"));
   g_lib.build = reinterpret_cast<build_fn_t>(dlsym(h, "gconv_graph_build"));
@@ -136,7 +140,7 @@ void load_library(const std::string& path) {
   TORCH_CHECK(g_lib.bn_bytes && g_lib.bn_fwd && g_lib.bn_bwd && g_lib.pair_bytes && g_lib.split_rows &&
                   g_lib.pair_gemm && g_lib.gin_agg && g_lib.gin_agg_pair,
               "gconv_adapter_amd: C ABI symbols of the fine-tune surroundings missing in ", path);
-  TORCH_CHECK(g_lib.fwd && g_lib.bwd && g_lib.str && g_lib.build_bytes && g_lib.build && g_lib.bwd_partial &&
+  TORCH_CHECK(g_lib.fwd && g_lib.infer && g_lib.bwd && g_lib.str && g_lib.build_bytes && g_lib.build && g_lib.bwd_partial &&
                   g_lib.bwd_finalize && g_lib.ln_fwd && g_lib.ln_bwd && g_lib.ln_bytes && g_lib.padded_rank &&
                   g_lib.ws_fwd && g_lib.ws_bwd && g_lib.spmm_ws && g_lib.spmm && g_lib.build_ex,
               "gconv_adapter_amd: C ABI symbols missing in ", path);
@@ -615,6 +619,37 @@ at::Tensor adapter_apply_direct(at::Tensor x, c10::optional<at::Tensor> anchor, 
   }
   pack_get(pack_id)->ensure_accumulators();
   return AdapterFnDirect::apply(x, anchor, pack_id, arena, graph_addr, fp, ws_fwd, ws_bwd, act, skip, stream);
+}
+
+// Forward only (gconv_adapter_infer_f32): no autograd node, no saved tensors — what GConvAdapter.forward calls under
+// torch.no_grad() / when nothing that reaches it requires a gradient (the reference's evaluation passes,
+// /root/reference/scripts/finetune_inductive_learning.py:95-104). `arena` keeps the plan's memory referenced for
+// the duration of the call only: the launch is ordered on `stream` like every other use of the plan.
+at::Tensor adapter_infer(at::Tensor x, at::Tensor w_down, c10::optional<at::Tensor> b_down_, at::Tensor w_up,
+                         c10::optional<at::Tensor> b_up_, c10::optional<at::Tensor> scalar_, at::Tensor arena,
+                         int64_t graph_addr, int64_t ws_bytes, int64_t act, bool skip, int64_t stream) {
+  at::Tensor b_down = b_down_.value_or(at::Tensor()), b_up = b_up_.value_or(at::Tensor()),
+             scalar = scalar_.value_or(at::Tensor());
+  TORCH_CHECK(g_lib.handle, "gconv_adapter_amd: library not loaded");
+  TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat,
+              "gconv_adapter_amd computes in fp32 on a HIP device (no CPU path)");
+  (void)arena;
+  if (!x.is_contiguous()) x = x.contiguous();
+  if (!w_down.is_contiguous()) w_down = w_down.contiguous();
+  if (!w_up.is_contiguous()) w_up = w_up.contiguous();
+  const int64_t n = x.size(0), d = x.size(1), r = w_down.size(0);
+  gconv_graph_t g;
+  std::memcpy(&g, reinterpret_cast<const void*>(graph_addr), sizeof(g));
+  TORCH_CHECK(n == g.fwd.num_nodes, "x has ", n, " nodes but the graph plan was built for ", g.fwd.num_nodes);
+  at::Tensor out = at::empty_like(x);
+  at::Tensor ws = forward_workspace(x, ws_bytes);
+  gconv_adapter_params_t p{fptr(w_down), fptr(b_down), fptr(w_up), fptr(b_up), fptr(scalar),
+                           static_cast<int32_t>(d), static_cast<int32_t>(r),
+                           static_cast<int32_t>(act), skip ? 1 : 0};
+  check(g_lib.infer(&g, &p, x.data_ptr<float>(), out.data_ptr<float>(), ws.data_ptr(), static_cast<size_t>(ws_bytes),
+                    reinterpret_cast<void*>(stream)),
+        "adapter_infer");
+  return out;
 }
 
 at::Tensor adapter_apply(at::Tensor x, at::Tensor w_down, c10::optional<at::Tensor> b_down,
@@ -1228,6 +1263,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "C++ autograd bridge to the gconv_adapter C ABI + native graph-plan prefetch worker";
   m.def("load_library", &load_library);
   m.def("adapter_apply", &adapter_apply);
+  m.def("adapter_infer", &adapter_infer);
   m.def("adapter_apply_direct", &adapter_apply_direct);
   m.def("pack_create", &pack_create);
   m.def("pack_release", &pack_release);

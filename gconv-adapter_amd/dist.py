@@ -285,17 +285,97 @@ def _least_busy_block(cpus: List[int], per: int, sample_s: float = 0.05) -> List
     return blocks[min(range(len(blocks)), key=lambda i: (load[i], i))]
 
 
+# ---------------------------------------------------------------------------------------
+# The container's CPU share (cgroup). A GPU box hands a container a CFS QUOTA (the 1-GPU boxes of this
+# pool: 16 CPUs of a 256-thread host): a process group that uses more CPU time than quota x period is
+# frozen — every thread of it — until the next 100 ms period. One rank of the adapter step keeps three
+# host threads busy (training loop, autograd engine, graph-plan worker; RCCL adds a proxy thread), so
+# 8 ranks x 3 threads on a 16-CPU quota is 1.5x the share: the ranks' threads must fit INSIDE the quota
+# by construction. `host_core_budget` is that rule, `pin_to_local_cores` applies it, and the bench line
+# of an N > 1 run carries the quota and the throttle counters so that a bad curve can be told from a bad box.
+# ---------------------------------------------------------------------------------------
+def parse_cpu_max(text: str) -> Optional[float]:
+    """CPUs of a cgroup-v2 ``cpu.max`` line (``"1600000 100000"`` -> 16.0); ``"max 100000"`` (no quota),
+    empty or malformed text -> None."""
+    f = text.split()
+    if len(f) != 2 or f[0] == "max":
+        return None
+    try:
+        quota, period = int(f[0]), int(f[1])
+    except ValueError:
+        return None
+    return quota / period if quota > 0 and period > 0 else None
+
+
+def parse_cpu_stat(text: str) -> dict:
+    """``cpu.stat`` of cgroup v2 (``nr_periods``, ``nr_throttled``, ``throttled_usec``) or v1
+    (``throttled_time`` in ns) -> {nr_periods, nr_throttled, throttled_usec}; missing keys are 0."""
+    kv = {}
+    for line in text.splitlines():
+        f = line.split()
+        if len(f) == 2:
+            try:
+                kv[f[0]] = int(f[1])
+            except ValueError:
+                pass
+    usec = kv.get("throttled_usec", kv.get("throttled_time", 0) // 1000)
+    return {"nr_periods": kv.get("nr_periods", 0), "nr_throttled": kv.get("nr_throttled", 0), "throttled_usec": usec}
+
+
+def cpu_quota() -> Optional[float]:
+    """This container's CPU quota in CPUs (cgroup v2 ``/sys/fs/cgroup/cpu.max``, v1 ``cpu.cfs_quota_us`` /
+    ``cpu.cfs_period_us``), None when there is none or it cannot be read."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            return parse_cpu_max(fh.read())
+    except OSError:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as q, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as p:
+            return parse_cpu_max(f"{q.read().strip()} {p.read().strip()}".replace("-1 ", "max "))
+    except OSError:
+        return None
+
+
+def cpu_throttle_stats() -> dict:
+    """Throttle counters of this container's cgroup (all zero when unreadable): sample before and after a timed
+    region — a growing ``nr_throttled`` means the ranks' host threads were frozen by the CFS quota inside it."""
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        try:
+            with open(path) as fh:
+                return parse_cpu_stat(fh.read())
+        except OSError:
+            continue
+    return parse_cpu_stat("")
+
+
+def host_core_budget(local_world: int, quota: Optional[float] = None, most: int = 8) -> int:
+    """Cores one rank pins itself to: `most` (8: room for its three busy threads, the runtime's and RCCL's helpers
+    on one CCD) unless the container's quota is smaller than `most` x ranks — then floor(quota / ranks), at least
+    1: 8 ranks under a 16-CPU quota get 2 cores each, so that all ranks together cannot exceed the quota and no
+    CFS period ends in a freeze. Threads then share cores (hand-offs cost a context switch, a few microseconds)
+    instead of the whole process group losing the rest of a 100 ms period."""
+    if quota is None:
+        quota = cpu_quota()
+    if quota is None:
+        return most
+    return max(1, min(most, int(quota // max(local_world, 1))))
+
+
 def pin_to_local_cores(local_rank: Optional[int] = None, local_world: Optional[int] = None,
-                       cores_per_rank: int = 8) -> List[int]:
+                       cores_per_rank: Optional[int] = None) -> List[int]:
     """Pins all threads of this process to `local_core_set(...)`; returns the set. Ranks and
-    world default to LOCAL_RANK / LOCAL_WORLD_SIZE (torchrun). No-op (returns []) when
-    GCONV_NO_PIN is set or the platform has no sched_setaffinity."""
+    world default to LOCAL_RANK / LOCAL_WORLD_SIZE (torchrun), `cores_per_rank` to `host_core_budget`
+    (GCONV_CORES_PER_RANK overrides). No-op (returns []) when GCONV_NO_PIN is set or the platform has
+    no sched_setaffinity."""
     if os.environ.get("GCONV_NO_PIN") or not hasattr(os, "sched_setaffinity"):
         return []
     if local_rank is None:
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if local_world is None:
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    if cores_per_rank is None:
+        cores_per_rank = int(os.environ.get("GCONV_CORES_PER_RANK", 0)) or host_core_budget(local_world)
     cpus = local_core_set(local_rank, local_world, cores_per_rank)
     if cpus:
         set_process_affinity(cpus)

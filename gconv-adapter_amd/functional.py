@@ -37,6 +37,35 @@ def _ptr(t) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+def adapter_infer(x, w_down, b_down, w_up, b_up, scalar, plan: GraphPlan, act: int, skip: bool) -> torch.Tensor:
+    """Forward only (``gconv_adapter_infer_f32``): what ``GConvAdapter.forward`` runs under ``torch.no_grad()``
+    or when nothing that reaches it requires a gradient — the reference's evaluation passes
+    (``/root/reference/scripts/finetune_inductive_learning.py:95-104``). Same bits in ``out`` as the training
+    forward; no saved tensors are allocated or written."""
+    lib = _lib.load()
+    if not x.is_cuda or x.dtype != torch.float32:
+        _require_hip_f32(x, "x")
+    n, d = x.shape
+    r = w_down.shape[0]
+    if n != plan.num_nodes:
+        raise RuntimeError(f"x has {n} nodes but the graph plan was built for {plan.num_nodes}")
+    plan.sizes(lib, d, r)   # (validates the rank)
+    ws_bytes = plan.infer_bytes(lib, d, r)
+    x, w_down, w_up = x.contiguous(), w_down.contiguous(), w_up.contiguous()
+    dev = x.device
+    if dev.index != torch.cuda.current_device():
+        torch.cuda.set_device(dev)
+    out = torch.empty_like(x)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    params = _lib.AdapterParams(w_down.data_ptr(), _ptr(b_down), w_up.data_ptr(), _ptr(b_up),
+                                _ptr(scalar), d, r, act, int(skip))
+    st = lib.gconv_adapter_infer_f32(plan.ref(), C.byref(params), x.data_ptr(), out.data_ptr(), ws.data_ptr(),
+                                     ws_bytes, _stream(dev.index))
+    if st != 0:
+        _lib.check(st, "adapter_infer")
+    return out
+
+
 class GConvAdapterFunction(torch.autograd.Function):
     """out = s * (S act(S x Wd^T + bd) Wu^T + bu + [skip] x) on a [N, d] input.
 

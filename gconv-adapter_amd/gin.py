@@ -363,6 +363,10 @@ class GinFrozenLayerFunction(torch.autograd.Function):
         return _aggregate(ctx.plan.bwd, ga, None, None, None), None, None, None
 
 
+def _invalidate_split_after_load(module, _incompatible_keys) -> None:
+    module.invalidate_mlp_split()
+
+
 class MolecularGINConv(nn.Module):
     """Drop-in for the reference's ``MolecularGINConv`` (module docstring)."""
 
@@ -382,10 +386,12 @@ class MolecularGINConv(nn.Module):
         #: read the skipped-edge counter back after building a batch's code counts (one host
         #: synchronisation per batch) and raise on out-of-range bond attributes
         self.validate_edge_attr = False
-        # the frozen MLP's weights as bf16 triples: W1, W2 (forward), W2^T, W1^T (input gradient)
-        self.__dict__["_mlp_split"] = [_SplitWeights() for _ in range(4)]
-
-        self.register_load_state_dict_post_hook(lambda module, _keys: module.invalidate_mlp_split())
+        # the frozen MLP's weights as bf16 triples / fp16 pairs: W1, W2 (forward), W2^T, W1^T (input
+        # gradient). Both caches exist from construction on: a module built directly on the device
+        # (`with torch.device("cuda")`) is never moved, so `_apply` never runs for it.
+        self.invalidate_mlp_split()
+        # (a module-level function, not a lambda: the hook dict is part of the pickled state)
+        self.register_load_state_dict_post_hook(_invalidate_split_after_load)
 
     def invalidate_mlp_split(self) -> None:
         """Drops the cached bf16 images of the MLP's weights; the next forward splits them again.

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GCONV_ABI_VERSION 9
+#define GCONV_ABI_VERSION 10
 
 typedef int32_t gconv_status_t;
 typedef void*   gconv_stream_t; /* hipStream_t */
@@ -167,6 +167,15 @@ typedef struct gconv_graph {
   int32_t        normalize;
   int32_t        max_degree;     /* of `fwd`                                            */
   int32_t        bad_index;      /* 1 if an edge endpoint was outside [0, num_nodes)    */
+  int32_t*       tile_sync;      /* 16 words of LIBRARY-owned device memory (not in the arena; a slot of a
+                                  * per-device pool, handed out by the graph build) that read 0 between
+                                  * launches: word 0 = the fused forward kernel's tile ticket, word 4 = the
+                                  * backward kernel's (dynamic tile deal: a persistent workgroup takes the next
+                                  * unclaimed tile of the size-sorted list instead of a fixed share; the last
+                                  * ticket's owner puts the word back to 0). NULL (pool allocation failed, or a
+                                  * struct filled by hand): static deal. Like `long_sync`, the words belong to ONE
+                                  * launch at a time: launches that use the same plan must be ordered (one
+                                  * stream, or events) — PyTorch's forward / backward on one stream are.   */
 } gconv_graph_t;
 
 /* Bytes of device memory gconv_graph_build needs (outputs + scratch, upper bound). */
@@ -287,6 +296,18 @@ gconv_status_t gconv_adapter_fwd_f32(const gconv_graph_t* graph,
                                      float* out, float* saved_h, float* saved_h1, float* saved_p,
                                      void* workspace, size_t workspace_bytes,
                                      gconv_stream_t stream);
+
+/* Forward ONLY — replaces `GConvAdapter.forward` where the reference runs it under `torch.no_grad()`:
+ * its three evaluations per epoch (`scripts/finetune_inductive_learning.py:95-104,401-409`) and the
+ * transductive script's `evaluate` (`scripts/finetune_transductive_learning.py:233-260`). The same launches
+ * and the same bits in `out` as gconv_adapter_fwd_f32; nothing is kept for a backward pass: the fused tile
+ * path stores `out` only (its rank-width intermediates never leave LDS), the general path keeps them in
+ * `workspace` (>= gconv_adapter_infer_workspace_bytes, 16-byte aligned, non-NULL).  (ABI 10)              */
+size_t gconv_adapter_infer_workspace_bytes(const gconv_graph_t* graph, int32_t hidden, int32_t rank);
+gconv_status_t gconv_adapter_infer_f32(const gconv_graph_t* graph,
+                                       const gconv_adapter_params_t* params, const float* x,
+                                       float* out, void* workspace, size_t workspace_bytes,
+                                       gconv_stream_t stream);
 
 /* replaces: the autograd backward of the same ops, entered from
  * `loss.backward()` (`scripts/finetune_inductive_learning.py:66`,

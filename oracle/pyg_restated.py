@@ -109,11 +109,24 @@ def _act(name: str, h: torch.Tensor) -> torch.Tensor:
     raise ValueError("Invalid non_linearity. Supported types: 'relu', 'silu', 'none'.")
 
 
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1   # nn.BatchNorm1d defaults (the reference constructs it with none, :54-55)
+
+
 def adapter_forward(x: torch.Tensor, edge_index: torch.Tensor, params: Dict[str, torch.Tensor],
                     flags: AdapterFlags, training: bool = True) -> torch.Tensor:
     """``params`` keys follow the reference state_dict: conv_down.lin.weight [r,d],
     conv_down.bias [r], conv_up.lin.weight [d,r], conv_up.bias [d], scalar [1],
-    normalization.weight / normalization.bias [d] (optional)."""
+    normalization.weight / normalization.bias [d] (optional) and, for ``batch_norm``, the module's
+    buffers normalization.running_mean / normalization.running_var [d] (optional).
+
+    ``training`` is ``module.training`` of the reference module: the train loop calls ``model.train()``
+    (``scripts/finetune_inductive_learning.py:38``), the three evaluations per epoch ``model.eval()`` under
+    ``torch.no_grad()`` (``:95-104``). Only the ``batch_norm`` tail depends on it, exactly as
+    ``nn.BatchNorm1d.forward`` does (track_running_stats=True, momentum 0.1, eps 1e-5):
+      training  batch statistics (biased variance) normalise; the running buffers, when given, are
+                updated IN PLACE with momentum 0.1 and the UNBIASED batch variance;
+      eval      the running buffers normalise (no buffers: nothing to evaluate with -> ValueError, where
+                torch would fall back to batch statistics only for track_running_stats=False)."""
     h = gcn_conv(x, edge_index, params["conv_down.lin.weight"], params.get("conv_down.bias"),
                  flags.normalize)
     h = _act(flags.non_linearity, h)
@@ -123,8 +136,12 @@ def adapter_forward(x: torch.Tensor, edge_index: torch.Tensor, params: Dict[str,
         out = out + x                                     # :94-95 (in-place there)
     if flags.normalization == "batch_norm":
         if out.size(0) > 1:                               # :99
-            out = F.batch_norm(out, None, None, params.get("normalization.weight"),
-                               params.get("normalization.bias"), training=True)
+            rm, rv = params.get("normalization.running_mean"), params.get("normalization.running_var")
+            if not training and (rm is None or rv is None):
+                raise ValueError("adapter_forward(training=False) with batch_norm needs normalization.running_mean / "
+                                 "normalization.running_var (the module's buffers)")
+            out = F.batch_norm(out, rm, rv, params.get("normalization.weight"), params.get("normalization.bias"),
+                               training=training, momentum=BN_MOMENTUM, eps=BN_EPS)
     elif flags.normalization == "layer_norm":
         d = out.size(-1)
         out = F.layer_norm(out, (d,), params.get("normalization.weight"),
@@ -143,7 +160,8 @@ def adapter_forward_backward(x: torch.Tensor, edge_index: torch.Tensor,
     """Forward + autograd backward with upstream gradient ``grad_out``.
 
     Returns (out, grads) where grads has one entry per parameter plus ``x``."""
-    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()
+              if not k.startswith("normalization.running_")}          # (buffers are not leaves)
     xl = x.detach().clone().requires_grad_(need_dx)
     out = adapter_forward(xl, edge_index, leaves, flags)
     out.backward(grad_out)

@@ -56,6 +56,21 @@ def test_module_surface_matches_the_reference():
         m(torch.zeros(2, 300), torch.zeros(2, 0, dtype=torch.long), torch.zeros(0, 2, dtype=torch.long))
 
 
+def test_module_is_complete_after_construction_and_pickles():
+    """Round-4 advisor findings: the fp16-pair cache used to appear only in `_apply` / `load_state_dict`
+    (a module built directly on its device never had it), and a lambda hook made the module unpicklable."""
+    import copy
+    import pickle
+    m = ga.MolecularGINConv(32)
+    assert len(m.__dict__["_mlp_pair"]) == 4 and len(m.__dict__["_mlp_split"]) == 4
+    m2 = pickle.loads(pickle.dumps(m))                      # what torch.save(model) does
+    assert len(m2.__dict__["_mlp_pair"]) == 4
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k])
+    m2.load_state_dict(m.state_dict())                      # the hook survived the round trip
+    copy.deepcopy(m)
+
+
 # --------------------------------------------------------------------------- GPU
 def _module(d, params, dev):
     m = ga.MolecularGINConv(d).to(dev)
@@ -430,6 +445,32 @@ def test_relational_bias_matches_restatement(dev, heads, d, trans, kind):
     close(got, want.detach(), "out")
     close(xd.grad, x64.grad, "dx")
     close(bd.grad, b64.grad, "db", atol=1e-5 * max(1.0, float(b64.grad.abs().max())))
+
+
+@pytest.mark.gpu
+def test_frozen_layer_built_directly_on_the_device(dev):
+    """A layer constructed under `torch.device("cuda")` and never moved (no `_apply`, no `load_state_dict`)
+    runs its frozen forward and backward (round-4 advisor finding: AttributeError on `_mlp_pair`)."""
+    batch, cfg = ga.synth.make_workload("esol")
+    d = cfg["d"]
+    ei = batch.edge_index.to(dev)
+    ea = _bond_attr(ei.shape[1], 5).to(dev)
+    torch.manual_seed(0)
+    with torch.device(dev):
+        layer = ga.MolecularGINConv(d)
+    moved = ga.MolecularGINConv(d)
+    moved.load_state_dict({k: v.cpu() for k, v in layer.state_dict().items()})
+    moved = moved.to(dev)
+    for m in (layer, moved):
+        for p in m.parameters():
+            p.requires_grad_(False)
+    x = batch.x.to(dev).requires_grad_(True)
+    y = layer(x, ei, ea)
+    y.square().sum().backward()
+    x2 = batch.x.to(dev).requires_grad_(True)
+    y2 = moved(x2, ei, ea)
+    y2.square().sum().backward()
+    assert torch.equal(y, y2) and torch.equal(x.grad, x2.grad)
 
 
 @pytest.mark.gpu

@@ -6,9 +6,15 @@ to the layer's output), around a stand-in backbone with the reference's control 
     (/root/reference/src/models/inductive/gnn.py:97-130) with this package's frozen GIN layers
     and BatchNorm; adapters called with three positional arguments (`:103,115`);
   * NodeFormer shape, `[1, N, d]`: `NodeFormer.forward`
-    (/root/reference/src/models/transductive/nodeformer.py:403-438; DIFFormer's loop,
-    difformer.py:235-260, has the same shape) with a frozen linear "conv", the in-place residual
-    `z += layer_[i]` (`:418`), LayerNorm and ELU; adapters called with two arguments (`:407,427`).
+    (/root/reference/src/models/transductive/nodeformer.py:403-438) with a frozen linear "conv", the
+    in-place residual `z += layer_[i]` (`:418`), LayerNorm and ELU; adapters called with two arguments
+    (`:407,427`);
+  * DIFFormer shape, 2-D `[N, d]`: `DIFFormer.forward`
+    (/root/reference/src/models/transductive/difformer.py:216-267). NOT NodeFormer's loop:
+    the conv consumes the running `x`, not `layer_[i]` (`:241`), so a sequential pre-adapter reaches the
+    output only through the alpha-mix residual `alpha x + (1 - alpha) layer_[i]` (`:244`); LayerNorm
+    AFTER the mix (`:246`); a trainable input MLP + ReLU in front (`:221-225`, the freeze rule keeps
+    every `fc` trainable, `:207-208`); adapters called with two arguments (`:236,251`).
 
 Each model is compared with the SAME model assembled from the CPU oracles in fp64: loss and the
 gradient of every trainable parameter (adapters, norm layers, head). BASELINE configs[4] is the
@@ -33,8 +39,8 @@ MODES = [(("pre", "post"), "sequential"), (("pre", "post"), "parallel"), (("pre"
          (("post",), "sequential"), (("post",), "parallel")]
 
 
-def _add_adapters(model, positions, kind, d, r, layers):
-    """`add_adapter` (gnn.py:63-82, nodeformer.py:354-388) called once per position."""
+def _add_adapters(model, positions, kind, d, r, layers, head_names=("head",)):
+    """`add_adapter` (gnn.py:63-82, nodeformer.py:354-388, difformer.py:180-214) called once per position."""
     model.adapter_type = kind
     for position in positions:
         bank = model.pre_adapters if position == "pre" else model.post_adapters
@@ -49,7 +55,8 @@ def _add_adapters(model, positions, kind, d, r, layers):
                 p.fill_(0.7)
     for name, module in model.named_modules():        # freeze rule (gnn.py:230-241)
         for _, p in module.named_parameters(recurse=False):
-            p.requires_grad = ("adapter" in name or "head" in name or isinstance(module, (nn.LayerNorm, nn.BatchNorm1d)))
+            p.requires_grad = ("adapter" in name or any(h in name for h in head_names)
+                               or isinstance(module, (nn.LayerNorm, nn.BatchNorm1d)))
 
 
 def _adapter_params(state, bank, layer):
@@ -267,3 +274,106 @@ def test_nodeformer_shape_insertion_modes(dev, positions, kind):
     # no ReLU / BatchNorm between the adapters and the loss besides the adapters' own (inside the
     # oracle too, on values bounded away from the kink by the 0.1-scale weights): element-wise
     assert _compare(model, state, want_loss, loss) == 5 * n_adapters + 2 * (MiniFormer.LAYERS + 1) + 2
+
+
+# ------------------------------------------------------------------------------------------
+# DIFFormer shape (difformer.py:216-267): [N, d], the conv consumes x, alpha-mix residual, LayerNorm after
+# ------------------------------------------------------------------------------------------
+class MiniDIFFormer(nn.Module):
+    IN, D, R, LAYERS, ALPHA = 24, 32, 16, 2, 0.5
+
+    def __init__(self):
+        super().__init__()
+        self.fcs = nn.ModuleList([nn.Linear(self.IN, self.D), nn.Linear(self.D, 3)])           # both trainable (:207-208)
+        self.convs = nn.ModuleList([nn.Linear(self.D, self.D) for _ in range(self.LAYERS)])    # frozen stand-in for
+        self.bns = nn.ModuleList([nn.LayerNorm(self.D) for _ in range(self.LAYERS + 1)])       # DIFFormerConv(x, x, ei, w)
+        self.pre_adapters, self.post_adapters, self.adapter_type = nn.ModuleDict(), nn.ModuleDict(), None
+
+    def forward(self, x, adjs):
+        layer_ = []
+        x = F.relu(self.bns[0](self.fcs[0](x)))             # :221-225 (dropout p = 0)
+        layer_.append(x)
+        for i, conv in enumerate(self.convs):
+            ls = str(i)
+            pre = None
+            if ls in self.pre_adapters:
+                pre = self.pre_adapters[ls](layer_[i], adjs[0])
+                if self.adapter_type == "sequential":
+                    layer_[i] = pre
+            x = conv(x)                                     # x, NOT layer_[i] (:241)
+            x = self.ALPHA * x + (1 - self.ALPHA) * layer_[i]   # :244
+            x = self.bns[i + 1](x)                          # :246
+            post = None
+            if ls in self.post_adapters:
+                post = self.post_adapters[ls](x, adjs[0])
+                if self.adapter_type == "sequential":
+                    x = post
+            if self.adapter_type == "parallel":
+                if pre is not None:
+                    x = x + pre
+                if post is not None:
+                    x = x + post
+            layer_.append(x)
+        return self.fcs[-1](x)
+
+
+def _oracle_difformer(state, kind, x, ei):
+    flags = pyg_restated.AdapterFlags(learnable_scalar=True, normalize=True)
+    D, a = MiniDIFFormer.D, MiniDIFFormer.ALPHA
+
+    def ln(v, i):
+        return F.layer_norm(v, (D,), state[f"bns.{i}.weight"], state[f"bns.{i}.bias"], 1e-5)
+    x = F.relu(ln(F.linear(x, state["fcs.0.weight"], state["fcs.0.bias"]), 0))
+    layer_ = [x]
+    for i in range(MiniDIFFormer.LAYERS):
+        pre = post = None
+        ap = _adapter_params(state, "pre_adapters", i)
+        if ap:
+            pre = pyg_restated.adapter_forward(layer_[i], ei, ap, flags)
+            if kind == "sequential":
+                layer_[i] = pre
+        x = F.linear(x, state[f"convs.{i}.weight"], state[f"convs.{i}.bias"])
+        x = ln(a * x + (1 - a) * layer_[i], i + 1)
+        ap = _adapter_params(state, "post_adapters", i)
+        if ap:
+            post = pyg_restated.adapter_forward(x, ei, ap, flags)
+            if kind == "sequential":
+                x = post
+        if kind == "parallel":
+            if pre is not None:
+                x = x + pre
+            if post is not None:
+                x = x + post
+        layer_.append(x)
+    return F.linear(x, state["fcs.1.weight"], state["fcs.1.bias"])
+
+
+@pytest.mark.parametrize("positions,kind", MODES)
+def test_difformer_shape_insertion_modes(dev, positions, kind):
+    """The five insertion modes in DIFFormer's control flow, 2-D input, loops pre-added (`adjs[0]` of
+    `scripts/finetune_transductive_learning.py:111-114`). A ReLU sits between the trainable input MLP and the
+    adapters: seeds are drawn until the fp64 oracle model has no unit near a kink (`helpers.KinkWatch`)."""
+    torch.manual_seed(2)
+    model = MiniDIFFormer()
+    _add_adapters(model, positions, kind, MiniDIFFormer.D, MiniDIFFormer.R, MiniDIFFormer.LAYERS, head_names=("fc",))
+    assert all(p.requires_grad for p in model.fcs.parameters()) and not any(p.requires_grad for p in model.convs.parameters())
+    model = model.to(dev).train()
+    state = {k: v.detach().cpu().double().requires_grad_(True) for k, v in model.state_dict().items()}
+    for seed in range(3, 67):
+        b = ga.synth.planetoid_like(700, 1500, hidden=MiniDIFFormer.IN, seed=seed)
+        x = b.x[0]                                           # DIFFormer takes [N, in] (`:216-221`)
+        y = torch.randint(0, 3, (b.num_nodes,), generator=torch.Generator().manual_seed(seed + 1))
+        for v in state.values():
+            v.grad = None
+        with KinkWatch() as watch:
+            want_loss = F.cross_entropy(_oracle_difformer(state, kind, x.double(), b.edge_index), y)
+        if watch.risky == 0:
+            break
+    assert watch.risky == 0 and watch.units > 10_000, "no seeded graph without a unit at a ReLU kink"
+    want_loss.backward()
+    out = model(x.to(dev), [b.edge_index.to(dev)])
+    assert out.shape == (b.num_nodes, 3)
+    loss = F.cross_entropy(out.double(), y.to(dev))
+    loss.backward()
+    n_adapters = MiniDIFFormer.LAYERS * len(positions)
+    assert _compare(model, state, want_loss, loss) == 5 * n_adapters + 2 * (MiniDIFFormer.LAYERS + 1) + 4

@@ -139,7 +139,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_library_host_only_entry_points():
     lib = ga._lib.load()
-    assert lib.gconv_abi_version() == 9
+    assert lib.gconv_abi_version() == 10
     assert [lib.gconv_padded_rank(r) for r in (0, 1, 4, 5, 8, 16, 17, 33, 64, 65)] == \
         [0, 4, 4, 8, 8, 16, 32, 64, 64, 0]
     assert b"workspace" in lib.gconv_status_string(-3)
@@ -361,3 +361,29 @@ def test_header_is_plain_c_and_a_c_program_links_the_library():
     needed = subprocess.run(["readelf", "-d", out], capture_output=True, text=True).stdout
     assert "libgconv_adapter.so" in needed and "libtorch" not in needed and "libpython" not in needed
     assert "libstdc++" not in needed        # (a C program: the C++ runtime comes in only through the library itself)
+
+
+def test_cpu_quota_parsing_and_the_host_core_budget():
+    """Round 5: an N-rank run sizes each rank's pinned core set from the container's CFS
+    quota, and its bench line carries the quota and the throttle counters. The parsers, on the texts the kernel
+    writes (cgroup v2 `cpu.max` / `cpu.stat`, v1 `cpu.stat`)."""
+    d = ga.dist
+    assert d.parse_cpu_max("1600000 100000\n") == 16.0
+    assert d.parse_cpu_max("150000 100000") == 1.5
+    assert d.parse_cpu_max("max 100000\n") is None
+    assert d.parse_cpu_max("") is None and d.parse_cpu_max("garbage") is None and d.parse_cpu_max("0 100000") is None
+    v2 = "usage_usec 123\nuser_usec 100\nsystem_usec 23\nnr_periods 420\nnr_throttled 7\nthrottled_usec 81234\nnr_bursts 0\n"
+    assert d.parse_cpu_stat(v2) == {"nr_periods": 420, "nr_throttled": 7, "throttled_usec": 81234}
+    v1 = "nr_periods 10\nnr_throttled 2\nthrottled_time 5000000\n"
+    assert d.parse_cpu_stat(v1) == {"nr_periods": 10, "nr_throttled": 2, "throttled_usec": 5000}
+    assert d.parse_cpu_stat("") == {"nr_periods": 0, "nr_throttled": 0, "throttled_usec": 0}
+    # 8 ranks under the 16-CPU quota of a GPU box: 2 cores each (8 x 3 busy threads would be 1.5 x the share)
+    assert d.host_core_budget(8, 16.0) == 2
+    assert d.host_core_budget(4, 16.0) == 4 and d.host_core_budget(2, 16.0) == 8 and d.host_core_budget(1, 16.0) == 8
+    assert d.host_core_budget(8, 4.0) == 1                      # never below one core
+    assert d.host_core_budget(8, 256.0) == 8                    # never above the CCD's worth
+    assert isinstance(d.host_core_budget(8), int)               # reads this container's own quota
+    stats = d.cpu_throttle_stats()
+    assert set(stats) == {"nr_periods", "nr_throttled", "throttled_usec"}
+    q = d.cpu_quota()
+    assert q is None or q > 0

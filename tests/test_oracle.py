@@ -131,6 +131,48 @@ def test_sem8_residual_before_norm_before_scalar():
     assert torch.allclose(oracle.adapter_forward(x, ei, params, flags), want)
 
 
+def test_sem9_batch_norm_tail_follows_the_module_training_flag():
+    """`training` = the reference module's `.training`: its `nn.BatchNorm1d` (`gconv_adapter.py:54-55,98-100`)
+    normalises with batch statistics and updates its running buffers under `model.train()`
+    (`finetune_inductive_learning.py:41`), and with the running buffers under `model.eval()` (`:96`). The
+    restatement is checked against that very class in fp64."""
+    n, d, r = 40, 8, 3
+    fl = oracle.AdapterFlags(normalization="batch_norm", learnable_scalar=True)
+    base = oracle.AdapterFlags(normalization="none", learnable_scalar=False)
+    params = oracle.init_params(d, r, fl)
+    params["normalization.running_mean"] = torch.zeros(d, dtype=torch.float64)
+    params["normalization.running_var"] = torch.ones(d, dtype=torch.float64)
+    bn = torch.nn.BatchNorm1d(d).double()
+    with torch.no_grad():
+        bn.weight.copy_(params["normalization.weight"]); bn.bias.copy_(params["normalization.bias"])
+    for step in range(3):                                   # three training steps: buffers move together
+        ei = _rand_graph(n, 120, 10 + step)
+        x = torch.randn(n, d, dtype=torch.float64, generator=torch.Generator().manual_seed(step)) + step
+        pre = oracle.adapter_forward(x, ei, params, base)   # conv + x
+        bn.train()
+        want = bn(pre) * params["scalar"]
+        got = oracle.adapter_forward(x, ei, params, fl, training=True)
+        assert torch.allclose(got, want, rtol=1e-12, atol=1e-12)
+        assert torch.allclose(params["normalization.running_mean"], bn.running_mean, rtol=1e-12, atol=1e-12)
+        assert torch.allclose(params["normalization.running_var"], bn.running_var, rtol=1e-12, atol=1e-12)
+    ei = _rand_graph(n, 100, 99)
+    x = torch.randn(n, d, dtype=torch.float64)
+    bn.eval()
+    frozen = {k: v.clone() for k, v in params.items()}
+    want = bn(oracle.adapter_forward(x, ei, params, base)) * params["scalar"]
+    got = oracle.adapter_forward(x, ei, params, fl, training=False)
+    assert torch.allclose(got, want, rtol=1e-12, atol=1e-12)
+    scratch = {k: v.clone() for k, v in params.items()}     # (a training call updates its buffers in place)
+    assert not torch.allclose(got, oracle.adapter_forward(x, ei, scratch, fl, training=True))   # (it matters)
+    for k in ("normalization.running_mean", "normalization.running_var"):   # evaluation does not touch the buffers
+        assert torch.equal(params[k], frozen[k])
+    with pytest.raises(ValueError):                         # nothing to evaluate with
+        oracle.adapter_forward(x, ei, {k: v for k, v in params.items() if "running" not in k}, fl, training=False)
+    # without buffers training mode is what every fixture used so far
+    bare = {k: v for k, v in params.items() if "running" not in k}
+    assert torch.allclose(oracle.adapter_forward(x, ei, bare, fl), oracle.adapter_forward(x, ei, bare, fl, training=True))
+
+
 def test_invalid_flags_raise_value_error():
     x = torch.randn(3, 4, dtype=torch.float64)
     ei = torch.tensor([[0], [1]])

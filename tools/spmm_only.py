@@ -5,7 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import gconv_adapter_amd as ga
 dev = torch.device("cuda:0")
-batch, cfg = ga.synth.make_workload("arxiv")
+if "--banded" in sys.argv:   # the locality control of bench.py --banded (1 M nodes, neighbours within +-2048)
+    batch, cfg = ga.synth.banded_like(1_000_000, 8, 2048), {"r": 32}
+else:
+    batch, cfg = ga.synth.make_workload("arxiv")
 n, r = batch.num_nodes, cfg["r"]
 plan = ga.get_plan(batch.edge_index.to(dev), n, True)
 h = torch.randn(n, r, device=dev); y = torch.empty_like(h)
