@@ -61,6 +61,7 @@ class CsrStruct(C.Structure):
         ("long_seg_base", C.c_void_p),
         ("seg_long", C.c_void_p),
         ("long_sync", C.c_void_p),
+        ("near_edges", C.c_int32),
     ]
 
 

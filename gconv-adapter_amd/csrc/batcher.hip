@@ -222,6 +222,7 @@ extern "C" gconv_status_t gconv_graph_from_store(const gconv_graph_t* dataset, c
   *g = gconv_graph_t{};
   g->fwd.num_nodes = num_nodes; g->fwd.nnz = static_cast<int32_t>(nnz);
   g->fwd.rowptr = rowptr; g->fwd.col = col;
+  g->fwd.near_edges = static_cast<int32_t>(nnz);   // block-diagonal by construction: every neighbour sits in its row's molecule
   g->bwd = g->fwd;
   g->dis = dis;
   g->tile_ptr = tile_ptr;

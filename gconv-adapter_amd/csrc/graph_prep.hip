@@ -105,14 +105,22 @@ __global__ void make_keys_kernel(const int64_t* __restrict__ ei, int64_t E, int3
 template <typename K>
 __global__ void build_csr_kernel(const K* __restrict__ keys, int64_t E, int32_t n, KeyOps<K> ko,
                                  int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
-                                 int32_t* __restrict__ nnz_out) {
+                                 int32_t* __restrict__ nnz_out, int32_t* __restrict__ near_out) {
   int64_t p = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (p > E) return;
-  const int64_t r_prev = (p == 0) ? -1 : static_cast<int64_t>(ko.row(keys[p - 1]));
-  const int64_t r_cur = (p == E) ? n : static_cast<int64_t>(ko.row(keys[p]));
-  for (int64_t r = r_prev + 1; r <= r_cur; ++r) rowptr[r] = static_cast<int32_t>(p);
-  if (p < E && r_cur < n) col[p] = static_cast<int32_t>(ko.col(keys[p]));
-  if (r_cur == n && r_prev < n) *nnz_out = static_cast<int32_t>(p);
+  bool near = false;
+  if (p <= E) {
+    const int64_t r_prev = (p == 0) ? -1 : static_cast<int64_t>(ko.row(keys[p - 1]));
+    const int64_t r_cur = (p == E) ? n : static_cast<int64_t>(ko.row(keys[p]));
+    for (int64_t r = r_prev + 1; r <= r_cur; ++r) rowptr[r] = static_cast<int32_t>(p);
+    if (p < E && r_cur < n) {
+      const int64_t c = ko.col(keys[p]);
+      col[p] = static_cast<int32_t>(c);
+      near = (c * 8) / n == (r_cur * 8) / n;   // column in the row's eighth of the node range (gconv_csr_t::near_edges)
+    }
+    if (r_cur == n && r_prev < n) *nnz_out = static_cast<int32_t>(p);
+  }
+  const int cnt = __popcll(__ballot(near));    // one add per wave
+  if ((threadIdx.x & 63) == 0 && cnt > 0) atomicAdd(near_out, cnt);
 }
 
 __global__ void row_stats_kernel(const int32_t* __restrict__ rowptr, int32_t n,
@@ -311,7 +319,7 @@ static gconv_status_t build_direction(const int64_t* ei, int64_t E, int32_t n, i
     sorted = keys_b;
   }
   build_csr_kernel<K><<<static_cast<unsigned>((E + 1 + T - 1) / T), T, 0, stream>>>(
-      sorted, E, n, ko, o.rowptr, o.col, info + base);
+      sorted, E, n, ko, o.rowptr, o.col, info + base, info + base + 4);
   GCONV_LAUNCH_CHECK();
   if (n > 0) {
     row_stats_kernel<<<(n + T - 1) / T, T, 0, stream>>>(o.rowptr, n, dis, o.long_rows,
@@ -894,15 +902,25 @@ __global__ __launch_bounds__(kCountThreads) void counting_build_kernel(CountArgs
         }
         asym |= fwd != back;
       };
+      // gconv_csr_t::near_edges on the way: stored edges whose column lies in its row's eighth of the node range
+      int near_cnt = 0;
+      auto near = [&](int s, int d) {
+        return !(a.normalize && s == d) && (static_cast<int64_t>(s) * 8) / n == (static_cast<int64_t>(d) * 8) / n;
+      };
       test(s0, d0, dd0, ds0);                          // (0, 0 when the thread has no first edge: skipped as a self-loop)
+      if (gtid < E) near_cnt += near(s0, d0);
       for (int64_t e = gtid + gsize; e < E; e += gsize) {
         const int s = static_cast<int>(a.ei[e]), d = static_cast<int>(a.ei[E + e]);
         const int dd = ldc(deg + d), ds = ldc(deg + s);
         ell_row(d, rd);
         ell_row(s, rs);
         test(s, d, dd, ds);
+        near_cnt += near(s, d);
       }
       if (asym) atomicOr(&info[INFO_ASYM], 1);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) near_cnt += __shfl_xor(near_cnt, off);
+      if (lane == 0 && near_cnt > 0) atomicAdd(&info[a.fwd + 4], near_cnt);
     }
   }
   GCONV_STAMP(3);
@@ -1183,6 +1201,7 @@ extern "C" gconv_status_t gconv_graph_build_ex(const int64_t* edge_index, int64_
     c.n_long = cnt[1]; c.n_seg = cnt[2];
     c.long_rows = o.long_rows; c.long_seg_base = o.long_seg_base; c.seg_long = o.seg_long;
     c.long_sync = o.long_sync;
+    c.near_edges = cnt[4];   // (radix builder: build_csr_kernel; the one-launch builders leave the word at 0)
   };
   auto fill_tiles = [&](const int32_t* h, bool symmetric) {
     g->tile_ptr = tile_ptr;

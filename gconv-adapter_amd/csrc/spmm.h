@@ -38,6 +38,8 @@ struct SpmmArgs {
   uint32_t flags;
   int seg_only;         // launch the long-row segment blocks only (the fused K2'+K3 / B3+B4 kernels
                         // gather the short rows themselves and read the long rows' results)
+  int xcd_rows;         // 1: row block -> XCD map of a graph with local neighbourhoods (set by launch_spmm
+                        // from gconv_csr_t::near_edges): a contiguous eighth of the row blocks per XCD
 };
 
 template <int F>

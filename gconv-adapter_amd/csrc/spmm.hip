@@ -17,6 +17,8 @@
 //     cut into GCONV_SEG_EDGES-edge segments; one wave reduces one segment
 //     (extra blocks at the tail of the same launch), and a second small launch
 //     adds a row's segment sums in segment order and runs the epilogue.
+#include <cstdlib>
+
 #include "spmm.h"
 
 namespace gconv {
@@ -207,7 +209,16 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(SpmmArgs a) {
   }
 
   f32x4 bias_grad = zero4();
-  const int rblock = blockIdx.x - seg_blocks;
+  int rblock = blockIdx.x - seg_blocks;
+  if (a.xcd_rows) {
+    // Local neighbourhoods (gconv_csr_t::near_edges): workgroups are dealt round-robin over the eight XCDs, so
+    // with consecutive row blocks on consecutive XCDs every one of the eight private L2s ends up fetching every
+    // H row (banded control: L2 hit 0.47, 7 x the table through the fabric). Blocks b and b + 8 share an XCD:
+    // they take CONSECUTIVE row blocks of one contiguous eighth instead. A permutation of the row blocks — a
+    // row's sum, and the bias-partial slot of its block, do not depend on it (same bits).
+    const int per = a.row_blocks >> 3;
+    if (rblock < 8 * per) rblock = (rblock & 7) * per + (rblock >> 3);
+  }
   const int row = a.row_lo + (rblock * 4 + wave) * RPW + grp;
   const int rowc = min(row, a.row_hi - 1);
   const int e0 = a.rowptr[rowc], e1 = a.rowptr[rowc + 1];
@@ -269,6 +280,10 @@ gconv_status_t launch_spmm(const gconv_csr_t* g, SpmmArgs a, int width, int epi,
   a.seg_long = g->seg_long;
   a.long_sync = g->long_sync;
   if (a.n == 0) return GCONV_OK;
+  // at least half of the stored edges stay inside their row's eighth of the node range, and there are enough
+  // row blocks for the eighths to matter: XCD-contiguous rows (GCONV_SPMM_XCD_ROWS=0 / 1 forces it off / on)
+  static const char* xr = getenv("GCONV_SPMM_XCD_ROWS");
+  a.xcd_rows = xr ? (xr[0] == '1') : (2 * static_cast<int64_t>(g->near_edges) >= g->nnz && g->nnz > 0 && a.n >= (1 << 15));
   if (a.row_hi == 0) { a.row_lo = 0; a.row_hi = a.n; }
   if (a.row_lo < 0 || a.row_hi > a.n || a.row_lo >= a.row_hi) return GCONV_E_INVALID_ARG;
   if (a.n_seg > 0 && !a.seg_partial) return GCONV_E_WORKSPACE;

@@ -43,6 +43,8 @@ class CsrView:
         # training loop that builds a plan per batch would keep allocating fresh arenas
         self._plan, self.struct = weakref.proxy(plan), struct
         self.nnz, self.n_long, self.n_seg = struct.nnz, struct.n_long, struct.n_seg
+        #: stored edges whose column lies in its row's eighth of the node range (radix builder; 0 = not counted)
+        self.near_edges = struct.near_edges
         self.addr = C.addressof(struct)   # (the gconv_csr_t inside the plan's struct: for the C++ binding)
 
     def ref(self):

@@ -101,6 +101,13 @@ typedef struct gconv_csr {
                                  * zero between launches (the wave that completes a row adds
                                  * the row's segment sums and resets its counter). Launches
                                  * that share a CSR must therefore be stream-ordered.      */
+  int32_t        near_edges;    /* stored edges whose column lies in the same EIGHTH of the node range as
+                                 * their row (counted by the radix builder; 0 = not counted: the one-launch
+                                 * builders of small graphs / molecule batches). At least half of nnz: the
+                                 * graph's neighbourhoods are local, and the row kernel then gives every XCD
+                                 * a CONTIGUOUS eighth of the rows instead of every eighth block (round 5:
+                                 * with round-robin blocks each of the eight private L2s fetches every H row —
+                                 * 7 x the table on the banded control, profiles/r05_spmm_banded_pmc.json).  */
 } gconv_csr_t;
 
 /* Tiles of the fused (one-launch) adapter kernels. The node range is cut into contiguous tiles

@@ -121,7 +121,7 @@ def test_forward_only_through_the_ctypes_binding_and_the_c_abi(dev):
     out = torch.empty_like(x)
     ws = torch.empty(need, dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    assert lib.gconv_adapter_infer_f32(plan.ref(), C.byref(P), x.data_ptr(), out.data_ptr(), ws.data_ptr(), need - 256, st) == -3
+    assert lib.gconv_adapter_infer_f32(plan.ref(), C.byref(P), x.data_ptr(), out.data_ptr(), ws.data_ptr(), need // 2, st) == -3
     assert lib.gconv_adapter_infer_f32(plan.ref(), C.byref(P), x.data_ptr(), None, ws.data_ptr(), need, st) == -1
     assert lib.gconv_adapter_infer_f32(plan.ref(), C.byref(P), x.data_ptr(), out.data_ptr(), ws.data_ptr(), need, st) == 0
     assert torch.equal(out, want)

@@ -1207,7 +1207,9 @@ def _plan_arrays(plan):
     """Everything a plan holds, long rows keyed by row (their order in the lists is not specified)."""
     def csr(v):
         s = v.struct
-        out = {"nnz": v.nnz, "rowptr": v.rowptr.cpu(), "col": v.col.cpu(), "n_long": v.n_long, "n_seg": v.n_seg}
+        out = {"nnz": v.nnz, "rowptr": v.rowptr.cpu(), "col": v.col.cpu(), "n_long": v.n_long, "n_seg": v.n_seg,
+               # (the single-workgroup builder of graphs up to 4096 nodes does not count the near edges)
+               "near_edges": v.near_edges if plan.num_nodes > 4096 else None}
         if v.n_long:
             rows = plan.arena_view(s.long_rows, v.n_long, torch.int32).cpu().tolist()
             base = plan.arena_view(s.long_seg_base, v.n_long, torch.int32).cpu().tolist()

@@ -27,3 +27,13 @@ done
 unset GCONV_TILE_STATIC_DEAL GCONV_LAB_STATIC
 cat "$OUT/step.txt"
 date
+echo "[4] SpMM row -> XCD schedule on the banded control (and S-arxiv, where it must stay off)"; date
+for xr in 0 1 auto; do
+  if [ $xr = auto ]; then unset GCONV_SPMM_XCD_ROWS; else export GCONV_SPMM_XCD_ROWS=$xr; fi
+  echo "== GCONV_SPMM_XCD_ROWS=$xr" >> "$OUT/spmm_xcd.txt"
+  timeout -k 10 300 python3 tools/spmm_only.py --banded --time >> "$OUT/spmm_xcd.txt" 2>&1 || exit 1
+  timeout -k 10 300 python3 tools/spmm_only.py --time >> "$OUT/spmm_xcd.txt" 2>&1 || exit 1
+done
+unset GCONV_SPMM_XCD_ROWS
+cat "$OUT/spmm_xcd.txt"
+date
