@@ -530,8 +530,14 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
     // block past the tile lies outside the buffer and costs no traffic.
     const int nb4 = ceil_div(nt, 16);
     auto load_x = [&](int blk, f32x4 (&xq)[4]) {
+#ifdef GCONV_LAB_FWD_NO_XREAD   // lab build (wrong results): what phase 4 costs without its re-read of X
+#pragma unroll
+      for (int m = 0; m < 4; ++m) xq[m] = zero4f();
+      (void)blk;
+#else
 #pragma unroll
       for (int m = 0; m < 4; ++m) xq[m] = buf_ld4_last(rx, voff4 + (16 * blk + m) * rowb);
+#endif
     };
     f32x4 xa[4], xb[4];
     load_x(slot, xa);
@@ -1115,9 +1121,12 @@ gconv_status_t launch_tile_fwd(TileFwdArgs a, int n_tiles, int tile_nodes_max,
   const int nq = tile_nq(a.d);
   a.n_tiles = n_tiles;
   n_tiles = tile_grid(n_tiles);
-  // one tile per workgroup: nothing to deal. GCONV_TILE_STATIC_DEAL=1: the static deal everywhere (A/B knob)
-  static const bool static_deal = getenv("GCONV_TILE_STATIC_DEAL") != nullptr;
-  if (a.n_tiles <= n_tiles || static_deal) a.sync = nullptr;
+  // The dynamic deal is a lab knob (GCONV_TILE_DYNAMIC_DEAL=1): measured in round 5 on the whole 4096-molecule
+  // batch, it changes neither the kernel alone (61.9 against 62.2 us) nor the step next to the graph build of the
+  // next batch (1.0112 against 1.0111 ms; 0.8905 with one cached plan) — the build's kernels slow every tile
+  // workgroup alike, they do not delay some of them (LAB.md). One tile per workgroup: nothing to deal anyway.
+  static const bool dynamic_deal = getenv("GCONV_TILE_DYNAMIC_DEAL") != nullptr;
+  if (a.n_tiles <= n_tiles || !dynamic_deal) a.sync = nullptr;
   a.cap = ceil_div(tile_nodes_max > 0 ? tile_nodes_max : 1, 16) * 16;
   const size_t lds = tile_lds_bytes(a.d, a.fp, tile_nodes_max, tile_edges_max);
   const int threads = tile_threads_fwd(a.d, a.fp);
