@@ -86,7 +86,6 @@ class GraphStruct(C.Structure):
         ("normalize", C.c_int32),
         ("max_degree", C.c_int32),
         ("bad_index", C.c_int32),
-        ("tile_sync", C.c_void_p),
     ]
 
 

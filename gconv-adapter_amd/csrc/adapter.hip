@@ -264,7 +264,6 @@ static gconv_status_t adapter_forward(const gconv_graph_t* gr, const gconv_adapt
     t.x = x; t.out = out; t.saved_h = saved_h; t.saved_h1 = saved_h1; t.saved_p = saved_p;
     t.w_down = p->w_down; t.b_down = p->b_down; t.w_up = p->w_up; t.b_up = p->b_up;
     t.scalar = p->scalar; t.d = d; t.r = r; t.fp = fp; t.act = p->act; t.skip = p->skip;
-    t.sync = gr->tile_sync;   // (word 0: the forward kernel's ticket)
 #ifdef GCONV_TILE_STAMPS
     t.stamps = static_cast<long long*>(workspace);   // diagnostic build: workspace = stamp buffer
 #endif

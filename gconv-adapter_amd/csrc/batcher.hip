@@ -237,7 +237,6 @@ extern "C" gconv_status_t gconv_graph_from_store(const gconv_graph_t* dataset, c
   const int64_t eb = static_cast<int64_t>(g->tile_nodes_max) * (dataset->max_degree > 0 ? dataset->max_degree : 1);
   g->tile_edges_max = static_cast<int32_t>(eb < nnz ? eb : nnz);
   g->symmetric = 1; g->normalize = dataset->normalize; g->max_degree = dataset->max_degree; g->bad_index = 0;
-  g->tile_sync = tile_sync_take();
   return GCONV_OK;
 }
 

@@ -81,7 +81,6 @@ __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; 
 // T / 4 (T / 2 .. T / 6: 39.2 .. 40.1); 4096 molecules 156.3 -> 154.7 at T = 101 (4 tiles per workgroup,
 // slack T) against 170.7 at T = 58 / slack T / 4 (7 per workgroup, a third of them with a halo);
 // 32 molecules 24.6 -> 23.6 at T = 16.
-int32_t* tile_sync_take();                     // graph_prep.hip: 16 zeroed ticket words for a new plan (or nullptr)
 int tile_nominal(int n);                       // graph_prep.hip (reads GCONV_TILE_NODES_OVERRIDE / _MAX)
 int tile_slack(int T, int n);                  // how far below its nominal position a cut may sit
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -161,6 +160,16 @@ __device__ __forceinline__ f32x4 buf_ld4_last(rsrc_t r, int byte_off) {   // a r
 }
 __device__ __forceinline__ void buf_st4(rsrc_t r, int byte_off, f32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), r, byte_off, 0, GCONV_STORE_AUX);
+}
+// the same with the policy as a template argument (the fused tile kernels choose per launch: their phase-4 loops
+// exist twice): NT = non-temporal (aux bit 1), else the default policy
+template <bool NT>
+__device__ __forceinline__ void buf_st4_p(rsrc_t r, int byte_off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), r, byte_off, 0, NT ? 2 : 0);
+}
+template <bool NT>
+__device__ __forceinline__ void buf_st1_p(rsrc_t r, int byte_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, byte_off, 0, NT ? 2 : 0);
 }
 __device__ __forceinline__ float buf_ld1(rsrc_t r, int byte_off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));

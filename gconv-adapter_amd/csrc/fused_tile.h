@@ -12,9 +12,8 @@ struct TileFwdArgs {
   const float* w_down; const float* b_down; const float* w_up; const float* b_up;
   const float* scalar;
   int d, r, fp, act, skip, cap, n_tiles, n;   // n = nodes of the graph (rows of x)
-  // the plan's ticket word for the dynamic tile deal (gconv_graph_t::tile_sync, word 0; reads 0 between
-  // launches); the launcher clears it when every workgroup has one tile only (static deal)
-  int* sync;
+  int stagger;   // odd workgroups walk their tiles smallest first (set by the launcher)
+  int store_nt;  // output rows with non-temporal stores (set by the launcher: tile_store_nt)
   long long* stamps;   // diagnostic build only (-DGCONV_TILE_STAMPS, tools/tilestamps.py)
 };
 
@@ -29,6 +28,7 @@ struct TileBwdArgs {
   float* part_wd; float* part_wu; float* part_cs; float* part_bd;
   float* part_ds;   // complete scalar-gradient partial: (G Wu).P + [skip] G.X + b_up.colsum(G)
   int d, r, fp, act, skip, cap, want_ds, n_tiles, n;
+  int stagger, store_nt;   // as in TileFwdArgs
   long long* stamps;   // diagnostic build only
 };
 

@@ -41,6 +41,9 @@
 #ifndef GCONV_TILE_WGPC
 #define GCONV_TILE_WGPC 1
 #endif
+#ifndef GCONV_TILE_STAGGER_DEFAULT
+#define GCONV_TILE_STAGGER_DEFAULT 1
+#endif
 
 // Diagnostic build (-DGCONV_TILE_STAMPS): per-workgroup phase time stamps (100 MHz wall clock)
 // into a side buffer that nothing else reads; never compiled into the product library.
@@ -158,6 +161,28 @@ __device__ __forceinline__ TileView tile_view(const gconv_tile_t* tiles, int idx
   v.e0 = uniform(r1.y);
   v.hb = halo + static_cast<size_t>(uniform(r1.x)) * kHaloSlot;
   return v;
+}
+
+// Entry of the size-sorted tile list that workgroup w = blockIdx.x runs in pass `pass` of `npass`, or -1 (the ragged
+// last pass has no tile for some workgroups). Boustrophedon: even passes deal forwards, odd passes backwards.
+// `stagger`: odd workgroups take THEIR passes in the opposite order (their smallest tile first).
+__device__ __forceinline__ int tile_order_index(int pass, int npass, int n_tiles, int stagger) {
+  const int G = gridDim.x, w = blockIdx.x;
+  int p = pass;
+  if (stagger == 1) p = (w & 1) ? npass - 1 - pass : pass;                       // odd workgroups (= odd XCDs): smallest first
+  else if (stagger == 3) p = ((w >> 3) & 1) ? npass - 1 - pass : pass;          // lab: every other workgroup of an XCD
+  else if (stagger == 5) p = ((w >> 4) & 1) ? npass - 1 - pass : pass;          // lab: pairs of workgroups of an XCD
+  else if (stagger == 7) p = ((w ^ (w >> 3)) & 1) ? npass - 1 - pass : pass;    // lab: checkerboard over (XCD, slot)
+  else if (stagger > 1) p = (pass + (w % stagger) * npass / stagger) % npass;   // `stagger` groups, rotated starts
+  const int idx = (p & 1) ? (p + 1) * G - 1 - w : p * G + w;
+  return idx < n_tiles ? idx : -1;
+}
+// the first VALID entry of a workgroup's walk (for the prologue's record request; clamped, never -1)
+__device__ __forceinline__ int tile_first_index(int n_tiles, int stagger) {
+  const int npass = ceil_div(n_tiles, static_cast<int>(gridDim.x));
+  int idx = -1;
+  for (int p = 0; p < npass && idx < 0; ++p) idx = tile_order_index(p, npass, n_tiles, stagger);
+  return min(max(idx, 0), n_tiles - 1);
 }
 
 // graph node of the tile's local row lr (< n0): own rows are contiguous, halo rows come from the slot
@@ -378,7 +403,7 @@ struct TileCsrStage {
 // ===========================================================================
 // forward — persistent workgroups walk the tiles (weights staged / loaded once)
 // ===========================================================================
-template <int FP, int NQ, bool NORM>
+template <int FP, int NQ, bool NORM, bool NT>
 #if GCONV_TILE_WGPC >= 2
 __global__ __launch_bounds__(320, 3) void tile_fwd_kernel(TileFwdArgs a) {
 #else
@@ -407,7 +432,8 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
   // tile's record — and only then stages the LDS weights, so it pays one cold round trip, not four.
   TILE_STAMP(9);
   const float sraw = (a.scalar ? a.scalar : a.w_down)[0];
-  i32x4 rec = tile_rec_load(a.tiles, blockIdx.x);   // grid <= n_tiles
+  i32x4 rec = tile_rec_load(a.tiles, tile_first_index(a.n_tiles, a.stagger));   // (grid <= n_tiles)
+  TileView tv_s{};
 #ifdef GCONV_TILE_STAMPS
   if (threadIdx.x == 0) {   // where this workgroup runs: HW_ID (wave / simd / cu / sh / se) and XCC_ID
     a.stamps[blockIdx.x * 16 + 12] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
@@ -453,45 +479,24 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
   lds_barrier();
 
   TILE_STAMP(0);
-  // Which tile comes next. The list is sorted by size, largest first. Up to one tile per workgroup (and
-  // without the plan's ticket word) the deal is STATIC and boustrophedon: pass 0 gives workgroup w the w-th
-  // largest tile, pass 1 the (2 G - 1 - w)-th, ... With more tiles than workgroups only the FIRST tile is
-  // static; every further one is the next unclaimed entry of the list (a.sync: one returning agent-scope
-  // add per tile, asked for at the top of a tile, consumed behind phase 1, the record fetched under phases
-  // 2 - 4): a workgroup that starts late, or shares its CU with a kernel of another stream (the graph
-  // build of the next batch), takes fewer tiles instead of finishing last — round 5, VERDICT r04 item 2.
-  // A tile's rows have one writer and its arithmetic does not depend on who runs it: same bits either way.
-  // Every workgroup draws exactly one ticket beyond the list, so n_tiles tickets are drawn in all and the
-  // workgroup that draws the last one puts the word back to zero for the next launch.
-  const bool dyn = a.sync != nullptr;   // (kernel argument: uniform)
-  int* nextp = rp + a.cap + 8;          // two words of rp's unused tail, alternating per tile
-  int idx = blockIdx.x;
-  for (int pass = 0;; ++pass) {
-    const int G = gridDim.x;
-    if (idx >= a.n_tiles) break;
-    const TileView tv = tile_view(a.tiles, idx, rec, a.halo);      // the tile of this pass
+  // Tiles are dealt from the size-sorted list boustrophedon: pass 0 gives workgroup w the w-th largest tile,
+  // pass 1 the (2 G - 1 - w)-th, ... — the big tiles end up alone. a.stagger: workgroups with an odd index walk
+  // THEIR tiles in the opposite order (smallest first), so that the chip's workgroups are not all in the same
+  // phase of a tile at the same time (tile_order_index below).
+  const int npass = ceil_div(a.n_tiles, static_cast<int>(gridDim.x));
+  for (int pass = 0; pass < npass; ++pass) {
+    const int idx = tile_order_index(pass, npass, a.n_tiles, a.stagger);
+    {   // the next pass's record is requested now (clamped index: always a valid entry)
+      const int nidx = tile_order_index(min(pass + 1, npass - 1), npass, a.n_tiles, a.stagger);
+      const i32x4 nrec = tile_rec_load(a.tiles, min(max(nidx, 0), a.n_tiles - 1));
+      if (idx < 0) { rec = nrec; continue; }   // (ragged last pass: no tile for this workgroup — uniform)
+      const TileView tvv = tile_view(a.tiles, idx, rec, a.halo);
+      rec = nrec;
+      tv_s = tvv;
+    }
+    const TileView tv = tv_s;                                       // the tile of this pass
     const int ts = tv.ts, nt = tv.nt;
-    int ticket = 0, nidx = 0;
-    if (!dyn) {   // the next pass's record is requested now (clamped index: always a valid entry)
-      nidx = ((pass + 1) & 1) ? (pass + 2) * G - 1 - static_cast<int>(blockIdx.x)
-                              : (pass + 1) * G + static_cast<int>(blockIdx.x);
-      rec = tile_rec_load(a.tiles, min(nidx, a.n_tiles - 1));
-    } else if (threadIdx.x == 0) {
-      ticket = __hip_atomic_fetch_add(a.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (nt <= 0) {  // uniform: an empty tile only passes the deal on
-      if (dyn) {
-        if (threadIdx.x == 0) {
-          nextp[pass & 1] = G + ticket;
-          if (ticket == a.n_tiles - 1) __hip_atomic_store(a.sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        lds_barrier();
-        nidx = uniform(nextp[pass & 1]);
-        rec = tile_rec_load(a.tiles, min(nidx, a.n_tiles - 1));
-      }
-      idx = nidx;
-      continue;
-    }
+    if (nt <= 0) continue;  // uniform
     TILE_STAMP_NT(nt);
     TILE_STAMP(1);
     // Row pitch in bytes, re-derived per tile behind an opaque asm: the byte offsets built on
@@ -514,15 +519,7 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
     tile_rowsA<FP, NQ, NORM, false>(rxa, a.x, wl, bufA, a.dis, nullptr, 1.f, tv, a.d, rowb, nwaves, wave,
                                     lane, [&]() { csr.advance(); });
     csr.finish();
-    if (dyn && threadIdx.x == 0) {   // the ticket has had all of phase 1 to come back
-      nextp[pass & 1] = G + ticket;
-      if (ticket == a.n_tiles - 1) __hip_atomic_store(a.sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     lds_barrier();
-    if (dyn) {   // the next tile's record: requested here, needed at the top of the next pass
-      nidx = uniform(nextp[pass & 1]);
-      rec = tile_rec_load(a.tiles, min(nidx, a.n_tiles - 1));
-    }
     TILE_STAMP(2);
 
     // phase 4's first two X tiles are requested now: their latency passes under phases 2 / 3.
@@ -573,6 +570,9 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
     // requested so far has landed (the phases in between waited on younger loads): saying so
     // gives the loop below one known state on entry and around its back edge.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    // NT (template argument, chosen per launch: tile_store_nt): `out` with non-temporal or with default-policy
+    // stores. `out` is the NEXT kernel's X: on the kernel alone nt wins (round 1: nothing re-reads the output
+    // there); in the step, with several tiles per workgroup, the default policy does (round 5: whole batch -4 %).
     if (active && slot < nb4) {
       auto step = [&](int b, f32x4 (&xv)[4], int refill) {
         float pa[KS];
@@ -590,7 +590,7 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
           f32x4 o;
 #pragma unroll
           for (int c = 0; c < 4; ++c) o[c] = sval * (acc[c][m] + bu[c] + (a.skip ? xv[m][c] : 0.f));
-          buf_st4(ro, voff4 + (16 * b + m) * rowb, o);  // rows / columns past the tile: dropped
+          buf_st4_p<NT>(ro, voff4 + (16 * b + m) * rowb, o);  // rows / columns past the tile: dropped
         }
         load_x(refill, xv);
       };
@@ -605,7 +605,6 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
     }
     lds_barrier();  // bufA / bufB are reused by the next tile
     TILE_STAMP(5);
-    idx = nidx;
   }
 }
 
@@ -614,7 +613,7 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
 // scalar-gradient pieces stay in registers across all tiles of a workgroup, so ONE
 // partial row per workgroup reaches HBM and B5 is a single launch.
 // ===========================================================================
-template <int FP, int NQ, bool NORM, bool NEED_DX>
+template <int FP, int NQ, bool NORM, bool NEED_DX, bool NT>
 #if GCONV_TILE_WGPC >= 2
 __global__ __launch_bounds__(320, 3) void tile_bwd_kernel(TileBwdArgs a) {
 #else
@@ -640,7 +639,8 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
   const int pid = blockIdx.x;
   // (prologue: all first-touch requests back to back, LDS staging after them — see forward)
   const float sraw = (a.scalar ? a.scalar : a.w_down)[0];
-  i32x4 rec = tile_rec_load(a.tiles, blockIdx.x);   // grid <= n_tiles
+  i32x4 rec = tile_rec_load(a.tiles, tile_first_index(a.n_tiles, a.stagger));   // (grid <= n_tiles)
+  TileView tv_s{};
 #ifdef GCONV_TILE_STAMPS
   if (threadIdx.x == 0) {
     a.stamps[blockIdx.x * 16 + 12] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
@@ -694,19 +694,22 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
   lds_barrier();
 
   TILE_STAMP(0);
-  // tiles are dealt from the size-sorted list boustrophedon: pass 0 gives workgroup w the
-  // w-th largest tile, pass 1 the (2 G - 1 - w)-th, ... — the big tiles end up alone
-  for (int pass = 0;; ++pass) {
-    const int G = gridDim.x;
-    const int idx = (pass & 1) ? (pass + 1) * G - 1 - static_cast<int>(blockIdx.x) : pass * G + static_cast<int>(blockIdx.x);
-    if (idx >= a.n_tiles) break;
-    const TileView tv = tile_view(a.tiles, idx, rec, a.halo);      // the tile of this pass
-    const int ts = tv.ts, nt = tv.nt;
+  // tiles are dealt from the size-sorted list boustrophedon (see the forward kernel; a.stagger: odd workgroups
+  // walk their tiles smallest first — their partial sums then add the same tiles in the opposite order: fixed per
+  // launch geometry, so still the same bits run to run)
+  const int npass = ceil_div(a.n_tiles, static_cast<int>(gridDim.x));
+  for (int pass = 0; pass < npass; ++pass) {
+    const int idx = tile_order_index(pass, npass, a.n_tiles, a.stagger);
     {   // the next pass's record is requested now (clamped index: always a valid entry)
-      const int nidx = ((pass + 1) & 1) ? (pass + 2) * G - 1 - static_cast<int>(blockIdx.x)
-                                        : (pass + 1) * G + static_cast<int>(blockIdx.x);
-      rec = tile_rec_load(a.tiles, min(nidx, a.n_tiles - 1));
+      const int nidx = tile_order_index(min(pass + 1, npass - 1), npass, a.n_tiles, a.stagger);
+      const i32x4 nrec = tile_rec_load(a.tiles, min(max(nidx, 0), a.n_tiles - 1));
+      if (idx < 0) { rec = nrec; continue; }   // (ragged last pass: no tile for this workgroup — uniform)
+      const TileView tvv = tile_view(a.tiles, idx, rec, a.halo);
+      rec = nrec;
+      tv_s = tvv;
     }
+    const TileView tv = tv_s;                                       // the tile of this pass
+    const int ts = tv.ts, nt = tv.nt;
     if (nt <= 0) continue;  // uniform
     TILE_STAMP_NT(nt);
     TILE_STAMP(1);
@@ -819,7 +822,7 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
     // (everything requested so far has landed — the phases in between waited on younger
     // loads; saying so gives the loop one known state on entry and around its back edge)
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    if (owner && slot < nb4) {
+    if (owner && slot < nb4) {   // (NT: dX with non-temporal / default-policy stores — see the forward kernel)
       const float skipf = a.skip ? sval : 0.f;
       auto step = [&](int b, float (&gv)[16], float (&xv)[16], int refill) {
         // dWd^T += T^T X, dWu^T += P^T G: one node per MFMA, the node's 4 rank values of tile mt
@@ -858,7 +861,7 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
               const int n = 4 * g4 + v;
-              buf_st1(rdx, voff1 + (16 * b + n) * rowb, acc[v] + skipf * gv[n]);
+              buf_st1_p<NT>(rdx, voff1 + (16 * b + n) * rowb, acc[v] + skipf * gv[n]);
             }
           }
         }
@@ -1035,13 +1038,17 @@ bool tile_path_ok(const gconv_graph_t* g, int d, int fp) {
 template <int FP, int NQ>
 static gconv_status_t launch_tile_fwd_t(const TileFwdArgs& a, int grid, int threads, size_t lds,
                                         hipStream_t stream) {
+#define GCONV_TILE_FWD_LAUNCH(NORM_, NT_)                                       \
+  do {                                                                          \
+    GCONV_TILE_LDS_OPT_IN((tile_fwd_kernel<FP, NQ, NORM_, NT_>));               \
+    tile_fwd_kernel<FP, NQ, NORM_, NT_><<<grid, threads, lds, stream>>>(a);     \
+  } while (0)
   if (a.dis) {
-    GCONV_TILE_LDS_OPT_IN((tile_fwd_kernel<FP, NQ, true>));
-    tile_fwd_kernel<FP, NQ, true><<<grid, threads, lds, stream>>>(a);
+    if (a.store_nt) GCONV_TILE_FWD_LAUNCH(true, true); else GCONV_TILE_FWD_LAUNCH(true, false);
   } else {
-    GCONV_TILE_LDS_OPT_IN((tile_fwd_kernel<FP, NQ, false>));
-    tile_fwd_kernel<FP, NQ, false><<<grid, threads, lds, stream>>>(a);
+    if (a.store_nt) GCONV_TILE_FWD_LAUNCH(false, true); else GCONV_TILE_FWD_LAUNCH(false, false);
   }
+#undef GCONV_TILE_FWD_LAUNCH
   GCONV_LAUNCH_CHECK();
   return GCONV_OK;
 }
@@ -1049,23 +1056,22 @@ static gconv_status_t launch_tile_fwd_t(const TileFwdArgs& a, int grid, int thre
 template <int FP, int NQ>
 static gconv_status_t launch_tile_bwd_t(const TileBwdArgs& a, int grid, int threads, size_t lds,
                                         hipStream_t stream) {
+#define GCONV_TILE_BWD_LAUNCH(NORM_, DX_, NT_)                                       \
+  do {                                                                               \
+    GCONV_TILE_LDS_OPT_IN((tile_bwd_kernel<FP, NQ, NORM_, DX_, NT_>));               \
+    tile_bwd_kernel<FP, NQ, NORM_, DX_, NT_><<<grid, threads, lds, stream>>>(a);     \
+  } while (0)
+  // (without dX there is no streamed output: one policy)
   if (a.dis) {
-    if (a.dx) {
-      GCONV_TILE_LDS_OPT_IN((tile_bwd_kernel<FP, NQ, true, true>));
-      tile_bwd_kernel<FP, NQ, true, true><<<grid, threads, lds, stream>>>(a);
-    } else {
-      GCONV_TILE_LDS_OPT_IN((tile_bwd_kernel<FP, NQ, true, false>));
-      tile_bwd_kernel<FP, NQ, true, false><<<grid, threads, lds, stream>>>(a);
-    }
+    if (!a.dx) GCONV_TILE_BWD_LAUNCH(true, false, true);
+    else if (a.store_nt) GCONV_TILE_BWD_LAUNCH(true, true, true);
+    else GCONV_TILE_BWD_LAUNCH(true, true, false);
   } else {
-    if (a.dx) {
-      GCONV_TILE_LDS_OPT_IN((tile_bwd_kernel<FP, NQ, false, true>));
-      tile_bwd_kernel<FP, NQ, false, true><<<grid, threads, lds, stream>>>(a);
-    } else {
-      GCONV_TILE_LDS_OPT_IN((tile_bwd_kernel<FP, NQ, false, false>));
-      tile_bwd_kernel<FP, NQ, false, false><<<grid, threads, lds, stream>>>(a);
-    }
+    if (!a.dx) GCONV_TILE_BWD_LAUNCH(false, false, true);
+    else if (a.store_nt) GCONV_TILE_BWD_LAUNCH(false, true, true);
+    else GCONV_TILE_BWD_LAUNCH(false, true, false);
   }
+#undef GCONV_TILE_BWD_LAUNCH
   GCONV_LAUNCH_CHECK();
   return GCONV_OK;
 }
@@ -1111,6 +1117,23 @@ GCONV_TILE_DEFINE_FP(GCONV_TILE_ONLY_FP)
     default: return GCONV_E_UNSUPPORTED;                                                \
   }
 
+// Odd workgroups walk their tiles smallest first (tile_order_index): only with at least two passes.
+// GCONV_TILE_STAGGER=0 / 1 forces it off / on (A/B knob, read once).
+static int tile_stagger(int n_tiles, int grid) {
+  static const char* v = getenv("GCONV_TILE_STAGGER");
+  const int mode = v ? atoi(v) : GCONV_TILE_STAGGER_DEFAULT;   // 0 off, 1 odd workgroups reversed, k > 1: k groups, rotated
+  return n_tiles >= 2 * grid ? mode : 0;
+}
+
+// Output rows (out, dX) non-temporal? One tile per workgroup (a 512-molecule shard): yes, as since round 1. Two or
+// more passes (the whole 4096-molecule batch): default policy — the step runs 3 - 4 % faster (the next kernel reads
+// these rows; the kernel ALONE is slower that way, which is what round 1 measured). GCONV_TILE_STORE_NT=0 / 1 forces.
+static int tile_store_nt(int n_tiles, int grid) {
+  static const char* v = getenv("GCONV_TILE_STORE_NT");
+  if (v) return v[0] == '1';
+  return n_tiles >= 2 * grid ? 0 : 1;
+}
+
 int tile_grid(int n_tiles) {  // persistent: one workgroup per CU
   const int kMax = launch_cus() * (GCONV_TILE_WGPC >= 2 ? 2 : 1);
   return n_tiles < kMax ? (n_tiles > 0 ? n_tiles : 1) : kMax;
@@ -1121,12 +1144,8 @@ gconv_status_t launch_tile_fwd(TileFwdArgs a, int n_tiles, int tile_nodes_max,
   const int nq = tile_nq(a.d);
   a.n_tiles = n_tiles;
   n_tiles = tile_grid(n_tiles);
-  // The dynamic deal is a lab knob (GCONV_TILE_DYNAMIC_DEAL=1): measured in round 5 on the whole 4096-molecule
-  // batch, it changes neither the kernel alone (61.9 against 62.2 us) nor the step next to the graph build of the
-  // next batch (1.0112 against 1.0111 ms; 0.8905 with one cached plan) — the build's kernels slow every tile
-  // workgroup alike, they do not delay some of them (LAB.md). One tile per workgroup: nothing to deal anyway.
-  static const bool dynamic_deal = getenv("GCONV_TILE_DYNAMIC_DEAL") != nullptr;
-  if (a.n_tiles <= n_tiles || !dynamic_deal) a.sync = nullptr;
+  a.stagger = tile_stagger(a.n_tiles, n_tiles);
+  a.store_nt = tile_store_nt(a.n_tiles, n_tiles);
   a.cap = ceil_div(tile_nodes_max > 0 ? tile_nodes_max : 1, 16) * 16;
   const size_t lds = tile_lds_bytes(a.d, a.fp, tile_nodes_max, tile_edges_max);
   const int threads = tile_threads_fwd(a.d, a.fp);
@@ -1138,6 +1157,8 @@ gconv_status_t launch_tile_bwd(TileBwdArgs a, int n_tiles, int tile_nodes_max,
   const int nq = tile_nq(a.d);
   a.n_tiles = n_tiles;
   n_tiles = tile_grid(n_tiles);
+  a.stagger = tile_stagger(a.n_tiles, n_tiles);
+  a.store_nt = tile_store_nt(a.n_tiles, n_tiles);
   a.cap = ceil_div(tile_nodes_max > 0 ? tile_nodes_max : 1, 16) * 16;
   const size_t lds = tile_lds_bytes(a.d, a.fp, tile_nodes_max, tile_edges_max);
   const int threads = tile_threads_bwd(a.d);

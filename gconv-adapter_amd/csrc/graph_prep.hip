@@ -179,41 +179,6 @@ __global__ void sym_check_kernel(const int32_t* __restrict__ rowptr,
 }
 
 // ---------------------------------------------------------------------------
-// Ticket words of the fused tile kernels' dynamic deal (gconv_graph_t::tile_sync): 16 words per plan out of a
-// per-device pool the library allocates (and zeroes) once; a kernel leaves its word at zero again, so a slot can
-// be handed to the 4096th plan after this one without any clearing. Not part of the caller's arena: the four
-// builders (single workgroup, counting, radix, assembly from a resident dataset) write every arena byte they
-// own and none of them would have to know about it. nullptr if the allocation fails (static deal).
-// ---------------------------------------------------------------------------
-int32_t* tile_sync_take() {
-  constexpr uint32_t kSlots = 4096, kWords = 16;
-  struct Pool { std::atomic<int32_t*> base{nullptr}; std::atomic<uint32_t> next{0}; bool failed = false; };
-  static Pool pools[64];
-  static std::mutex mu;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  Pool& p = pools[dev];
-  int32_t* base = p.base.load(std::memory_order_acquire);
-  if (!base) {
-    std::lock_guard<std::mutex> lock(mu);
-    base = p.base.load(std::memory_order_relaxed);
-    if (!base && !p.failed) {
-      void* mem = nullptr;
-      if (hipMalloc(&mem, kSlots * kWords * sizeof(int32_t)) != hipSuccess ||
-          hipMemset(mem, 0, kSlots * kWords * sizeof(int32_t)) != hipSuccess) {
-        (void)hipGetLastError();
-        p.failed = true;
-        return nullptr;
-      }
-      base = static_cast<int32_t*>(mem);
-      p.base.store(base, std::memory_order_release);
-    }
-    if (!base) return nullptr;
-  }
-  return base + kWords * (p.next.fetch_add(1, std::memory_order_relaxed) % kSlots);
-}
-
-// ---------------------------------------------------------------------------
 // arena layout
 // ---------------------------------------------------------------------------
 struct CsrSlots {
@@ -1210,7 +1175,6 @@ extern "C" gconv_status_t gconv_graph_build_ex(const int64_t* edge_index, int64_
     g->n_tiles = (h[INFO_NOTILE] || n == 0) ? 0 : L.ntiles;
     g->tile_nodes_max = h[INFO_TILEMAX];
     g->tile_edges_max = h[INFO_TILEEDGES];
-    g->tile_sync = tile_sync_take();
   };
   CountState* cs_small = small_build_ok(E, n) ? usable_state(false) : nullptr;
   if (cs_small) {   // ONE launch, counters straight into pinned memory (see small_graph_build_kernel)

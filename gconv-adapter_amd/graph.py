@@ -142,18 +142,6 @@ class GraphPlan:
             self._sizes[("infer", d, r)] = hit
         return hit
 
-    def tile_sync_words(self) -> Optional[torch.Tensor]:
-        """The plan's 16 ticket words (``gconv_graph_t::tile_sync``, library-owned device memory) copied to the
-        host — all zero whenever no fused tile kernel of this plan is in flight (tests); None without them."""
-        ptr = self.struct.tile_sync
-        if not ptr:
-            return None
-        buf = (C.c_int32 * 16)()
-        rc = C.CDLL("libamdhip64.so").hipMemcpy(buf, C.c_void_p(ptr), C.c_size_t(64), 2)   # hipMemcpyDeviceToHost
-        if rc != 0:
-            raise RuntimeError(f"hipMemcpy of the ticket words failed ({rc})")
-        return torch.tensor(list(buf), dtype=torch.int32)
-
     def ref(self):
         return self._ref
 

@@ -174,15 +174,6 @@ typedef struct gconv_graph {
   int32_t        normalize;
   int32_t        max_degree;     /* of `fwd`                                            */
   int32_t        bad_index;      /* 1 if an edge endpoint was outside [0, num_nodes)    */
-  int32_t*       tile_sync;      /* 16 words of LIBRARY-owned device memory (not in the arena; a slot of a
-                                  * per-device pool, handed out by the graph build) that read 0 between
-                                  * launches: word 0 = the fused forward kernel's tile ticket, word 4 = the
-                                  * backward kernel's (dynamic tile deal: a persistent workgroup takes the next
-                                  * unclaimed tile of the size-sorted list instead of a fixed share; the last
-                                  * ticket's owner puts the word back to 0). NULL (pool allocation failed, or a
-                                  * struct filled by hand): static deal. Like `long_sync`, the words belong to ONE
-                                  * launch at a time: launches that use the same plan must be ordered (one
-                                  * stream, or events) — PyTorch's forward / backward on one stream are.   */
 } gconv_graph_t;
 
 /* Bytes of device memory gconv_graph_build needs (outputs + scratch, upper bound). */
