@@ -186,7 +186,12 @@ __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirs
 // multiplies a 4-vector by 64 per-lane scalars: M = 4 wastes nothing at rank 4 or 8, where the
 // 16x16x4 form pads the rank dimension to 16.
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+#ifdef GCONV_LAB_NO_MFMA   // lab build (wrong results): one fma keeps the operands live, the matrix pipe stays idle —
+  c[0] += a * b;           // the upper bound of what ANY cheaper matrix arithmetic could return (LAB.md, round 5)
+  return c;
+#else
   return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+#endif
 }
 
 // Wave index inside the workgroup as a provably wave-uniform (SGPR) value. Without the
@@ -200,7 +205,12 @@ __device__ __forceinline__ int wave_id() {
 //   A: lane l holds A[l & 15][l >> 4];  B: lane l holds B[l >> 4][l & 15]
 //   D: lane l, reg m holds D[4 * (l >> 4) + m][l & 15]
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+#ifdef GCONV_LAB_NO_MFMA
+  c[0] += a * b;
+  return c;
+#else
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
 }
 
 }  // namespace gconv

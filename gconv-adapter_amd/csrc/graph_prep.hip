@@ -1026,7 +1026,8 @@ static CountState* usable_state(bool device_block) {
 //                    one-tile-per-CU kernels of the step a second round more often than a dozen 2 - 5 us kernels do
 //   fused            the narrow grid with its two barriers in one launch: 48 us per plan, 0.222 ms/step
 struct CountPlan { int grid; bool split, cooperative; };
-static CountPlan count_plan(bool background) {
+constexpr int32_t kBgSplitMinNodes = 1 << 16;   // background builds of graphs this large: the split counting builder
+static CountPlan count_plan(bool background, int32_t num_nodes) {
   struct Caps { int wide = -1, narrow = -1; };
   static Caps caps[16];
   static std::mutex mu;
@@ -1053,7 +1054,13 @@ static CountPlan count_plan(bool background) {
   const char* bg = std::getenv("GCONV_BG_BUILD");   // (read per call: bench A/B)
   if (background) {
     if (bg && bg[0] == 's') return {kCountGridNarrow, true, false};   // split launches need no co-residency at all
+    if (bg && bg[0] == 'w') return {kCountGrid, true, false};         // lab: the same three launches, 256 short-lived workgroups each
     if (bg && bg[0] == 'f') return {caps[dev].narrow ? kCountGridNarrow : 0, false, coop};
+    // Round 5, next to the whole 4096-molecule batch's step (103 k nodes; tools/lab/r05_bg.sh, one box, medians over 4 s):
+    // radix pipeline 0.9637 ms/step, the counting builder as three narrow launches 0.9400, three wide ones 0.9490, one
+    // narrow launch 0.9626 (0.8459 with one cached plan); next to the 512-molecule shard's step the radix pipeline
+    // stays the best neighbour (0.2157 against 0.2231 / 0.2398 / 0.2303). Hence by size (GCONV_BG_BUILD=radix forces).
+    if (!(bg && bg[0] == 'r') && num_nodes >= kBgSplitMinNodes) return {kCountGridNarrow, true, false};
     return {0, false, false};                          // radix pipeline (measured: least disturbance, see above)
   }
   if (caps[dev].wide) return {kCountGrid, false, coop};
@@ -1235,7 +1242,7 @@ extern "C" gconv_status_t gconv_graph_build_ex(const int64_t* edge_index, int64_
   // Which one-launch builder this device and this call can take (count_plan): the wide grid in-stream when
   // every workgroup can be resident at once, the narrow one as three barrier-free launches next to other
   // kernels (GCONV_BUILD_BACKGROUND), none on a device too small for either -> the radix pipeline.
-  const CountPlan cp = counting_build_ok(E, n) ? count_plan((flags & GCONV_BUILD_BACKGROUND) != 0) : CountPlan{0, false, false};
+  const CountPlan cp = counting_build_ok(E, n) ? count_plan((flags & GCONV_BUILD_BACKGROUND) != 0, n) : CountPlan{0, false, false};
   CountState* cs = cp.grid > 0 ? usable_state(true) : nullptr;
   if (cs) {   // one launch (see counting_build_kernel)
     std::lock_guard<std::mutex> lock(cs->mu);
@@ -1253,7 +1260,8 @@ extern "C" gconv_status_t gconv_graph_build_ex(const int64_t* edge_index, int64_
     if (cp.split) {          // a launch per phase: nothing waits inside a kernel
       for (int ph = 1; ph <= 4; ph <<= 1) {
         a.phases = ph;
-        counting_build_kernel<kCountGridNarrow><<<kCountGridNarrow, kCountThreads, 0, stream>>>(a);
+        if (cp.grid == kCountGrid) counting_build_kernel<kCountGrid><<<kCountGrid, kCountThreads, 0, stream>>>(a);
+        else counting_build_kernel<kCountGridNarrow><<<kCountGridNarrow, kCountThreads, 0, stream>>>(a);
       }
     } else {
       a.phases = 7;
