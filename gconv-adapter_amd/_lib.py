@@ -111,6 +111,7 @@ class AdapterParams(C.Structure):
         ("rank", C.c_int32),
         ("act", C.c_int32),
         ("skip", C.c_int32),
+        ("walk", C.c_int32),
     ]
 
 

@@ -116,6 +116,11 @@ class GConvAdapter(nn.Module):
         #: Set False for ``torch.autograd.grad(..., parameters)`` or autograd hooks on the
         #: parameters (DistributedDataParallel).
         self.direct_param_grads = DIRECT_PARAM_GRADS
+        #: ``gconv_adapter_params_t::walk`` of this module's kernels: None = alternate with the adapter calls on a
+        #: batch's graph plan (consecutive adapters of a model forward get 0, 1, 0, ...), 0 / 1 = fixed. Only the
+        #: order in which a batch of >= 512 tiles is walked: `out` and dX do not depend on it, parameter gradients
+        #: within fp32 summation error (set it when a call must reproduce its bits whatever ran before it)
+        self.walk = None
 
         # near-identity init (reference :73-78)
         nn.init.normal_(self.conv_down.lin.weight, mean=0.0, std=1e-5)
@@ -142,6 +147,9 @@ class GConvAdapter(nn.Module):
             self.__dict__["_flat_params"] = p
         ext = _torch_ext.get()
         sc = p[4] if fuse_scalar else None
+        # which half of the fused kernels' persistent workgroups walks its tiles smallest-first: alternates between
+        # the consecutive adapter calls of a model forward (gconv_adapter_params_t::walk; `self.walk` pins it)
+        walk = plan.next_walk() if self.walk is None else int(self.walk) & 1
         # Nothing records a graph (the reference's evaluation passes run under torch.no_grad(),
         # finetune_inductive_learning.py:95-104; or no input of the call requires a gradient): the
         # forward-only entry point — same bits in `out`, no saved tensors allocated or written
@@ -149,7 +157,7 @@ class GConvAdapter(nn.Module):
                                                or p[2].requires_grad or p[3].requires_grad
                                                or (sc is not None and sc.requires_grad)):
             if ext is None:
-                return adapter_infer(x2d, p[0], p[1], p[2], p[3], sc, plan, p[5], bool(self.skip_connection))
+                return adapter_infer(x2d, p[0], p[1], p[2], p[3], sc, plan, p[5], bool(self.skip_connection), walk)
             dev = x2d.device
             if dev.index != torch.cuda.current_device():
                 torch.cuda.set_device(dev)
@@ -157,11 +165,11 @@ class GConvAdapter(nn.Module):
             plan.sizes(lib, self.hidden_size, self.bottleneck_size)   # (validates the rank)
             return ext.adapter_infer(x2d, p[0], p[1], p[2], p[3], sc, plan.arena, plan.struct_addr,
                                      plan.infer_bytes(lib, self.hidden_size, self.bottleneck_size), p[5],
-                                     bool(self.skip_connection), _stream(dev.index))
+                                     bool(self.skip_connection), _stream(dev.index), walk)
         if ext is None:   # pure-Python binding of the same C ABI
             return GConvAdapterFunction.apply(x2d, p[0], p[1], p[2], p[3],
                                               p[4] if fuse_scalar else None, plan, p[5],
-                                              bool(self.skip_connection))
+                                              bool(self.skip_connection), walk)
         dev = x2d.device
         if dev.index != torch.cuda.current_device():
             torch.cuda.set_device(dev)
@@ -176,10 +184,10 @@ class GConvAdapter(nn.Module):
                 anchor = p[0] if p[0].requires_grad else next(
                     (q for q in p[1:5] if q is not None and q.requires_grad), None)
                 return ext.adapter_apply_direct(x2d, anchor, pack, plan.arena, plan.struct_addr, fp, ws_fwd,
-                                                ws_bwd, p[5], bool(self.skip_connection), _stream(dev.index))
+                                                ws_bwd, p[5], bool(self.skip_connection), _stream(dev.index), walk)
         return ext.adapter_apply(x2d, p[0], p[1], p[2], p[3], p[4] if fuse_scalar else None,
                                  plan.arena, plan.struct_addr, fp, ws_fwd, ws_bwd, p[5],
-                                 bool(self.skip_connection), _stream(dev.index))
+                                 bool(self.skip_connection), _stream(dev.index), walk)
 
     def _param_pack(self, ext, p, fuse_scalar: bool):
         """Handle of the C++ ParamPack for direct gradient deposit, or None when a parameter

@@ -264,6 +264,7 @@ static gconv_status_t adapter_forward(const gconv_graph_t* gr, const gconv_adapt
     t.x = x; t.out = out; t.saved_h = saved_h; t.saved_h1 = saved_h1; t.saved_p = saved_p;
     t.w_down = p->w_down; t.b_down = p->b_down; t.w_up = p->w_up; t.b_up = p->b_up;
     t.scalar = p->scalar; t.d = d; t.r = r; t.fp = fp; t.act = p->act; t.skip = p->skip;
+    t.stagger = p->walk & 1;
 #ifdef GCONV_TILE_STAMPS
     t.stamps = static_cast<long long*>(workspace);   // diagnostic build: workspace = stamp buffer
 #endif
@@ -431,6 +432,7 @@ static gconv_status_t adapter_bwd(const gconv_graph_t* gr, const gconv_adapter_p
     t.part_wd = tw.part_wd; t.part_wu = tw.part_wu; t.part_cs = tw.part_cs;
     t.part_bd = tw.part_bd; t.part_ds = tw.part_ds;
     t.d = d; t.r = r; t.fp = fp; t.act = p->act; t.skip = p->skip;
+    t.stagger = (p->walk & 1) ^ 1;   // the backward takes the half the forward did not (gconv_adapter_params_t::walk)
     t.want_ds = grad_scalar != nullptr;
 #ifdef GCONV_TILE_STAMPS
     t.stamps = reinterpret_cast<long long*>(static_cast<char*>(workspace) + tw.bytes);

@@ -12,7 +12,7 @@ struct TileFwdArgs {
   const float* w_down; const float* b_down; const float* w_up; const float* b_up;
   const float* scalar;
   int d, r, fp, act, skip, cap, n_tiles, n;   // n = nodes of the graph (rows of x)
-  int stagger;   // odd workgroups walk their tiles smallest first (set by the launcher)
+  int stagger;   // in: the caller's walk bit (0 / 1); the launcher turns it into the kernels' mode (0, +1, -1)
   int store_nt;  // output rows with non-temporal stores (set by the launcher: tile_store_nt)
   long long* stamps;   // diagnostic build only (-DGCONV_TILE_STAMPS, tools/tilestamps.py)
 };

@@ -24,6 +24,7 @@
 // path (adapter.hip); replaces /root/reference/src/finetune/gconv_adapter.py:80-108 and
 // its autograd backward for the batches the inductive script feeds it
 // (scripts/finetune_inductive_learning.py:43-67).
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -165,15 +166,16 @@ __device__ __forceinline__ TileView tile_view(const gconv_tile_t* tiles, int idx
 
 // Entry of the size-sorted tile list that workgroup w = blockIdx.x runs in pass `pass` of `npass`, or -1 (the ragged
 // last pass has no tile for some workgroups). Boustrophedon: even passes deal forwards, odd passes backwards.
-// `stagger`: odd workgroups take THEIR passes in the opposite order (their smallest tile first).
+// `stagger` (+1 / -1, 0 = off): HALF the workgroups (the odd / the even ones) take THEIR passes in the opposite order,
+// smallest tile first — the chip's workgroups are then not all in the same phase of equally large tiles (round 5, in the
+// step: -3.4 ... -3.8 %; rotated starts in 2 or 4 groups, or other choices of the half, did no better:
+// profiles/r05_lab_tile_step_policies.txt). Which half alternates between consecutive adapters of a model
+// (gconv_adapter_params_t::walk), so that a workgroup starts a kernel with the tile it ended the previous kernel with.
 __device__ __forceinline__ int tile_order_index(int pass, int npass, int n_tiles, int stagger) {
   const int G = gridDim.x, w = blockIdx.x;
   int p = pass;
-  if (stagger == 1) p = (w & 1) ? npass - 1 - pass : pass;                       // odd workgroups (= odd XCDs): smallest first
-  else if (stagger == 3) p = ((w >> 3) & 1) ? npass - 1 - pass : pass;          // lab: every other workgroup of an XCD
-  else if (stagger == 5) p = ((w >> 4) & 1) ? npass - 1 - pass : pass;          // lab: pairs of workgroups of an XCD
-  else if (stagger == 7) p = ((w ^ (w >> 3)) & 1) ? npass - 1 - pass : pass;    // lab: checkerboard over (XCD, slot)
-  else if (stagger > 1) p = (pass + (w % stagger) * npass / stagger) % npass;   // `stagger` groups, rotated starts
+  if (stagger == 1) p = (w & 1) ? npass - 1 - pass : pass;          // odd workgroups: smallest tile first
+  else if (stagger == -1) p = (w & 1) ? pass : npass - 1 - pass;   // the other half (gconv_adapter_params_t::walk)
   const int idx = (p & 1) ? (p + 1) * G - 1 - w : p * G + w;
   return idx < n_tiles ? idx : -1;
 }
@@ -1117,12 +1119,14 @@ GCONV_TILE_DEFINE_FP(GCONV_TILE_ONLY_FP)
     default: return GCONV_E_UNSUPPORTED;                                                \
   }
 
-// Odd workgroups walk their tiles smallest first (tile_order_index): only with at least two passes.
-// GCONV_TILE_STAGGER=0 / 1 forces it off / on (A/B knob, read once).
-static int tile_stagger(int n_tiles, int grid) {
+// Half the workgroups walk their tiles smallest first (tile_order_index), with at least two passes only; `walk`
+// (gconv_adapter_params_t::walk for the forward, its complement for the backward) picks the half.
+// GCONV_TILE_STAGGER=0 switches it off (A/B knob, read once).
+static int tile_stagger(int n_tiles, int grid, int walk) {
   static const char* v = getenv("GCONV_TILE_STAGGER");
-  const int mode = v ? atoi(v) : GCONV_TILE_STAGGER_DEFAULT;   // 0 off, 1 odd workgroups reversed, k > 1: k groups, rotated
-  return n_tiles >= 2 * grid ? mode : 0;
+  const int mode = v ? atoi(v) : GCONV_TILE_STAGGER_DEFAULT;
+  if (mode == 0 || n_tiles < 2 * grid) return 0;
+  return walk ? -1 : 1;
 }
 
 // Output rows (out, dX) non-temporal? One tile per workgroup (a 512-molecule shard): yes, as since round 1. Two or
@@ -1144,7 +1148,7 @@ gconv_status_t launch_tile_fwd(TileFwdArgs a, int n_tiles, int tile_nodes_max,
   const int nq = tile_nq(a.d);
   a.n_tiles = n_tiles;
   n_tiles = tile_grid(n_tiles);
-  a.stagger = tile_stagger(a.n_tiles, n_tiles);
+  a.stagger = tile_stagger(a.n_tiles, n_tiles, a.stagger);   // (in: the caller's walk bit)
   a.store_nt = tile_store_nt(a.n_tiles, n_tiles);
   a.cap = ceil_div(tile_nodes_max > 0 ? tile_nodes_max : 1, 16) * 16;
   const size_t lds = tile_lds_bytes(a.d, a.fp, tile_nodes_max, tile_edges_max);
@@ -1157,7 +1161,7 @@ gconv_status_t launch_tile_bwd(TileBwdArgs a, int n_tiles, int tile_nodes_max,
   const int nq = tile_nq(a.d);
   a.n_tiles = n_tiles;
   n_tiles = tile_grid(n_tiles);
-  a.stagger = tile_stagger(a.n_tiles, n_tiles);
+  a.stagger = tile_stagger(a.n_tiles, n_tiles, a.stagger);   // (in: the caller's walk bit)
   a.store_nt = tile_store_nt(a.n_tiles, n_tiles);
   a.cap = ceil_div(tile_nodes_max > 0 ? tile_nodes_max : 1, 16) * 16;
   const size_t lds = tile_lds_bytes(a.d, a.fp, tile_nodes_max, tile_edges_max);

@@ -176,7 +176,7 @@ struct AdapterFn : public torch::autograd::Function<AdapterFn> {
                             c10::optional<at::Tensor> b_down_, at::Tensor w_up,
                             c10::optional<at::Tensor> b_up_, c10::optional<at::Tensor> scalar_,
                             at::Tensor arena, int64_t graph_addr, int64_t fp, int64_t ws_fwd,
-                            int64_t ws_bwd, int64_t act, bool skip, int64_t stream) {
+                            int64_t ws_bwd, int64_t act, bool skip, int64_t stream, int64_t walk) {
     // optional parameters travel as c10::optional (an undefined Tensor is not a legal
     // autograd input); inside they are plain, possibly undefined, tensors
     at::Tensor b_down = b_down_.value_or(at::Tensor()), b_up = b_up_.value_or(at::Tensor()),
@@ -198,11 +198,12 @@ struct AdapterFn : public torch::autograd::Function<AdapterFn> {
     float* sv = saved.data_ptr<float>();
     gconv_adapter_params_t p{fptr(w_down), fptr(b_down), fptr(w_up), fptr(b_up), fptr(scalar),
                              static_cast<int32_t>(d), static_cast<int32_t>(r),
-                             static_cast<int32_t>(act), skip ? 1 : 0};
+                             static_cast<int32_t>(act), skip ? 1 : 0, static_cast<int32_t>(walk)};
     check(g_lib.fwd(&g, &p, x.data_ptr<float>(), out.data_ptr<float>(), sv,
                     act == GCONV_ACT_SILU ? sv + 2 * n * fp : nullptr, sv + n * fp, ws.data_ptr(),
                     static_cast<size_t>(ws_fwd), reinterpret_cast<void*>(stream)),
           "adapter_fwd");
+    ctx->saved_data["walk"] = walk;
     ctx->save_for_backward({x, w_down, b_down, w_up, b_up, scalar, saved, arena});
     ctx->saved_data["g"] = std::string(reinterpret_cast<const char*>(&g), sizeof(g));
     ctx->saved_data["fp"] = fp;
@@ -238,7 +239,8 @@ struct AdapterFn : public torch::autograd::Function<AdapterFn> {
     const float* svp = saved.data_ptr<float>();
     gconv_adapter_params_t p{fptr(w_down), fptr(b_down), fptr(w_up), fptr(b_up), fptr(scalar),
                              static_cast<int32_t>(d), static_cast<int32_t>(r),
-                             static_cast<int32_t>(act), skip ? 1 : 0};
+                             static_cast<int32_t>(act), skip ? 1 : 0,
+                             static_cast<int32_t>(ctx->saved_data["walk"].toInt())};
     check(g_lib.bwd(&g, &p, x.data_ptr<float>(), go.data_ptr<float>(), svp,
                     act == GCONV_ACT_SILU ? svp + 2 * n * fp : nullptr, svp + n * fp,
                     fptr_mut(gx), gwd.data_ptr<float>(), fptr_mut(gbd), gwu.data_ptr<float>(),
@@ -246,7 +248,7 @@ struct AdapterFn : public torch::autograd::Function<AdapterFn> {
                     reinterpret_cast<void*>(stream)),
           "adapter_bwd");
     at::Tensor none;
-    return {gx, gwd, gbd, gwu, gbu, gsc, none, none, none, none, none, none, none, none};
+    return {gx, gwd, gbd, gwu, gbu, gsc, none, none, none, none, none, none, none, none, none};
   }
 };
 
@@ -471,7 +473,7 @@ struct AdapterFnDirect : public torch::autograd::Function<AdapterFnDirect> {
   static at::Tensor forward(torch::autograd::AutogradContext* ctx, at::Tensor x,
                             c10::optional<at::Tensor> anchor, int64_t pack_id, at::Tensor arena,
                             int64_t graph_addr, int64_t fp, int64_t ws_fwd, int64_t ws_bwd, int64_t act,
-                            bool skip, int64_t stream) {
+                            bool skip, int64_t stream, int64_t walk) {
     // `anchor` is the module's W_down: a real edge to a parameter's grad accumulator keeps the node
     // alive when x needs no gradient AND puts it on the path of backward(inputs=parameters); its
     // gradient slot stays undefined (the accumulator is a no-op), the deposit happens below.
@@ -494,14 +496,14 @@ struct AdapterFnDirect : public torch::autograd::Function<AdapterFnDirect> {
     float* sv = saved.data_ptr<float>();
     gconv_adapter_params_t p{fptr(pk->w_down), fptr(pk->b_down), fptr(pk->w_up), fptr(pk->b_up),
                              fptr(pk->scalar), static_cast<int32_t>(d), static_cast<int32_t>(r),
-                             static_cast<int32_t>(act), skip ? 1 : 0};
+                             static_cast<int32_t>(act), skip ? 1 : 0, static_cast<int32_t>(walk)};
     check(g_lib.fwd(&g, &p, x.data_ptr<float>(), out.data_ptr<float>(), sv,
                     act == GCONV_ACT_SILU ? sv + 2 * n * fp : nullptr, sv + n * fp, ws.data_ptr(),
                     static_cast<size_t>(ws_fwd), reinterpret_cast<void*>(stream)),
           "adapter_fwd");
     ctx->save_for_backward({x, saved, arena});
     ctx->saved_data["g"] = std::string(reinterpret_cast<const char*>(&g), sizeof(g));
-    ctx->saved_data["i"] = std::vector<int64_t>{pack_id, fp, ws_bwd, act, skip ? 1 : 0, stream};
+    ctx->saved_data["i"] = std::vector<int64_t>{pack_id, fp, ws_bwd, act, skip ? 1 : 0, stream, walk};
     return out;
   }
 
@@ -576,7 +578,7 @@ struct AdapterFnDirect : public torch::autograd::Function<AdapterFnDirect> {
     const float* svp = saved.data_ptr<float>();
     gconv_adapter_params_t p{fptr(pk->w_down), fptr(pk->b_down), fptr(pk->w_up), fptr(pk->b_up),
                              fptr(pk->scalar), static_cast<int32_t>(d), static_cast<int32_t>(r),
-                             static_cast<int32_t>(act), skip ? 1 : 0};
+                             static_cast<int32_t>(act), skip ? 1 : 0, static_cast<int32_t>(iv[6])};
     gconv_pending_finalize_t pend;
     check(g_lib.bwd_partial(&g, &p, x.data_ptr<float>(), go.data_ptr<float>(), svp,
                             act == GCONV_ACT_SILU ? svp + 2 * n * fp : nullptr, svp + n * fp,
@@ -586,7 +588,7 @@ struct AdapterFnDirect : public torch::autograd::Function<AdapterFnDirect> {
           "adapter_bwd");
     if (named && !any_wanted)
       return {gx, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
-              at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+              at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
     {
       std::lock_guard<std::mutex> lk(st->mu);
       if (!st->pending.empty() && st->stream != stream) flush_locked(*st);   // another stream: do not mix
@@ -601,24 +603,24 @@ struct AdapterFnDirect : public torch::autograd::Function<AdapterFnDirect> {
       queue_grad(pk->scalar, std::move(gsc), want[4], *st);
     }
     at::Tensor none;
-    return {gx, none, none, none, none, none, none, none, none, none, none};
+    return {gx, none, none, none, none, none, none, none, none, none, none, none};
   }
 };
 
 at::Tensor adapter_apply_direct(at::Tensor x, c10::optional<at::Tensor> anchor, int64_t pack_id,
                                 at::Tensor arena, int64_t graph_addr, int64_t fp, int64_t ws_fwd,
-                                int64_t ws_bwd, int64_t act, bool skip, int64_t stream) {
+                                int64_t ws_bwd, int64_t act, bool skip, int64_t stream, int64_t walk) {
   {
     const std::shared_ptr<ParamPack> pk = pack_get(pack_id);
     if (has_grad_observers(pk->w_down) || has_grad_observers(pk->b_down) || has_grad_observers(pk->w_up) ||
         has_grad_observers(pk->b_up) || has_grad_observers(pk->scalar)) {
       auto opt = [](const at::Tensor& t) { return t.defined() ? c10::optional<at::Tensor>(t) : c10::nullopt; };
       return AdapterFn::apply(x, pk->w_down, opt(pk->b_down), pk->w_up, opt(pk->b_up), opt(pk->scalar), arena,
-                              graph_addr, fp, ws_fwd, ws_bwd, act, skip, stream);
+                              graph_addr, fp, ws_fwd, ws_bwd, act, skip, stream, walk);
     }
   }
   pack_get(pack_id)->ensure_accumulators();
-  return AdapterFnDirect::apply(x, anchor, pack_id, arena, graph_addr, fp, ws_fwd, ws_bwd, act, skip, stream);
+  return AdapterFnDirect::apply(x, anchor, pack_id, arena, graph_addr, fp, ws_fwd, ws_bwd, act, skip, stream, walk);
 }
 
 // Forward only (gconv_adapter_infer_f32): no autograd node, no saved tensors — what GConvAdapter.forward calls under
@@ -627,7 +629,8 @@ at::Tensor adapter_apply_direct(at::Tensor x, c10::optional<at::Tensor> anchor, 
 // the duration of the call only: the launch is ordered on `stream` like every other use of the plan.
 at::Tensor adapter_infer(at::Tensor x, at::Tensor w_down, c10::optional<at::Tensor> b_down_, at::Tensor w_up,
                          c10::optional<at::Tensor> b_up_, c10::optional<at::Tensor> scalar_, at::Tensor arena,
-                         int64_t graph_addr, int64_t ws_bytes, int64_t act, bool skip, int64_t stream) {
+                         int64_t graph_addr, int64_t ws_bytes, int64_t act, bool skip, int64_t stream,
+                         int64_t walk) {
   at::Tensor b_down = b_down_.value_or(at::Tensor()), b_up = b_up_.value_or(at::Tensor()),
              scalar = scalar_.value_or(at::Tensor());
   TORCH_CHECK(g_lib.handle, "gconv_adapter_amd: library not loaded");
@@ -645,7 +648,7 @@ at::Tensor adapter_infer(at::Tensor x, at::Tensor w_down, c10::optional<at::Tens
   at::Tensor ws = forward_workspace(x, ws_bytes);
   gconv_adapter_params_t p{fptr(w_down), fptr(b_down), fptr(w_up), fptr(b_up), fptr(scalar),
                            static_cast<int32_t>(d), static_cast<int32_t>(r),
-                           static_cast<int32_t>(act), skip ? 1 : 0};
+                           static_cast<int32_t>(act), skip ? 1 : 0, static_cast<int32_t>(walk)};
   check(g_lib.infer(&g, &p, x.data_ptr<float>(), out.data_ptr<float>(), ws.data_ptr(), static_cast<size_t>(ws_bytes),
                     reinterpret_cast<void*>(stream)),
         "adapter_infer");
@@ -656,9 +659,9 @@ at::Tensor adapter_apply(at::Tensor x, at::Tensor w_down, c10::optional<at::Tens
                          at::Tensor w_up, c10::optional<at::Tensor> b_up,
                          c10::optional<at::Tensor> scalar, at::Tensor arena, int64_t graph_addr,
                          int64_t fp, int64_t ws_fwd, int64_t ws_bwd, int64_t act, bool skip,
-                         int64_t stream) {
+                         int64_t stream, int64_t walk) {
   return AdapterFn::apply(x, w_down, b_down, w_up, b_up, scalar, arena, graph_addr, fp, ws_fwd,
-                          ws_bwd, act, skip, stream);
+                          ws_bwd, act, skip, stream, walk);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1230,7 +1233,7 @@ at::Tensor adapter(const at::Tensor& x, const at::Tensor& w_down, const c10::opt
   const int64_t wsb = std::max<int64_t>(g_lib.ws_bwd(&g, static_cast<int32_t>(sh.d), static_cast<int32_t>(sh.r)), 16);
   c10::OptionalDeviceGuard guard(x.device());
   return AdapterFn::apply(x, w_down, b_down, w_up, b_up, scalar, arena, reinterpret_cast<int64_t>(plan.data_ptr()),
-                          sh.fp, wsf, wsb, act_code(act_), skip, reinterpret_cast<int64_t>(current_stream(x)));
+                          sh.fp, wsf, wsb, act_code(act_), skip, reinterpret_cast<int64_t>(current_stream(x)), 0);
 }
 
 }  // namespace ops

@@ -37,7 +37,8 @@ def _ptr(t) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def adapter_infer(x, w_down, b_down, w_up, b_up, scalar, plan: GraphPlan, act: int, skip: bool) -> torch.Tensor:
+def adapter_infer(x, w_down, b_down, w_up, b_up, scalar, plan: GraphPlan, act: int, skip: bool,
+                  walk: int = 0) -> torch.Tensor:
     """Forward only (``gconv_adapter_infer_f32``): what ``GConvAdapter.forward`` runs under ``torch.no_grad()``
     or when nothing that reaches it requires a gradient — the reference's evaluation passes
     (``/root/reference/scripts/finetune_inductive_learning.py:95-104``). Same bits in ``out`` as the training
@@ -58,7 +59,7 @@ def adapter_infer(x, w_down, b_down, w_up, b_up, scalar, plan: GraphPlan, act: i
     out = torch.empty_like(x)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     params = _lib.AdapterParams(w_down.data_ptr(), _ptr(b_down), w_up.data_ptr(), _ptr(b_up),
-                                _ptr(scalar), d, r, act, int(skip))
+                                _ptr(scalar), d, r, act, int(skip), int(walk))
     st = lib.gconv_adapter_infer_f32(plan.ref(), C.byref(params), x.data_ptr(), out.data_ptr(), ws.data_ptr(),
                                      ws_bytes, _stream(dev.index))
     if st != 0:
@@ -74,7 +75,7 @@ class GConvAdapterFunction(torch.autograd.Function):
     the plan, no device-guard context when the tensor already lives on the current device."""
 
     @staticmethod
-    def forward(ctx, x, w_down, b_down, w_up, b_up, scalar, plan: GraphPlan, act: int, skip: bool):
+    def forward(ctx, x, w_down, b_down, w_up, b_up, scalar, plan: GraphPlan, act: int, skip: bool, walk: int = 0):
         lib = _lib.load()
         if not x.is_cuda or x.dtype != torch.float32:
             _require_hip_f32(x, "x")
@@ -98,13 +99,13 @@ class GConvAdapterFunction(torch.autograd.Function):
         saved_h1 = saved[2] if act == 2 else None
         ws = torch.empty(ws_fwd, dtype=torch.uint8, device=dev)
         params = _lib.AdapterParams(w_down.data_ptr(), _ptr(b_down), w_up.data_ptr(), _ptr(b_up),
-                                    _ptr(scalar), d, r, act, int(skip))
+                                    _ptr(scalar), d, r, act, int(skip), int(walk))
         st = lib.gconv_adapter_fwd_f32(plan.ref(), C.byref(params), x.data_ptr(), out.data_ptr(),
                                        saved_h.data_ptr(), _ptr(saved_h1), saved_p.data_ptr(),
                                        ws.data_ptr(), ws_fwd, _stream(dev.index))
         if st != 0:
             _lib.check(st, "adapter_fwd")
-        ctx.plan, ctx.act, ctx.skip = plan, act, skip
+        ctx.plan, ctx.act, ctx.skip, ctx.walk = plan, act, skip, int(walk)
         ctx.save_for_backward(x, w_down, b_down, w_up, b_up, scalar, saved)
         return out
 
@@ -132,14 +133,14 @@ class GConvAdapterFunction(torch.autograd.Function):
         gs = torch.empty_like(scalar) if scalar is not None else None
         ws = torch.empty(ws_bwd, dtype=torch.uint8, device=dev)
         params = _lib.AdapterParams(w_down.data_ptr(), _ptr(b_down), w_up.data_ptr(), _ptr(b_up),
-                                    _ptr(scalar), d, r, act, int(ctx.skip))
+                                    _ptr(scalar), d, r, act, int(ctx.skip), ctx.walk)
         st = lib.gconv_adapter_bwd_f32(plan.ref(), C.byref(params), x.data_ptr(), g.data_ptr(),
                                        saved_h.data_ptr(), _ptr(saved_h1), saved_p.data_ptr(),
                                        _ptr(gx), gwd.data_ptr(), _ptr(gbd), gwu.data_ptr(),
                                        _ptr(gbu), _ptr(gs), ws.data_ptr(), ws_bwd, _stream(dev.index))
         if st != 0:
             _lib.check(st, "adapter_bwd")
-        return gx, gwd, gbd, gwu, gbu, gs, None, None, None
+        return gx, gwd, gbd, gwu, gbu, gs, None, None, None, None
 
 
 def gconv_adapter(x: torch.Tensor, plan: GraphPlan, w_down, b_down, w_up, b_up,

@@ -120,6 +120,7 @@ class GraphPlan:
         self._ref = C.byref(self.struct)
         self.struct_addr = C.addressof(self.struct)
         self._sizes = {}
+        self._walk = 0
 
     def sizes(self, lib, d: int, r: int):
         """(padded rank, forward workspace bytes, backward workspace bytes) for hidden d and
@@ -133,6 +134,14 @@ class GraphPlan:
                    max(int(lib.gconv_adapter_bwd_workspace_bytes(self._ref, d, r)), 16))
             self._sizes[(d, r)] = hit
         return hit
+
+    def next_walk(self) -> int:
+        """``gconv_adapter_params_t::walk`` for the next adapter call on this plan: 0, 1, 0, 1, ... in call order, so
+        that consecutive adapters of a model forward alternate (a training batch has a fresh plan: adapter k of the
+        model gets k & 1 every step). ``GConvAdapter.walk = 0 | 1`` pins it per module instead."""
+        w = self._walk
+        self._walk = w ^ 1
+        return w
 
     def infer_bytes(self, lib, d: int, r: int) -> int:
         """Workspace bytes of the forward-only call (``gconv_adapter_infer_f32``) — cached like ``sizes``."""

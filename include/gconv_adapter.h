@@ -277,6 +277,15 @@ typedef struct gconv_adapter_params {
   int32_t rank;         /* r, 1..64                                           */
   int32_t act;          /* GCONV_ACT_*                                        */
   int32_t skip;         /* skip_connection                                    */
+  int32_t walk;         /* 0 / 1: which half of the fused tile kernels' persistent workgroups walks its tiles
+                         * smallest-first (batches with two or more tiles per workgroup; ignored otherwise).
+                         * Pass the SAME value to the forward and the backward call of an adapter (the backward
+                         * takes the other half itself) and ALTERNATE it between consecutive adapters of a model:
+                         * every workgroup then starts a kernel with the tile it ended the previous one with —
+                         * the rows written last are read first (round 5: whole 4096-molecule batch, 5 chained
+                         * adapters, -2.5 % per step). Results: `out` and grad_x do not depend on it; a parameter
+                         * gradient is a sum of per-workgroup partials whose tiles are added in walk order — same
+                         * bits for the same `walk`, equal within fp32 summation error otherwise.  (ABI 10)  */
 } gconv_adapter_params_t;
 
 size_t gconv_adapter_fwd_workspace_bytes(const gconv_graph_t* graph, int32_t hidden, int32_t rank);

@@ -132,55 +132,42 @@ def test_forward_only_through_the_ctypes_binding_and_the_c_abi(dev):
         int(lib.gconv_adapter_fwd_workspace_bytes(mplan.ref(), mcfg["d"], mcfg["r"]))
 
 
-_ORDER_SCRIPT = r"""
-import sys, torch
-sys.path.insert(0, {root!r})
-import gconv_adapter_amd as ga
-dev = torch.device("cuda:0")
-b = ga.synth.molecule_batch("hiv", 2700, hidden=300, seed=7)
-m = ga.GConvAdapter(300, 8, learnable_scalar=True).to(dev)
-g = torch.Generator().manual_seed(0)
-with torch.no_grad():
-    for p in m.parameters():
-        p.copy_((torch.randn(p.shape, generator=g) * 0.1).to(dev))
-ei = b.edge_index.to(dev)
-assert ga.get_plan(ei, b.num_nodes, True).n_tiles >= 512      # at least two passes: the order knob engages
-x = b.x.to(dev).requires_grad_(True)
-out = m(x, ei)
-out.backward(torch.randn(out.shape, generator=g).to(dev))
-first = (out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in m.parameters()])
-gout = torch.randn(out.shape, generator=torch.Generator().manual_seed(1)).to(dev)
-again = []
-for _ in range(3):                                              # the same bits every launch
-    x.grad = None
-    for p in m.parameters():
-        p.grad = None
-    o = m(x, ei)
-    o.backward(gout)
-    again.append((o.detach().clone(), x.grad.clone(), [p.grad.clone() for p in m.parameters()]))
-assert all(torch.equal(a[0], again[0][0]) and torch.equal(a[1], again[0][1]) and
-           all(torch.equal(u, v) for u, v in zip(a[2], again[0][2])) for a in again[1:])
-assert torch.equal(again[0][0], first[0])
-torch.save({{"out": first[0].cpu(), "dx": first[1].cpu(), **{{k: g.cpu() for (k, _), g in zip(m.named_parameters(), first[2])}}}}, sys.argv[1])
-"""
-
-
 @pytest.mark.skipif(bool(os.environ.get("GCONV_NO_TILE_PATH")), reason="about the fused tile kernels")
-def test_tile_walk_order_does_not_change_the_outputs(dev, tmp_path):
-    """Round 5: with two or more tiles per persistent workgroup, odd workgroups may walk their tiles smallest first
-    (GCONV_TILE_STAGGER=0 / 1, read at the first launch: two processes) so that the chip is not in one phase
-    everywhere. A tile's rows have one writer and its arithmetic does not depend on when it runs: `out` and dX are
-    bit-identical; the parameter gradients are sums of per-workgroup partials whose tiles are then added in another
-    order — equal at the parameter-gradient tolerance."""
+def test_tile_walk_order_does_not_change_the_outputs(dev):
+    """Round 5: with two or more tiles per persistent workgroup HALF the workgroups walk their tiles smallest first,
+    and `gconv_adapter_params_t::walk` picks the half (the forward's; the backward takes the other): consecutive
+    adapters alternate (`GraphPlan.next_walk`), so a workgroup starts a kernel with the tile it ended the previous
+    kernel with. A tile's rows have one writer and its arithmetic does not depend on when it runs: `out` and dX are
+    bit-identical for walk = 0 / 1; the parameter gradients are sums of per-workgroup partials whose tiles are then
+    added in another order — equal at the parameter-gradient tolerance, and bit-identical for the SAME walk."""
     from helpers import grad_atol
-    script = tmp_path / "order.py"
-    script.write_text(_ORDER_SCRIPT.format(root=ROOT))
-    res = {}
-    for tag in ("0", "1"):
-        out = tmp_path / f"s{tag}.pt"
-        subprocess.run([sys.executable, str(script), str(out)], check=True, timeout=600,
-                       env={**os.environ, "GCONV_TILE_STAGGER": tag})
-        res[tag] = torch.load(out)
-    assert torch.equal(res["0"]["out"], res["1"]["out"]) and torch.equal(res["0"]["dx"], res["1"]["dx"])
-    for k, v in res["0"].items():
-        assert_close(res["1"][k].double(), v.double(), k, atol=grad_atol(v.double()))
+    b = ga.synth.molecule_batch("hiv", 2700, hidden=300, seed=7)
+    ei = b.edge_index.to(dev)
+    plan = ga.get_plan(ei, b.num_nodes, True)
+    assert plan.n_tiles >= 512                                  # at least two passes: the order matters at all
+    mod = ga.GConvAdapter(300, 8, learnable_scalar=True).to(dev)
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.copy_((torch.randn(p.shape, generator=g) * 0.1).to(dev))
+    gout = torch.randn(b.num_nodes, 300, generator=g).to(dev)
+
+    def run(walk):
+        mod.walk = walk
+        x = b.x.to(dev).requires_grad_(True)
+        mod.zero_grad(set_to_none=True)
+        out = mod(x, ei)
+        out.backward(gout)
+        return {"out": out.detach(), "dx": x.grad, **{k: p.grad.clone() for k, p in mod.named_parameters()}}
+    r0, r1, r0b = run(0), run(1), run(0)
+    for k in r0:
+        assert torch.equal(r0[k], r0b[k]), f"{k}: not reproducible for the same walk"
+    assert torch.equal(r0["out"], r1["out"]) and torch.equal(r0["dx"], r1["dx"])
+    for k, v in r0.items():
+        assert_close(r1[k].double().cpu(), v.double().cpu(), k, atol=grad_atol(v.double().cpu()))
+    # automatic mode: the plan hands out 0, 1, 0, ... in call order
+    mod.walk = None
+    w0 = plan._walk
+    with torch.no_grad():
+        mod(b.x.to(dev), ei); mod(b.x.to(dev), ei)
+    assert plan._walk == w0 and plan.next_walk() == w0 and plan.next_walk() == w0 ^ 1

@@ -205,7 +205,7 @@ def test_cpp_autograd_binding_loads_and_binds_the_same_c_abi():
     # CPU tensors are refused by the binding as well (RuntimeError, no compute fallback)
     with pytest.raises(RuntimeError):
         ext.adapter_apply(torch.randn(2, 8), torch.randn(2, 8), None, torch.randn(8, 2), None, None,
-                          torch.zeros(1, dtype=torch.uint8), 0, 4, 16, 16, 1, True, 0)
+                          torch.zeros(1, dtype=torch.uint8), 0, 4, 16, 16, 1, True, 0, 0)
 
 
 def test_host_thread_pinning_helpers():
