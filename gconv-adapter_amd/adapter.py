@@ -146,26 +146,32 @@ class GConvAdapter(nn.Module):
                   self.conv_up._parameters, self._parameters))
             self.__dict__["_flat_params"] = p
         ext = _torch_ext.get()
-        sc = p[4] if fuse_scalar else None
         # which half of the fused kernels' persistent workgroups walks its tiles smallest-first: alternates between
-        # the consecutive adapter calls of a model forward (gconv_adapter_params_t::walk; `self.walk` pins it)
-        walk = plan.next_walk() if self.walk is None else int(self.walk) & 1
+        # the consecutive adapter calls of a model forward (gconv_adapter_params_t::walk; `self.walk` pins it).
+        # (This function is the host side of a ~15 us kernel: every attribute access here is measurable — 0.7 us of
+        # extra Python per call cost the 512-molecule step 2 % in round 5.)
+        walk = self.walk
+        if walk is None:
+            walk = plan._walk
+            plan._walk = walk ^ 1
         # Nothing records a graph (the reference's evaluation passes run under torch.no_grad(),
         # finetune_inductive_learning.py:95-104; or no input of the call requires a gradient): the
-        # forward-only entry point — same bits in `out`, no saved tensors allocated or written
-        if not torch.is_grad_enabled() or not (x2d.requires_grad or p[0].requires_grad or p[1].requires_grad
-                                               or p[2].requires_grad or p[3].requires_grad
-                                               or (sc is not None and sc.requires_grad)):
-            if ext is None:
-                return adapter_infer(x2d, p[0], p[1], p[2], p[3], sc, plan, p[5], bool(self.skip_connection), walk)
-            dev = x2d.device
-            if dev.index != torch.cuda.current_device():
-                torch.cuda.set_device(dev)
-            lib = _lib.load()
-            plan.sizes(lib, self.hidden_size, self.bottleneck_size)   # (validates the rank)
-            return ext.adapter_infer(x2d, p[0], p[1], p[2], p[3], sc, plan.arena, plan.struct_addr,
-                                     plan.infer_bytes(lib, self.hidden_size, self.bottleneck_size), p[5],
-                                     bool(self.skip_connection), _stream(dev.index), walk)
+        # forward-only entry point — same bits in `out`, no saved tensors allocated or written.
+        # Training takes the first test only: W_down trains and grad mode is on.
+        if not (p[0].requires_grad and torch.is_grad_enabled()):
+            sc = p[4] if fuse_scalar else None
+            if not torch.is_grad_enabled() or not (x2d.requires_grad or p[1].requires_grad or p[2].requires_grad
+                                                   or p[3].requires_grad or (sc is not None and sc.requires_grad)):
+                if ext is None:
+                    return adapter_infer(x2d, p[0], p[1], p[2], p[3], sc, plan, p[5], bool(self.skip_connection), walk)
+                dev = x2d.device
+                if dev.index != torch.cuda.current_device():
+                    torch.cuda.set_device(dev)
+                lib = _lib.load()
+                plan.sizes(lib, self.hidden_size, self.bottleneck_size)   # (validates the rank)
+                return ext.adapter_infer(x2d, p[0], p[1], p[2], p[3], sc, plan.arena, plan.struct_addr,
+                                         plan.infer_bytes(lib, self.hidden_size, self.bottleneck_size), p[5],
+                                         bool(self.skip_connection), _stream(dev.index), walk & 1)
         if ext is None:   # pure-Python binding of the same C ABI
             return GConvAdapterFunction.apply(x2d, p[0], p[1], p[2], p[3],
                                               p[4] if fuse_scalar else None, plan, p[5],

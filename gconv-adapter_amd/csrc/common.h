@@ -81,6 +81,8 @@ __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; 
 // T / 4 (T / 2 .. T / 6: 39.2 .. 40.1); 4096 molecules 156.3 -> 154.7 at T = 101 (4 tiles per workgroup,
 // slack T) against 170.7 at T = 58 / slack T / 4 (7 per workgroup, a third of them with a halo);
 // 32 molecules 24.6 -> 23.6 at T = 16.
+// graphs of at least this many nodes get gconv_csr_t::near_edges counted and may take the SpMM's XCD-contiguous rows
+constexpr int kXcdRowsMinNodes = 1 << 15;
 int tile_nominal(int n);                       // graph_prep.hip (reads GCONV_TILE_NODES_OVERRIDE / _MAX)
 int tile_slack(int T, int n);                  // how far below its nominal position a cut may sit
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

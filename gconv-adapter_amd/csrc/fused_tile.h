@@ -12,8 +12,9 @@ struct TileFwdArgs {
   const float* w_down; const float* b_down; const float* w_up; const float* b_up;
   const float* scalar;
   int d, r, fp, act, skip, cap, n_tiles, n;   // n = nodes of the graph (rows of x)
-  int stagger;   // in: the caller's walk bit (0 / 1); the launcher turns it into the kernels' mode (0, +1, -1)
+  int stagger;   // in: the caller's walk bit (0 / 1); the launcher turns it into the kernels' mode (0, 1, 2)
   int store_nt;  // output rows with non-temporal stores (set by the launcher: tile_store_nt)
+  int npass;     // ceil(n_tiles / grid) (launcher)
   long long* stamps;   // diagnostic build only (-DGCONV_TILE_STAMPS, tools/tilestamps.py)
 };
 
@@ -28,7 +29,7 @@ struct TileBwdArgs {
   float* part_wd; float* part_wu; float* part_cs; float* part_bd;
   float* part_ds;   // complete scalar-gradient partial: (G Wu).P + [skip] G.X + b_up.colsum(G)
   int d, r, fp, act, skip, cap, want_ds, n_tiles, n;
-  int stagger, store_nt;   // as in TileFwdArgs
+  int stagger, store_nt, npass;   // as in TileFwdArgs
   long long* stamps;   // diagnostic build only
 };
 

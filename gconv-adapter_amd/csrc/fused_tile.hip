@@ -164,27 +164,23 @@ __device__ __forceinline__ TileView tile_view(const gconv_tile_t* tiles, int idx
   return v;
 }
 
-// Entry of the size-sorted tile list that workgroup w = blockIdx.x runs in pass `pass` of `npass`, or -1 (the ragged
-// last pass has no tile for some workgroups). Boustrophedon: even passes deal forwards, odd passes backwards.
-// `stagger` (+1 / -1, 0 = off): HALF the workgroups (the odd / the even ones) take THEIR passes in the opposite order,
-// smallest tile first — the chip's workgroups are then not all in the same phase of equally large tiles (round 5, in the
-// step: -3.4 ... -3.8 %; rotated starts in 2 or 4 groups, or other choices of the half, did no better:
-// profiles/r05_lab_tile_step_policies.txt). Which half alternates between consecutive adapters of a model
-// (gconv_adapter_params_t::walk), so that a workgroup starts a kernel with the tile it ended the previous kernel with.
-__device__ __forceinline__ int tile_order_index(int pass, int npass, int n_tiles, int stagger) {
+// Entry of the size-sorted tile list that workgroup w = blockIdx.x runs in pass `pass` (may lie past the end of the
+// list: the ragged pass has no tile for some workgroups). Boustrophedon: even passes deal forwards, odd passes
+// backwards. `rev` (wave-uniform 0 / 1): this workgroup takes ITS passes in the opposite order, smallest tile first.
+// HALF the workgroups do (tile_walk_reversed): the chip's workgroups are then not all in the same phase of equally
+// large tiles (round 5, in the step: -3.4 ... -3.8 %; rotated starts in 2 or 4 groups, or other choices of the half,
+// did no better: profiles/r05_lab_tile_step_policies.txt). Which half alternates between consecutive adapters of a
+// model (gconv_adapter_params_t::walk), so that a workgroup starts a kernel with the tile it ended the previous one with.
+// (pure arithmetic on purpose: with ?: hipcc emits scalar BRANCHES here, basic-block boundaries in the kernels'
+//  prologues, and splits the kernel-argument loads into three dependent batches in front of the first request)
+__device__ __forceinline__ int tile_order_index(int pass, int npass, int rev) {
   const int G = gridDim.x, w = blockIdx.x;
-  int p = pass;
-  if (stagger == 1) p = (w & 1) ? npass - 1 - pass : pass;          // odd workgroups: smallest tile first
-  else if (stagger == -1) p = (w & 1) ? pass : npass - 1 - pass;   // the other half (gconv_adapter_params_t::walk)
-  const int idx = (p & 1) ? (p + 1) * G - 1 - w : p * G + w;
-  return idx < n_tiles ? idx : -1;
+  const int p = pass + rev * (npass - 1 - 2 * pass);          // rev ? npass - 1 - pass : pass
+  return p * G + w + (p & 1) * (G - 1 - 2 * w);                // odd pass: (p + 1) G - 1 - w, even pass: p G + w
 }
-// the first VALID entry of a workgroup's walk (for the prologue's record request; clamped, never -1)
-__device__ __forceinline__ int tile_first_index(int n_tiles, int stagger) {
-  const int npass = ceil_div(n_tiles, static_cast<int>(gridDim.x));
-  int idx = -1;
-  for (int p = 0; p < npass && idx < 0; ++p) idx = tile_order_index(p, npass, n_tiles, stagger);
-  return min(max(idx, 0), n_tiles - 1);
+// a.stagger: 0 = nobody, 1 = the odd workgroups, 2 = the even ones
+__device__ __forceinline__ int tile_walk_reversed(int stagger) {
+  return static_cast<int>(stagger > 0) & (((static_cast<int>(blockIdx.x) ^ stagger) & 1) ^ 1);
 }
 
 // graph node of the tile's local row lr (< n0): own rows are contiguous, halo rows come from the slot
@@ -433,9 +429,19 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
   // it): the prologue requests ALL of them back to back — register fragments, scalar, the first
   // tile's record — and only then stages the LDS weights, so it pays one cold round trip, not four.
   TILE_STAMP(9);
-  const float sraw = (a.scalar ? a.scalar : a.w_down)[0];
-  i32x4 rec = tile_rec_load(a.tiles, tile_first_index(a.n_tiles, a.stagger));   // (grid <= n_tiles)
-  TileView tv_s{};
+  // (a BUFFER load, counted in vmcnt like the rest of the prologue: as a scalar load this value's cold round trip was
+  //  waited for with lgkmcnt(0) together with the kernel arguments, IN FRONT of every other request — round 5: the
+  //  walk-order arithmetic below made hipcc place it there, +0.4 us per kernel on one-tile-per-workgroup batches;
+  //  through a VGPR address it became a flat load, which drains vmcnt AND lgkmcnt wherever it is waited for)
+  const float sraw = buf_ld1(make_rsrc(a.scalar ? a.scalar : a.w_down, 4u), 0);
+  // this workgroup's walk: passes [pass0, pend). Only the ragged pass — the LAST one of the common order, hence the
+  // FIRST one of a reversed walk — may have no tile for it: it is cut off here, so that the loop below has no
+  // "skip" path (a request on such a path gave hipcc's vmcnt bookkeeping a pessimistic join: vmcnt(0) at the top
+  // of every tile, +0.3 us per kernel, round 5)
+  const int rev = tile_walk_reversed(a.stagger);
+  const int ragged = static_cast<int>(tile_order_index(rev ? 0 : a.npass - 1, a.npass, rev) >= a.n_tiles);
+  const int pass0 = rev & ragged, pend = a.npass - ((rev ^ 1) & ragged);
+  i32x4 rec = tile_rec_load(a.tiles, min(tile_order_index(pass0, a.npass, rev), a.n_tiles - 1));   // (grid <= n_tiles)
 #ifdef GCONV_TILE_STAMPS
   if (threadIdx.x == 0) {   // where this workgroup runs: HW_ID (wave / simd / cu / sh / se) and XCC_ID
     a.stamps[blockIdx.x * 16 + 12] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
@@ -485,19 +491,15 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
   // pass 1 the (2 G - 1 - w)-th, ... — the big tiles end up alone. a.stagger: workgroups with an odd index walk
   // THEIR tiles in the opposite order (smallest first), so that the chip's workgroups are not all in the same
   // phase of a tile at the same time (tile_order_index below).
-  const int npass = ceil_div(a.n_tiles, static_cast<int>(gridDim.x));
-  for (int pass = 0; pass < npass; ++pass) {
-    const int idx = tile_order_index(pass, npass, a.n_tiles, a.stagger);
-    {   // the next pass's record is requested now (clamped index: always a valid entry)
-      const int nidx = tile_order_index(min(pass + 1, npass - 1), npass, a.n_tiles, a.stagger);
-      const i32x4 nrec = tile_rec_load(a.tiles, min(max(nidx, 0), a.n_tiles - 1));
-      if (idx < 0) { rec = nrec; continue; }   // (ragged last pass: no tile for this workgroup — uniform)
-      const TileView tvv = tile_view(a.tiles, idx, rec, a.halo);
-      rec = nrec;
-      tv_s = tvv;
-    }
-    const TileView tv = tv_s;                                       // the tile of this pass
+  for (int pass = pass0; pass < pend; ++pass) {   // (every pass in [pass0, pend) has a tile for this workgroup)
+    const int idx = tile_order_index(pass, a.npass, rev);
+    const int nidx = min(max(tile_order_index(pass + 1, a.npass, rev), 0), a.n_tiles - 1);
+    // ORDER MATTERS (vmcnt retires in order): tile_view's short request for {slot, e0} — a line the record's own
+    // request has already pulled in — goes out BEFORE the next pass's record, a cold miss; issued behind it, every
+    // tile waited for that miss at its top (+0.6 us per kernel on one-tile-per-workgroup batches, round 5)
+    const TileView tv = tile_view(a.tiles, idx, rec, a.halo);      // the tile of this pass
     const int ts = tv.ts, nt = tv.nt;
+    rec = tile_rec_load(a.tiles, nidx);   // the next pass's record is requested now (clamped: always a valid entry)
     if (nt <= 0) continue;  // uniform
     TILE_STAMP_NT(nt);
     TILE_STAMP(1);
@@ -640,9 +642,19 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
   const int nwaves = blockDim.x >> 6;
   const int pid = blockIdx.x;
   // (prologue: all first-touch requests back to back, LDS staging after them — see forward)
-  const float sraw = (a.scalar ? a.scalar : a.w_down)[0];
-  i32x4 rec = tile_rec_load(a.tiles, tile_first_index(a.n_tiles, a.stagger));   // (grid <= n_tiles)
-  TileView tv_s{};
+  // (a BUFFER load, counted in vmcnt like the rest of the prologue: as a scalar load this value's cold round trip was
+  //  waited for with lgkmcnt(0) together with the kernel arguments, IN FRONT of every other request — round 5: the
+  //  walk-order arithmetic below made hipcc place it there, +0.4 us per kernel on one-tile-per-workgroup batches;
+  //  through a VGPR address it became a flat load, which drains vmcnt AND lgkmcnt wherever it is waited for)
+  const float sraw = buf_ld1(make_rsrc(a.scalar ? a.scalar : a.w_down, 4u), 0);
+  // this workgroup's walk: passes [pass0, pend). Only the ragged pass — the LAST one of the common order, hence the
+  // FIRST one of a reversed walk — may have no tile for it: it is cut off here, so that the loop below has no
+  // "skip" path (a request on such a path gave hipcc's vmcnt bookkeeping a pessimistic join: vmcnt(0) at the top
+  // of every tile, +0.3 us per kernel, round 5)
+  const int rev = tile_walk_reversed(a.stagger);
+  const int ragged = static_cast<int>(tile_order_index(rev ? 0 : a.npass - 1, a.npass, rev) >= a.n_tiles);
+  const int pass0 = rev & ragged, pend = a.npass - ((rev ^ 1) & ragged);
+  i32x4 rec = tile_rec_load(a.tiles, min(tile_order_index(pass0, a.npass, rev), a.n_tiles - 1));   // (grid <= n_tiles)
 #ifdef GCONV_TILE_STAMPS
   if (threadIdx.x == 0) {
     a.stamps[blockIdx.x * 16 + 12] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
@@ -699,19 +711,15 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
   // tiles are dealt from the size-sorted list boustrophedon (see the forward kernel; a.stagger: odd workgroups
   // walk their tiles smallest first — their partial sums then add the same tiles in the opposite order: fixed per
   // launch geometry, so still the same bits run to run)
-  const int npass = ceil_div(a.n_tiles, static_cast<int>(gridDim.x));
-  for (int pass = 0; pass < npass; ++pass) {
-    const int idx = tile_order_index(pass, npass, a.n_tiles, a.stagger);
-    {   // the next pass's record is requested now (clamped index: always a valid entry)
-      const int nidx = tile_order_index(min(pass + 1, npass - 1), npass, a.n_tiles, a.stagger);
-      const i32x4 nrec = tile_rec_load(a.tiles, min(max(nidx, 0), a.n_tiles - 1));
-      if (idx < 0) { rec = nrec; continue; }   // (ragged last pass: no tile for this workgroup — uniform)
-      const TileView tvv = tile_view(a.tiles, idx, rec, a.halo);
-      rec = nrec;
-      tv_s = tvv;
-    }
-    const TileView tv = tv_s;                                       // the tile of this pass
+  for (int pass = pass0; pass < pend; ++pass) {   // (every pass in [pass0, pend) has a tile for this workgroup)
+    const int idx = tile_order_index(pass, a.npass, rev);
+    const int nidx = min(max(tile_order_index(pass + 1, a.npass, rev), 0), a.n_tiles - 1);
+    // ORDER MATTERS (vmcnt retires in order): tile_view's short request for {slot, e0} — a line the record's own
+    // request has already pulled in — goes out BEFORE the next pass's record, a cold miss; issued behind it, every
+    // tile waited for that miss at its top (+0.6 us per kernel on one-tile-per-workgroup batches, round 5)
+    const TileView tv = tile_view(a.tiles, idx, rec, a.halo);      // the tile of this pass
     const int ts = tv.ts, nt = tv.nt;
+    rec = tile_rec_load(a.tiles, nidx);   // the next pass's record is requested now (clamped: always a valid entry)
     if (nt <= 0) continue;  // uniform
     TILE_STAMP_NT(nt);
     TILE_STAMP(1);
@@ -1126,7 +1134,7 @@ static int tile_stagger(int n_tiles, int grid, int walk) {
   static const char* v = getenv("GCONV_TILE_STAGGER");
   const int mode = v ? atoi(v) : GCONV_TILE_STAGGER_DEFAULT;
   if (mode == 0 || n_tiles < 2 * grid) return 0;
-  return walk ? -1 : 1;
+  return walk ? 2 : 1;   // the odd / the even workgroups (tile_walk_reversed)
 }
 
 // Output rows (out, dX) non-temporal? One tile per workgroup (a 512-molecule shard): yes, as since round 1. Two or
@@ -1149,6 +1157,7 @@ gconv_status_t launch_tile_fwd(TileFwdArgs a, int n_tiles, int tile_nodes_max,
   a.n_tiles = n_tiles;
   n_tiles = tile_grid(n_tiles);
   a.stagger = tile_stagger(a.n_tiles, n_tiles, a.stagger);   // (in: the caller's walk bit)
+  a.npass = ceil_div(a.n_tiles, n_tiles);
   a.store_nt = tile_store_nt(a.n_tiles, n_tiles);
   a.cap = ceil_div(tile_nodes_max > 0 ? tile_nodes_max : 1, 16) * 16;
   const size_t lds = tile_lds_bytes(a.d, a.fp, tile_nodes_max, tile_edges_max);
@@ -1162,6 +1171,7 @@ gconv_status_t launch_tile_bwd(TileBwdArgs a, int n_tiles, int tile_nodes_max,
   a.n_tiles = n_tiles;
   n_tiles = tile_grid(n_tiles);
   a.stagger = tile_stagger(a.n_tiles, n_tiles, a.stagger);   // (in: the caller's walk bit)
+  a.npass = ceil_div(a.n_tiles, n_tiles);
   a.store_nt = tile_store_nt(a.n_tiles, n_tiles);
   a.cap = ceil_div(tile_nodes_max > 0 ? tile_nodes_max : 1, 16) * 16;
   const size_t lds = tile_lds_bytes(a.d, a.fp, tile_nodes_max, tile_edges_max);

@@ -119,8 +119,10 @@ __global__ void build_csr_kernel(const K* __restrict__ keys, int64_t E, int32_t 
     }
     if (r_cur == n && r_prev < n) *nnz_out = static_cast<int32_t>(p);
   }
-  const int cnt = __popcll(__ballot(near));    // one add per wave
-  if ((threadIdx.x & 63) == 0 && cnt > 0) atomicAdd(near_out, cnt);
+  if (near_out) {   // (graphs below kXcdRowsMinNodes never use the count: no atomics on their side-stream builds)
+    const int cnt = __popcll(__ballot(near));    // one add per wave
+    if ((threadIdx.x & 63) == 0 && cnt > 0) atomicAdd(near_out, cnt);
+  }
 }
 
 __global__ void row_stats_kernel(const int32_t* __restrict__ rowptr, int32_t n,
@@ -284,7 +286,7 @@ static gconv_status_t build_direction(const int64_t* ei, int64_t E, int32_t n, i
     sorted = keys_b;
   }
   build_csr_kernel<K><<<static_cast<unsigned>((E + 1 + T - 1) / T), T, 0, stream>>>(
-      sorted, E, n, ko, o.rowptr, o.col, info + base, info + base + 4);
+      sorted, E, n, ko, o.rowptr, o.col, info + base, n >= kXcdRowsMinNodes ? info + base + 4 : nullptr);
   GCONV_LAUNCH_CHECK();
   if (n > 0) {
     row_stats_kernel<<<(n + T - 1) / T, T, 0, stream>>>(o.rowptr, n, dis, o.long_rows,
@@ -873,19 +875,22 @@ __global__ __launch_bounds__(kCountThreads) void counting_build_kernel(CountArgs
         return !(a.normalize && s == d) && (static_cast<int64_t>(s) * 8) / n == (static_cast<int64_t>(d) * 8) / n;
       };
       test(s0, d0, dd0, ds0);                          // (0, 0 when the thread has no first edge: skipped as a self-loop)
-      if (gtid < E) near_cnt += near(s0, d0);
+      const bool count_near = n >= kXcdRowsMinNodes;   // (grid-uniform; smaller graphs never use the count)
+      if (count_near && gtid < E) near_cnt += near(s0, d0);
       for (int64_t e = gtid + gsize; e < E; e += gsize) {
         const int s = static_cast<int>(a.ei[e]), d = static_cast<int>(a.ei[E + e]);
         const int dd = ldc(deg + d), ds = ldc(deg + s);
         ell_row(d, rd);
         ell_row(s, rs);
         test(s, d, dd, ds);
-        near_cnt += near(s, d);
+        if (count_near) near_cnt += near(s, d);
       }
       if (asym) atomicOr(&info[INFO_ASYM], 1);
+      if (count_near) {
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) near_cnt += __shfl_xor(near_cnt, off);
-      if (lane == 0 && near_cnt > 0) atomicAdd(&info[a.fwd + 4], near_cnt);
+        for (int off = 32; off > 0; off >>= 1) near_cnt += __shfl_xor(near_cnt, off);
+        if (lane == 0 && near_cnt > 0) atomicAdd(&info[a.fwd + 4], near_cnt);
+      }
     }
   }
   GCONV_STAMP(3);

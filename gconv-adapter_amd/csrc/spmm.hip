@@ -283,7 +283,7 @@ gconv_status_t launch_spmm(const gconv_csr_t* g, SpmmArgs a, int width, int epi,
   // at least half of the stored edges stay inside their row's eighth of the node range, and there are enough
   // row blocks for the eighths to matter: XCD-contiguous rows (GCONV_SPMM_XCD_ROWS=0 / 1 forces it off / on)
   static const char* xr = getenv("GCONV_SPMM_XCD_ROWS");
-  a.xcd_rows = xr ? (xr[0] == '1') : (2 * static_cast<int64_t>(g->near_edges) >= g->nnz && g->nnz > 0 && a.n >= (1 << 15));
+  a.xcd_rows = xr ? (xr[0] == '1') : (2 * static_cast<int64_t>(g->near_edges) >= g->nnz && g->nnz > 0 && a.n >= kXcdRowsMinNodes);
   if (a.row_hi == 0) { a.row_lo = 0; a.row_hi = a.n; }
   if (a.row_lo < 0 || a.row_hi > a.n || a.row_lo >= a.row_hi) return GCONV_E_INVALID_ARG;
   if (a.n_seg > 0 && !a.seg_partial) return GCONV_E_WORKSPACE;
