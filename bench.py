@@ -45,6 +45,7 @@ The JSON line also carries
 from __future__ import annotations
 
 import argparse
+from typing import Optional
 import json
 import os
 import sys
@@ -145,6 +146,7 @@ os.environ.setdefault("DISABLE_ADDMM_HIP_LT", "1")
 import gconv_adapter_amd as ga  # noqa: E402
 
 RESIDENT = 0
+PREFETCH_AT = os.environ.get("GCONV_BENCH_PREFETCH_AT", "auto")   # where the step starts the next plans' build
 PARTITION = "graphs"
 STRONG_WORKLOAD = "hiv4096"   # --scaling strong: the whole batch of BASELINE configs[2], split over the ranks
 _FULL_AFFINITY = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
@@ -218,19 +220,40 @@ class BatchStream:
             self.items.append((batch, x, ei, gout))
         self.cfg = cfg
         self.pos = 0
+        # where the step starts the build of the plan `depth` batches ahead (start_prefetch): between forward and
+        # backward for batches that fill the chip (>= 4096 nodes), at the top of the step for the reference's own
+        # 32-molecule batches (host-bound: a call in the middle of the step only delays the backward's launches —
+        # ESOL 0.154 -> 0.159 ms). GCONV_BENCH_PREFETCH_AT=top|backward forces one (A/B).
+        nodes = max(int(b.num_nodes) for b, *_ in self.items)
+        self.prefetch_beside_backward = (PREFETCH_AT == "backward") if PREFETCH_AT in ("top", "backward") else nodes >= 4096
 
     def avg(self, attr) -> float:
         return sum(float(getattr(b, attr)) for b, *_ in self.items) / len(self.items)
 
     def next(self, normalize: bool):
         batch, x, ei, gout = self.items[self.pos % len(self.items)]
-        if self.fresh and self.prefetch:  # start the graph build of the batch `depth` steps ahead now
-            ahead = range(1, self.depth + 1) if self.pos == 0 else (self.depth,)
-            for a in ahead:
-                _, nx, nei, _ = self.items[(self.pos + a) % len(self.items)]
-                ga.prefetch_plan(nei, nx.shape[-2], normalize)
+        if self.pos == 0 or not self.prefetch_beside_backward:
+            self.start_prefetch(normalize, self.pos)
         self.pos += 1
         return batch, x, ei, gout
+
+    def start_prefetch(self, normalize: bool, step: Optional[int] = None) -> None:
+        """Starts the graph build of the batch `depth` steps ahead (all of the first `depth` batches before the
+        first step). The build's side stream waits for what the main stream holds at THIS point
+        (`prefetch_plan`: an event recorded at submit time), so WHERE the loop calls it decides what the build
+        runs beside on the GPU: `adapter_step` calls it between the forward and the backward pass. Beside the
+        forward kernels — 10 waves x 168 VGPRs per CU: no build wave fits next to them, every CU a build
+        workgroup holds is lost to the forward — the whole-batch step paid 100 us (forward kernels 62 -> 82 us
+        each, tools/lab/r05_k0trace.sh); the backward kernels (8 waves x 203 VGPRs) leave room and do not slow down.
+        GCONV_BENCH_PREFETCH_AT=top: at the top of the step, as in rounds 1-4 (A/B)."""
+        if not (self.fresh and self.prefetch):
+            return
+        if step is None:
+            step = self.pos - 1                           # (the step that is running: next() has counted it)
+        ahead = range(1, self.depth + 1) if step == 0 else (self.depth,)
+        for a in ahead:
+            _, nx, nei, _ = self.items[(step + a) % len(self.items)]
+            ga.prefetch_plan(nei, nx.shape[-2], normalize)
 
 
 class StoreStream:
@@ -272,6 +295,8 @@ def adapter_step(mods, params, stream: BatchStream, normalize: bool, bucket=None
     h = x
     for m in mods:
         h = m(h, ei)
+    if isinstance(stream, BatchStream) and stream.prefetch_beside_backward and stream.pos > 1:
+        stream.start_prefetch(normalize)   # the next batches' graph build runs beside the BACKWARD pass
     h.backward(gout)
     if bucket is not None:
         # the backward pass has written every gradient into the flat bucket (gradient sinks):
