@@ -1073,6 +1073,14 @@ def main() -> None:
                    "cores_per_rank": len(_PINNED) if _PINNED else None,
                    "surface": "GConvAdapter nn.Module -> C ABI -> HIP"},
     }
+    # what `value` is, in one token, and where the number that rounds 1-3 headlined lives (round-4 advisor finding:
+    # the headline moved from the 512-molecule shard to the whole batch in round 4 — values across that change are
+    # not like for like)
+    line["headline_workload"] = f"{args.workload}_{line['scaling']}_n{world}"
+    line["comparable_to_previous_round"] = {
+        "round_4": "same metric, workload and scaling (hiv4096 strong): value / ms_per_step compare directly",
+        "rounds_1_to_3": "headlined the 512-molecule shard (weak scaling): compare extra.hiv512_graphs_per_s / "
+                         "extra.hiv512_ms_per_step"}
     if world > 1 and LAST_DIAG:
         per = LAST_DIAG.get("ms_per_step_per_rank") or [main_res["ms_per_step"]]
         line["diagnostics"] = {"ms_per_step_min_over_ranks": min(per), "ms_per_step_max_over_ranks": max(per), **LAST_DIAG,

@@ -192,6 +192,8 @@ SIGNATURES = {
     "gconv_segment_pool_f32": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "gconv_segment_pool_bwd_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "gconv_masked_loss_f64": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "gconv_masked_loss_workspace_bytes": (_sz, [_i64]),
+    "gconv_masked_loss_ws_f64": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _sz, _vp]),
     "gconv_adam_step_f32": (_i32, [_vp, _vp, _vp, _vp, C.c_int64, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_float, C.c_int64, _vp]),
 }

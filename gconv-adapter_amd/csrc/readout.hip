@@ -47,8 +47,10 @@ __global__ __launch_bounds__(256) void segment_pool_kernel(const float* __restri
                                                            int mean, float* __restrict__ out,
                                                            int32_t* __restrict__ counts) {
   __shared__ int seg[2];
+  __shared__ int badflag;
   __shared__ f32x4 red[3][64 * NP];
   const int g = blockIdx.x, lane = threadIdx.x & 63, wave = wave_id();
+  if (threadIdx.x == 0) badflag = 0;
   if (wave < 2) {
     const int b = lower_bound64(batch, n, static_cast<int64_t>(g) + wave, lane);
     if (lane == 0) seg[wave] = b;
@@ -62,28 +64,40 @@ __global__ __launch_bounds__(256) void segment_pool_kernel(const float* __restri
   // wave w: rows r0 + w, r0 + w + 4, ... added in that order; kU of them are requested before the first is added
   // (a molecule of 222 atoms would otherwise be 56 dependent round trips for its workgroup — and the kernel)
   constexpr int kU = 8;
+  // `batch` must be sorted (PyG's collation order): the segment [r0, r1) found by the search then holds exactly the
+  // rows of graph g. Checked on the way — every row this wave adds must carry g; graph 0 / the last graph also that
+  // no row lies in front of / behind all segments — at the price of one broadcast 8-byte load per row: a violation
+  // turns the graph's output row into NaN (the loss shows it without any host synchronisation) and raises the
+  // flag word counts[num_graphs] for `validate=True` (round-4 advisor finding: silently wrong sums).
+  bool bad = false;
   for (int row = r0 + wave; row < r1; row += 4 * kU) {
     f32x4 v[kU][NP];
 #pragma unroll
-    for (int u = 0; u < kU; ++u)
+    for (int u = 0; u < kU; ++u) {
+      if (row + 4 * u < r1) bad |= batch[row + 4 * u] != static_cast<int64_t>(g);
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         const int q = lane + 64 * p;
         v[u][p] = q < nq && row + 4 * u < r1 ? ldg4(x + static_cast<size_t>(row + 4 * u) * d + 4 * q)
                                             : f32x4{0.f, 0.f, 0.f, 0.f};
       }
+    }
 #pragma unroll
     for (int u = 0; u < kU; ++u)
 #pragma unroll
       for (int p = 0; p < NP; ++p) a[p] += v[u][p];
   }
+  if (g == 0) bad |= r0 != 0;                                    // rows in front of every segment (ids < 0, or disorder)
+  if (g == static_cast<int>(gridDim.x) - 1) bad |= r1 != n;      // rows behind every segment (ids >= size, or disorder)
+  if (bad) badflag = 1;                                          // (benign race: every writer stores 1)
   if (wave > 0) {
 #pragma unroll
     for (int p = 0; p < NP; ++p) red[wave - 1][lane + 64 * p] = a[p];
   }
   __syncthreads();
   if (wave == 0) {
-    const float scale = mean && r1 > r0 ? 1.f / static_cast<float>(r1 - r0) : 1.f;
+    const bool poisoned = badflag != 0;
+    const float scale = poisoned ? __builtin_nanf("") : (mean && r1 > r0 ? 1.f / static_cast<float>(r1 - r0) : 1.f);
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int q = lane + 64 * p;
@@ -91,7 +105,10 @@ __global__ __launch_bounds__(256) void segment_pool_kernel(const float* __restri
       for (int w = 0; w < 3; ++w) t += red[w][lane + 64 * p];   // waves added in wave order
       if (q < nq) stg4(out + static_cast<size_t>(g) * d + 4 * q, t * scale);
     }
-    if (lane == 0 && counts) counts[g] = r1 - r0;
+    if (lane == 0 && counts) {
+      counts[g] = r1 - r0;
+      if (poisoned) counts[gridDim.x] = 1;   // the flag word behind the counts (zeroed by the launcher)
+    }
   }
 }
 
@@ -168,6 +185,75 @@ __global__ __launch_bounds__(1024) void masked_loss_kernel(const float* __restri
   }
 }
 
+// The same loss for MANY logits (a multi-task head: ToxCast, 617 tasks x 4096 graphs = 2.5 M; round-4 advisor
+// finding: one workgroup walked them all, twice, in fp64). Stage 1: kLossBlocks workgroups, block b sums the elements
+// b * 1024 + t, (b + kLossBlocks) * 1024 + t, ... (fixed assignment and order), writes {sum, count} to the workspace
+// with write-through stores; the workgroup whose ticket is last adds the partials in block order, writes the loss and
+// the count, and resets the ticket (fixed order: the same bits every run). Stage 2 (second launch): the gradient.
+constexpr int kLossBlocks = 256;
+__global__ __launch_bounds__(1024) void masked_loss_partial_kernel(const float* __restrict__ logits,
+                                                                   const double* __restrict__ target, long long m,
+                                                                   int kind, double* __restrict__ out,
+                                                                   double* __restrict__ part, unsigned* __restrict__ ticket) {
+  __shared__ double red_s[16];
+  __shared__ long long red_c[16];
+  __shared__ int last_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double s = 0.0;
+  long long c = 0;
+  for (long long i = static_cast<long long>(blockIdx.x) * 1024 + tid; i < m; i += static_cast<long long>(gridDim.x) * 1024) {
+    const double t = target[i];
+    if (t != t) continue;
+    const double x = static_cast<double>(logits[i]);
+    if (kind == 0) s += fmax(x, 0.0) - x * t + log1p(exp(-fabs(x)));
+    else s += (x - t) * (x - t);
+    ++c;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_xor(s, off);
+    c += __shfl_xor(c, off);
+  }
+  if (lane == 0) { red_s[wave] = s; red_c[wave] = c; }
+  __syncthreads();
+  if (tid == 0) {
+    double ts = 0.0;
+    long long tc = 0;
+    for (int w = 0; w < 16; ++w) { ts += red_s[w]; tc += red_c[w]; }
+    __hip_atomic_store(part + 2 * blockIdx.x, ts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(part + 2 * blockIdx.x + 1, static_cast<double>(tc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_s = t == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (last_s && tid == 0) {
+    double ts = 0.0, tc = 0.0;
+    for (unsigned b = 0; b < gridDim.x; ++b) {
+      ts += __hip_atomic_load(part + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tc += __hip_atomic_load(part + 2 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    out[0] = tc > 0.0 ? ts / tc : 0.0;
+    out[1] = tc;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ __launch_bounds__(256) void masked_loss_grad_kernel(const float* __restrict__ logits,
+                                                               const double* __restrict__ target, long long m, int kind,
+                                                               const double* __restrict__ out, float* __restrict__ grad) {
+  const double cnt = out[1];
+  const double inv = cnt > 0.0 ? 1.0 / cnt : 0.0;
+  for (long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; i < m; i += static_cast<long long>(gridDim.x) * 256) {
+    const double t = target[i];
+    double gi = 0.0;
+    if (t == t) {
+      const double x = static_cast<double>(logits[i]);
+      gi = kind == 0 ? (1.0 / (1.0 + exp(-x)) - t) * inv : 2.0 * (x - t) * inv;
+    }
+    grad[i] = static_cast<float>(gi);
+  }
+}
+
 }  // namespace gconv
 
 using namespace gconv;
@@ -195,6 +281,8 @@ extern "C" gconv_status_t gconv_segment_pool_f32(const float* x, const int64_t* 
   if (!out || (num_nodes > 0 && (!x || !batch))) return GCONV_E_INVALID_ARG;
   if (!aligned16(x) || !aligned16(out)) return GCONV_E_ALIGNMENT;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  // counts[num_graphs] = "batch is not sorted / holds ids outside [0, num_graphs)" flag (include/gconv_adapter.h)
+  if (counts) GCONV_HIP(hipMemsetAsync(counts + num_graphs, 0, sizeof(int32_t), stream));
   GCONV_POOL_DISPATCH((segment_pool_kernel<NP><<<num_graphs, 256, 0, stream>>>(x, batch, num_nodes, hidden, mean,
                                                                                out, counts)))
   GCONV_LAUNCH_CHECK();
@@ -225,5 +313,32 @@ extern "C" gconv_status_t gconv_masked_loss_f64(const float* logits, const doubl
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   masked_loss_kernel<<<1, 1024, 0, stream>>>(logits, target, count, kind, loss_and_count, grad_logits);
   GCONV_LAUNCH_CHECK();
+  return GCONV_OK;
+}
+
+// (256 partial pairs + the ticket word; must read all zero in its LAST 64 bytes before the first call — the ticket
+//  goes back to zero at the end of every call)
+extern "C" size_t gconv_masked_loss_workspace_bytes(int64_t count) {
+  (void)count;
+  return static_cast<size_t>(kLossBlocks) * 2 * sizeof(double) + 64;
+}
+
+extern "C" gconv_status_t gconv_masked_loss_ws_f64(const float* logits, const double* target, int64_t count,
+                                                   int32_t kind, double* loss_and_count, float* grad_logits,
+                                                   void* workspace, size_t workspace_bytes, gconv_stream_t stream_) {
+  if (count < 0 || (kind != 0 && kind != 1) || !loss_and_count) return GCONV_E_INVALID_ARG;
+  if (count > 0 && (!logits || !target || !grad_logits)) return GCONV_E_INVALID_ARG;
+  if (!workspace || workspace_bytes < gconv_masked_loss_workspace_bytes(count)) return GCONV_E_WORKSPACE;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  double* part = static_cast<double*>(workspace);
+  unsigned* ticket = reinterpret_cast<unsigned*>(part + 2 * kLossBlocks);
+  const int blocks = static_cast<int>(count / 1024 + 1 < kLossBlocks ? count / 1024 + 1 : kLossBlocks);
+  masked_loss_partial_kernel<<<blocks, 1024, 0, stream>>>(logits, target, count, kind, loss_and_count, part, ticket);
+  GCONV_LAUNCH_CHECK();
+  if (count > 0) {
+    const int gblocks = static_cast<int>((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096);
+    masked_loss_grad_kernel<<<gblocks, 256, 0, stream>>>(logits, target, count, kind, loss_and_count, grad_logits);
+    GCONV_LAUNCH_CHECK();
+  }
   return GCONV_OK;
 }

@@ -7,8 +7,10 @@ and ``masked_loss`` is the training loop's NaN-masked fp64 loss
 On a 512-molecule shard torch spends ~25 small launches (4 - 8 us each, on the device and on the host) on
 the two.
 
-``batch`` must be sorted ascending, as PyG's collation emits it (``validate=True`` checks, at the price of a
-host synchronisation); ``size=None`` reads ``batch.max()`` back, as PyG does — pass the number of graphs.
+``batch`` must be sorted ascending, as PyG's collation emits it. The pooling kernel checks that on its way: graphs
+whose rows are out of order come out as NaN rows (visible in the loss without a host synchronisation), and
+``validate=True`` raises instead (one synchronisation); ``size=None`` reads ``batch.max()`` back, as PyG does —
+pass the number of graphs.
 """
 from __future__ import annotations
 
@@ -38,17 +40,18 @@ class SegmentPoolFunction(torch.autograd.Function):
         _on_device(x)
         n, d = x.shape
         out = torch.empty(size, d, dtype=torch.float32, device=x.device)
-        counts = torch.empty(max(size, 1), dtype=torch.int32, device=x.device)
+        counts = torch.empty(size + 1, dtype=torch.int32, device=x.device)   # (+ the "batch not sorted" flag word)
         st = lib.gconv_segment_pool_f32(x.data_ptr(), batch.data_ptr(), n, d, size, int(mean), out.data_ptr(),
                                         counts.data_ptr(), _stream(x.device.index))
         if st != 0:
             _lib.check(st, "segment_pool")
         ctx.mean, ctx.size = mean, size
         ctx.save_for_backward(batch, counts)
-        return out
+        ctx.mark_non_differentiable(counts)
+        return out, counts
 
     @staticmethod
-    def backward(ctx, go):
+    def backward(ctx, go, _gcounts=None):
         lib = _lib.load()
         batch, counts = ctx.saved_tensors
         go = go.contiguous()
@@ -67,8 +70,6 @@ def _pool(x: torch.Tensor, batch: Optional[torch.Tensor], size: Optional[int], m
         return x.mean(0, keepdim=True) if mean else x.sum(0, keepdim=True)
     if not x.is_cuda:
         raise RuntimeError("gconv_adapter_amd has no CPU path (x is on %s)" % x.device)
-    if validate and batch.numel() > 1 and not bool((batch[1:] >= batch[:-1]).all()):
-        raise RuntimeError("global pool: `batch` must be sorted ascending (PyG's collation order)")
     if size is None:
         size = int(batch.max()) + 1 if batch.numel() else 0
     native = x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and x.shape[1] <= 1024
@@ -78,7 +79,14 @@ def _pool(x: torch.Tensor, batch: Optional[torch.Tensor], size: Optional[int], m
             cnt = torch.zeros(size, dtype=x.dtype, device=x.device).index_add_(0, batch, torch.ones_like(batch, dtype=x.dtype))
             out = out / cnt.clamp(min=1).view(-1, *([1] * (x.dim() - 1)))
         return out
-    return SegmentPoolFunction.apply(x, batch, int(size), mean)
+    out, counts = SegmentPoolFunction.apply(x, batch, int(size), mean)
+    # The kernel checks the order on its way (csrc/readout.hip): a batch vector that is not sorted, or holds ids
+    # outside [0, size), gives NaN rows — the loss shows it — and raises counts[size]; `validate=True` reads the flag
+    # back (one host synchronisation) and raises here instead.
+    if validate and int(size) > 0 and int(counts[int(size)]) != 0:
+        raise RuntimeError("global pool: `batch` must be sorted ascending with ids in [0, size) (PyG's collation "
+                           "order); the affected graphs' rows were set to NaN")
+    return out
 
 
 def global_mean_pool(x: torch.Tensor, batch: Optional[torch.Tensor], size: Optional[int] = None,
@@ -93,6 +101,22 @@ def global_add_pool(x: torch.Tensor, batch: Optional[torch.Tensor], size: Option
     return _pool(x, batch, size, False, validate)
 
 
+#: up to this many logits ONE workgroup computes the loss (HIV: 4096 x 1); beyond it (ToxCast: 617 tasks x 4096)
+#: gconv_masked_loss_ws_f64 spreads the fp64 exp / log1p over 256 workgroups
+_LOSS_ONE_WORKGROUP = 16384
+_LOSS_WS = {}
+
+
+def _loss_workspace(lib, device) -> torch.Tensor:
+    """One zero-initialised workspace per device (the kernels leave its ticket word at zero; launches on one device
+    are ordered by the stream the training loop runs on)."""
+    ws = _LOSS_WS.get(device.index)
+    if ws is None:
+        ws = torch.zeros(int(lib.gconv_masked_loss_workspace_bytes(0)), dtype=torch.uint8, device=device)
+        _LOSS_WS[device.index] = ws
+    return ws
+
+
 class MaskedLossFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, output, target, kind: int):
@@ -105,8 +129,13 @@ class MaskedLossFunction(torch.autograd.Function):
         _on_device(o)
         res = torch.empty(2, dtype=torch.float64, device=o.device)
         grad = torch.empty_like(o)
-        st = lib.gconv_masked_loss_f64(o.data_ptr(), t.data_ptr(), o.numel(), kind, res.data_ptr(), grad.data_ptr(),
-                                       _stream(o.device.index))
+        if o.numel() > _LOSS_ONE_WORKGROUP:   # a multi-task head: block partials in a fixed order, two launches
+            ws = _loss_workspace(lib, o.device)
+            st = lib.gconv_masked_loss_ws_f64(o.data_ptr(), t.data_ptr(), o.numel(), kind, res.data_ptr(),
+                                              grad.data_ptr(), ws.data_ptr(), ws.numel(), _stream(o.device.index))
+        else:
+            st = lib.gconv_masked_loss_f64(o.data_ptr(), t.data_ptr(), o.numel(), kind, res.data_ptr(), grad.data_ptr(),
+                                           _stream(o.device.index))
         if st != 0:
             _lib.check(st, "masked_loss")
         ctx.save_for_backward(grad)

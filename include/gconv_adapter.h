@@ -416,11 +416,18 @@ gconv_status_t gconv_adapter_slab_bwd_f32(const gconv_graph_t* graph,
  *   ~25 small torch launches per step.
  * gconv_segment_pool_f32: out[g, :] = sum (mean != 0: mean) of x[i, :] over the nodes with batch[i] == g,
  *   g in [0, num_graphs); `batch` int64, SORTED ascending (PyG's collation order); rows are added in node
- *   order — no atomics; counts[g] (nullable) = the graph's node count; an empty graph gives zeros.
+ *   order — no atomics; counts (nullable, [num_graphs + 1]): counts[g] = the graph's node count, and
+ *   counts[num_graphs] = 1 if `batch` turned out NOT to be sorted or to hold ids outside [0, num_graphs) (ABI 10:
+ *   the output rows of the graphs where that shows are NaN — the loss carries it to the host without a
+ *   synchronisation; 0 otherwise); an empty graph gives zeros.
  * gconv_segment_pool_bwd_f32: grad_x[i, :] = grad_out[batch[i], :] (/ counts[batch[i]] for the mean).
  * gconv_masked_loss_f64: logits fp32 [count], target fp64 [count] with NaN = no label; kind 0 = BCE with
  *   logits, 1 = squared error, both in fp64; loss_and_count[0] = sum over the labelled / their number (0 if
  *   none), [1] = that number; grad_logits[i] = d loss / d logits[i] (fp32; 0 where there is no label).
+ * gconv_masked_loss_ws_f64 (ABI 10): the same loss for many logits (multi-task heads: 617 tasks x 4096 graphs) as
+ *   two launches of up to 256 / 4096 workgroups — block partials in a fixed order through `workspace`
+ *   (>= gconv_masked_loss_workspace_bytes(count), zero-initialised ONCE by the caller, left zeroed where it must
+ *   be by every call); same results as gconv_masked_loss_f64 up to the summation order, bitwise repeatable.
  * hidden a multiple of 4, <= 1024.                                                                     */
 gconv_status_t gconv_segment_pool_f32(const float* x, const int64_t* batch, int32_t num_nodes, int32_t hidden,
                                       int32_t num_graphs, int32_t mean, float* out, int32_t* counts,
@@ -430,6 +437,10 @@ gconv_status_t gconv_segment_pool_bwd_f32(const float* grad_out, const int64_t* 
                                           float* grad_x, gconv_stream_t stream);
 gconv_status_t gconv_masked_loss_f64(const float* logits, const double* target, int64_t count, int32_t kind,
                                      double* loss_and_count, float* grad_logits, gconv_stream_t stream);
+size_t gconv_masked_loss_workspace_bytes(int64_t count);
+gconv_status_t gconv_masked_loss_ws_f64(const float* logits, const double* target, int64_t count, int32_t kind,
+                                        double* loss_and_count, float* grad_logits, void* workspace,
+                                        size_t workspace_bytes, gconv_stream_t stream);
 
 /* ---- next to the path: the optimizer step over the trainable set -------------
  * replaces: `optim.Adam(...)` + `optimizer.step()`

@@ -82,6 +82,23 @@ def test_global_pool_on_a_molecule_batch_and_the_other_paths(dev):
                  oracle.global_pool(x6.cpu().double(), bv.cpu(), batch.num_graphs, True), "d=6", 1e-5, 1e-5)
     with pytest.raises(RuntimeError, match="sorted"):
         ga.global_mean_pool(x, bv.flip(0), batch.num_graphs, validate=True)
+    # round-4 advisor finding: an unsorted batch vector (or ids outside [0, size)) used to give silently wrong sums.
+    # The kernel now checks the order on its way: the affected graphs' rows are NaN (no host synchronisation needed
+    # to notice: the loss is NaN), the sorted neighbours are untouched, and validate=True raises.
+    swapped = bv.clone()
+    lo, hi = int(batch.graph_ptr[7]), int(batch.graph_ptr[9])          # two nodes of graphs 7 and 8 trade places
+    swapped[lo], swapped[hi - 1] = bv[hi - 1], bv[lo]
+    got = ga.global_mean_pool(x, swapped, batch.num_graphs)
+    bad = torch.isnan(got).any(1).cpu()
+    assert (bad[7] or bad[8]) and not bad[:7].any() and not bad[9:].any()      # the disorder shows, and only there
+    ok = torch.ones_like(bad); ok[7:9] = False
+    assert_close(got[ok.to(dev)].cpu().double(), want[ok], "sorted graphs next to a disorder", 1e-5, 1e-5)
+    with pytest.raises(RuntimeError, match="sorted"):
+        ga.global_mean_pool(x, swapped, batch.num_graphs, validate=True)
+    assert torch.isnan(ga.global_add_pool(x, bv, batch.num_graphs - 1)).any()     # ids >= size: flagged, not dropped
+    with pytest.raises(RuntimeError, match="sorted"):
+        ga.global_add_pool(x, bv, batch.num_graphs - 1, validate=True)
+    assert not torch.isnan(ga.global_mean_pool(x, bv, batch.num_graphs, validate=True)).any()
     with pytest.raises(RuntimeError, match="int64"):
         ga.global_mean_pool(x, bv.int(), batch.num_graphs)
     with pytest.raises(RuntimeError, match="no CPU path"):
@@ -90,7 +107,8 @@ def test_global_pool_on_a_molecule_batch_and_the_other_paths(dev):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["bce", "mse"])
-@pytest.mark.parametrize("shape,missing", [((512, 1), 0.1), ((32, 1), 0.0), ((4096, 12), 0.7), ((5, 3), 1.0), ((3000, 1), 0.5)])
+@pytest.mark.parametrize("shape,missing", [((512, 1), 0.1), ((32, 1), 0.0), ((4096, 12), 0.7), ((5, 3), 1.0), ((3000, 1), 0.5),
+                                           ((4096, 617), 0.3), ((700, 24), 1.0)])   # (> 16384 logits: 256 workgroups, two launches)
 def test_masked_loss_matches_the_loop(dev, kind, shape, missing):
     """Loss (fp64, rtol 1e-12: the sum runs in a different but fixed order) and d loss / d output (fp32 storage
     of an fp64 value: rtol 1e-6) against the restated loop, logits up to +-40 (no overflow in either tail)."""
