@@ -1133,17 +1133,20 @@ GCONV_TILE_DEFINE_FP(GCONV_TILE_ONLY_FP)
 static int tile_stagger(int n_tiles, int grid, int walk) {
   static const char* v = getenv("GCONV_TILE_STAGGER");
   const int mode = v ? atoi(v) : GCONV_TILE_STAGGER_DEFAULT;
-  if (mode == 0 || n_tiles < 2 * grid) return 0;
+  if (mode == 0 || n_tiles < (mode >= 2 ? grid + 1 : 2 * grid)) return 0;   // (mode 2: lab — also with one ragged second pass)
   return walk ? 2 : 1;   // the odd / the even workgroups (tile_walk_reversed)
 }
 
-// Output rows (out, dX) non-temporal? One tile per workgroup (a 512-molecule shard): yes, as since round 1. Two or
-// more passes (the whole 4096-molecule batch): default policy — the step runs 3 - 4 % faster (the next kernel reads
-// these rows; the kernel ALONE is slower that way, which is what round 1 measured). GCONV_TILE_STORE_NT=0 / 1 forces.
-static int tile_store_nt(int n_tiles, int grid) {
+// Output rows (out, dX) non-temporal? For small batches yes, as since round 1 (512 molecules, 16 MB per [N, d]
+// tensor: the step is 1 % faster with nt). From 24 MB on the default policy: the next kernel reads these rows, and the
+// step runs faster with them left in the caches — 1024 molecules (31 MB) -3.8 %, 2048 -7.7 %, 4096 -3.4 ... -4.2 %
+// (tools/lab/r05_midsize.sh, r05_storepolicy.sh); the kernel ALONE is slower that way, which is all round 1 measured.
+// GCONV_TILE_STORE_NT=0 / 1 forces.
+constexpr int64_t kStoreDefaultPolicyBytes = 24 << 20;
+static int tile_store_nt(int n, int d) {
   static const char* v = getenv("GCONV_TILE_STORE_NT");
   if (v) return v[0] == '1';
-  return n_tiles >= 2 * grid ? 0 : 1;
+  return static_cast<int64_t>(n) * d * 4 >= kStoreDefaultPolicyBytes ? 0 : 1;
 }
 
 int tile_grid(int n_tiles) {  // persistent: one workgroup per CU
@@ -1158,7 +1161,7 @@ gconv_status_t launch_tile_fwd(TileFwdArgs a, int n_tiles, int tile_nodes_max,
   n_tiles = tile_grid(n_tiles);
   a.stagger = tile_stagger(a.n_tiles, n_tiles, a.stagger);   // (in: the caller's walk bit)
   a.npass = ceil_div(a.n_tiles, n_tiles);
-  a.store_nt = tile_store_nt(a.n_tiles, n_tiles);
+  a.store_nt = tile_store_nt(a.n, a.d);
   a.cap = ceil_div(tile_nodes_max > 0 ? tile_nodes_max : 1, 16) * 16;
   const size_t lds = tile_lds_bytes(a.d, a.fp, tile_nodes_max, tile_edges_max);
   const int threads = tile_threads_fwd(a.d, a.fp);
@@ -1172,7 +1175,7 @@ gconv_status_t launch_tile_bwd(TileBwdArgs a, int n_tiles, int tile_nodes_max,
   n_tiles = tile_grid(n_tiles);
   a.stagger = tile_stagger(a.n_tiles, n_tiles, a.stagger);   // (in: the caller's walk bit)
   a.npass = ceil_div(a.n_tiles, n_tiles);
-  a.store_nt = tile_store_nt(a.n_tiles, n_tiles);
+  a.store_nt = tile_store_nt(a.n, a.d);
   a.cap = ceil_div(tile_nodes_max > 0 ? tile_nodes_max : 1, 16) * 16;
   const size_t lds = tile_lds_bytes(a.d, a.fp, tile_nodes_max, tile_edges_max);
   const int threads = tile_threads_bwd(a.d);

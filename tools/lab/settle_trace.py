@@ -8,7 +8,11 @@ import gconv_adapter_amd as ga
 dev = torch.device("cuda:0")
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 12.0
 name = sys.argv[2] if len(sys.argv) > 2 else "hiv4096"
-stream = bench.BatchStream(name, 0, dev, k=4, fresh=not os.environ.get("GCONV_LAB_STATIC"))   # STATIC: one cached plan
+shard = None
+if os.environ.get("GCONV_LAB_SHARD"):   # "0/2": rank 0's share of the batch cut over 2 ranks (a point of the strong-scaling curve)
+    r, w = os.environ["GCONV_LAB_SHARD"].split("/")
+    shard = (int(r), int(w))
+stream = bench.BatchStream(name, 0, dev, k=4, fresh=not os.environ.get("GCONV_LAB_STATIC"), shard=shard)   # STATIC: one cached plan
 mods = list(bench.build_adapters(stream.cfg, True, dev))
 params = [p for m in mods for p in m.parameters()]
 bench.pin_host_threads()
