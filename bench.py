@@ -290,8 +290,7 @@ def adapter_step(mods, params, stream: BatchStream, normalize: bool, bucket=None
     batch, x, ei, gout = stream.next(normalize)
     if bucket is not None:
         bucket.wait()         # the previous step's all-reduce, before its buffer is written again
-    for p in params:          # optimizer.zero_grad(set_to_none=True)
-        p.grad = None
+    ga.optim.zero_grad(params)     # optimizer.zero_grad(set_to_none=True): one host call for the parameter list
     h = x
     for m in mods:
         h = m(h, ei)

@@ -1270,6 +1270,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("adapter_apply_direct", &adapter_apply_direct);
   m.def("pack_create", &pack_create);
   m.def("pack_release", &pack_release);
+  // `optimizer.zero_grad(set_to_none=True)` for a list of parameters as ONE host call (the loop in Python costs
+  // ~0.28 us per parameter: 7 us of a 155 us ESOL step)
+  m.def("clear_grads", [](const std::vector<at::Tensor>& params) {
+    for (const at::Tensor& p : params)
+      if (p.defined() && p.grad().defined()) p.mutable_grad() = at::Tensor();
+  });
   m.def("set_grad_sink", &set_grad_sink, pybind11::arg("param"), pybind11::arg("dest"),
         pybind11::arg("only_if") = c10::optional<at::Tensor>());
   m.def("plan_submit", &plan_submit);

@@ -231,3 +231,19 @@ class FusedAdam(torch.optim.Optimizer):
                     self.state[p] = mine
             if fl.get("params"):
                 fl["steps"] = [int(self.state[p]["step"]) for p in fl["params"]]
+
+
+def zero_grad(params, set_to_none: bool = True) -> None:
+    """``optimizer.zero_grad(set_to_none=True)`` of the reference's loop (``finetune_inductive_learning.py:49``) for a
+    parameter list as ONE call into the C++ binding (0.3 us per parameter in Python: 7 us of a 155 us ESOL step);
+    falls back to the Python loop without the binding or with ``set_to_none=False``."""
+    from . import _torch_ext
+    ext = _torch_ext.get()
+    if set_to_none and ext is not None and hasattr(ext, "clear_grads"):
+        ext.clear_grads(params if isinstance(params, list) else list(params))
+        return
+    for p in params:
+        if set_to_none:
+            p.grad = None
+        elif p.grad is not None:
+            p.grad.zero_()

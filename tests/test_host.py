@@ -387,3 +387,15 @@ def test_cpu_quota_parsing_and_the_host_core_budget():
     assert set(stats) == {"nr_periods", "nr_throttled", "throttled_usec"}
     q = d.cpu_quota()
     assert q is None or q > 0
+
+
+def test_zero_grad_helper_sets_every_gradient_to_none():
+    import torch
+    ps = [torch.nn.Parameter(torch.randn(3)) for _ in range(4)]
+    for p in ps[:3]:
+        p.grad = torch.ones(3)
+    ga.optim.zero_grad(ps)
+    assert all(p.grad is None for p in ps)
+    ps[0].grad = torch.ones(3)
+    ga.optim.zero_grad(iter(ps[:1]), set_to_none=False)
+    assert torch.equal(ps[0].grad, torch.zeros(3))
