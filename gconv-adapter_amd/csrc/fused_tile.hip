@@ -42,6 +42,13 @@
 #ifndef GCONV_TILE_WGPC
 #define GCONV_TILE_WGPC 1
 #endif
+// Wave priority of the tile kernels' waves when a workgroup walks several tiles (s_setprio at kernel entry): a
+// graph-build wave of the prefetch worker that shares a SIMD with two backward waves then yields its issue slots to
+// them. Round 5, whole 4096-molecule batch, fresh plan per step (tools/lab/r05_prio.sh): 0.8959 / 0.8858 -> 0.8601 /
+// 0.8686 ms (one cached plan: 0.809 either way; the 512-molecule shard, one tile per workgroup, stays at 0).
+#ifndef GCONV_TILE_PRIO
+#define GCONV_TILE_PRIO 3
+#endif
 #ifndef GCONV_TILE_STAGGER_DEFAULT
 #define GCONV_TILE_STAGGER_DEFAULT 1
 #endif
@@ -411,6 +418,7 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
   constexpr int NCB = FP >= 16 ? FP / 16 : 1;
   constexpr int KS = FP / 4;
   constexpr int LPR = FP / 4;
+  if (GCONV_TILE_PRIO && a.npass > 1) __builtin_amdgcn_s_setprio(GCONV_TILE_PRIO);
   TILE_STAMP(8);
   f32x4* wl = lds4;                                              // [NQ][NCB][64]
   float* bufA = reinterpret_cast<float*>(lds4 + NQ * NCB * 64);  // [cap][FP]  H0', later P
@@ -627,6 +635,7 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
   constexpr int NCB = FP >= 16 ? FP / 16 : 1;
   constexpr int KS = FP / 4;
   constexpr int LPR = FP / 4;
+  if (GCONV_TILE_PRIO && a.npass > 1) __builtin_amdgcn_s_setprio(GCONV_TILE_PRIO);
   TILE_STAMP(8);
   f32x4* wl = lds4;                                              // [NQ][NCB][64]  W_up^T frags
   float* bufA = reinterpret_cast<float*>(lds4 + NQ * NCB * 64);  // [cap][FP]  dP', later T
