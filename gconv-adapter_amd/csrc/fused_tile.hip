@@ -49,6 +49,9 @@
 #ifndef GCONV_TILE_PRIO
 #define GCONV_TILE_PRIO 3
 #endif
+#ifndef GCONV_TILE_PRIO_MIN_PASSES   // (lab: 0 = every launch)
+#define GCONV_TILE_PRIO_MIN_PASSES 1
+#endif
 #ifndef GCONV_TILE_STAGGER_DEFAULT
 #define GCONV_TILE_STAGGER_DEFAULT 1
 #endif
@@ -418,7 +421,7 @@ __global__ __launch_bounds__((FP >= 32 || NQ > 19) ? 512 : 640) void tile_fwd_ke
   constexpr int NCB = FP >= 16 ? FP / 16 : 1;
   constexpr int KS = FP / 4;
   constexpr int LPR = FP / 4;
-  if (GCONV_TILE_PRIO && a.npass > 1) __builtin_amdgcn_s_setprio(GCONV_TILE_PRIO);
+  if (GCONV_TILE_PRIO && a.npass > GCONV_TILE_PRIO_MIN_PASSES) __builtin_amdgcn_s_setprio(GCONV_TILE_PRIO);
   TILE_STAMP(8);
   f32x4* wl = lds4;                                              // [NQ][NCB][64]
   float* bufA = reinterpret_cast<float*>(lds4 + NQ * NCB * 64);  // [cap][FP]  H0', later P
@@ -635,7 +638,7 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
   constexpr int NCB = FP >= 16 ? FP / 16 : 1;
   constexpr int KS = FP / 4;
   constexpr int LPR = FP / 4;
-  if (GCONV_TILE_PRIO && a.npass > 1) __builtin_amdgcn_s_setprio(GCONV_TILE_PRIO);
+  if (GCONV_TILE_PRIO && a.npass > GCONV_TILE_PRIO_MIN_PASSES) __builtin_amdgcn_s_setprio(GCONV_TILE_PRIO);
   TILE_STAMP(8);
   f32x4* wl = lds4;                                              // [NQ][NCB][64]  W_up^T frags
   float* bufA = reinterpret_cast<float*>(lds4 + NQ * NCB * 64);  // [cap][FP]  dP', later T

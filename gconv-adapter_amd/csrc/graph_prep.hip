@@ -1031,7 +1031,10 @@ static CountState* usable_state(bool device_block) {
 //                    one-tile-per-CU kernels of the step a second round more often than a dozen 2 - 5 us kernels do
 //   fused            the narrow grid with its two barriers in one launch: 48 us per plan, 0.222 ms/step
 struct CountPlan { int grid; bool split, cooperative; };
-constexpr int32_t kBgSplitMinNodes = 1 << 16;   // background builds of graphs this large: the split counting builder
+// background builds of graphs this large take the split counting builder (2048 molecules = 52 k nodes: 0.4927 -> 0.4772
+// ms/step against the radix pipeline; 1024 molecules = 26 k nodes: equal; 512: radix 0.2003 against 0.2037 —
+// tools/lab/r05_prio2.sh)
+constexpr int32_t kBgSplitMinNodes = 1 << 15;
 static CountPlan count_plan(bool background, int32_t num_nodes) {
   struct Caps { int wide = -1, narrow = -1; };
   static Caps caps[16];
@@ -1064,7 +1067,8 @@ static CountPlan count_plan(bool background, int32_t num_nodes) {
     // Round 5, next to the whole 4096-molecule batch's step (103 k nodes; tools/lab/r05_bg.sh, one box, medians over 4 s):
     // radix pipeline 0.9637 ms/step, the counting builder as three narrow launches 0.9400, three wide ones 0.9490, one
     // narrow launch 0.9626 (0.8459 with one cached plan); next to the 512-molecule shard's step the radix pipeline
-    // stays the best neighbour (0.2157 against 0.2231 / 0.2398 / 0.2303). Hence by size (GCONV_BG_BUILD=radix forces).
+    // stays the best neighbour (0.2157 against 0.2231 / 0.2398 / 0.2303). Hence by size (GCONV_BG_BUILD=radix forces);
+    // the threshold was then placed between the 1024- and the 2048-molecule batch (kBgSplitMinNodes).
     if (!(bg && bg[0] == 'r') && num_nodes >= kBgSplitMinNodes) return {kCountGridNarrow, true, false};
     return {0, false, false};                          // radix pipeline (measured: least disturbance, see above)
   }
