@@ -197,7 +197,7 @@ class BatchStream:
     DataLoader's prefetching workers play for collation in the reference."""
 
     def __init__(self, name: str, rank: int, device, k: int, fresh: bool, prefetch: bool = True,
-                 shard=None, depth: int = 2):
+                 shard=None, depth: int = 2, rotate: bool = False):
         self.fresh = fresh
         self.prefetch = prefetch   # False: the plan is built in-stream by the step's first adapter
         # plans are built `depth` batches ahead — torch's DataLoader keeps prefetch_factor = 2 batches per
@@ -208,7 +208,7 @@ class BatchStream:
         self.depth = max(1, min(int(os.environ.get("GCONV_BENCH_PREFETCH_DEPTH", depth)), k - 1)) if fresh else 1
         self.items = []
         cfg = None
-        for i in range(k if fresh else 1):
+        for i in range(k if fresh or rotate else 1):   # (rotate: lab — k batches in turn, their plans kept)
             if shard is None:
                 batch, cfg = ga.synth.make_workload(name, seed=rank * 1000 + i)
             else:                  # strong scaling: every rank cuts ITS graphs out of the same batch
@@ -226,6 +226,8 @@ class BatchStream:
         # ESOL 0.154 -> 0.159 ms). GCONV_BENCH_PREFETCH_AT=top|backward forces one (A/B).
         nodes = max(int(b.num_nodes) for b, *_ in self.items)
         self.prefetch_beside_backward = (PREFETCH_AT == "backward") if PREFETCH_AT in ("top", "backward") else nodes >= 4096
+        self.ready_event = (ga.CompletionEvent() if self.prefetch_beside_backward and self.fresh
+                            and not os.environ.get("GCONV_NO_COMPLETION_EVENT") else None)
 
     def avg(self, attr) -> float:
         return sum(float(getattr(b, attr)) for b, *_ in self.items) / len(self.items)
@@ -237,7 +239,7 @@ class BatchStream:
         self.pos += 1
         return batch, x, ei, gout
 
-    def start_prefetch(self, normalize: bool, step: Optional[int] = None) -> None:
+    def start_prefetch(self, normalize: bool, step: Optional[int] = None, ready=None) -> None:
         """Starts the graph build of the batch `depth` steps ahead (all of the first `depth` batches before the
         first step). The build's side stream waits for what the main stream holds at THIS point
         (`prefetch_plan`: an event recorded at submit time), so WHERE the loop calls it decides what the build
@@ -245,7 +247,9 @@ class BatchStream:
         forward kernels — 10 waves x 168 VGPRs per CU: no build wave fits next to them, every CU a build
         workgroup holds is lost to the forward — the whole-batch step paid 100 us (forward kernels 62 -> 82 us
         each, tools/lab/r05_k0trace.sh); the backward kernels (8 waves x 203 VGPRs) leave room and do not slow down.
-        GCONV_BENCH_PREFETCH_AT=top: at the top of the step, as in rounds 1-4 (A/B)."""
+        GCONV_BENCH_PREFETCH_AT=top: at the top of the step, as in rounds 1-4 (A/B). `ready`: a `CompletionEvent` the
+        forward pass's last adapter call has been armed with — the build waits for that kernel's own completion signal
+        and nothing is queued on the main stream (GCONV_NO_COMPLETION_EVENT=1: the recorded event, A/B)."""
         if not (self.fresh and self.prefetch):
             return
         if step is None:
@@ -253,7 +257,7 @@ class BatchStream:
         ahead = range(1, self.depth + 1) if step == 0 else (self.depth,)
         for a in ahead:
             _, nx, nei, _ = self.items[(step + a) % len(self.items)]
-            ga.prefetch_plan(nei, nx.shape[-2], normalize)
+            ga.prefetch_plan(nei, nx.shape[-2], normalize, ready=ready)
 
 
 class StoreStream:
@@ -291,17 +295,21 @@ def adapter_step(mods, params, stream: BatchStream, normalize: bool, bucket=None
     if bucket is not None:
         bucket.wait()         # the previous step's all-reduce, before its buffer is written again
     ga.optim.zero_grad(params)     # optimizer.zero_grad(set_to_none=True): one host call for the parameter list
+    beside = isinstance(stream, BatchStream) and stream.prefetch_beside_backward and stream.pos > 1
     h = x
-    for m in mods:
+    for m in mods[:-1]:
         h = m(h, ei)
-    if isinstance(stream, BatchStream) and stream.prefetch_beside_backward and stream.pos > 1:
-        stream.start_prefetch(normalize)   # the next batches' graph build runs beside the BACKWARD pass
+    if beside and stream.ready_event is not None:
+        stream.ready_event.arm()       # the last forward kernel's completion is what the build waits for
+    h = mods[-1](h, ei)
+    if beside:
+        stream.start_prefetch(normalize, ready=stream.ready_event)   # the next batches' graph build runs beside the BACKWARD pass
     h.backward(gout)
     if bucket is not None:
         # the backward pass has written every gradient into the flat bucket (gradient sinks):
         # ONE collective, launched behind the backward, waited for at the top of the next step
         bucket.all_reduce_grads(async_op=True)
-    if stream.fresh or isinstance(stream, StoreStream):
+    if (stream.fresh or isinstance(stream, StoreStream)) and not os.environ.get("GCONV_LAB_NO_DISCARD"):
         ga.PLAN_CACHE.discard(ei, x.shape[-2], normalize)   # a training batch is seen once
     return batch.num_graphs
 

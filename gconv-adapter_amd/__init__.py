@@ -6,7 +6,7 @@ repo-root module ``gconv_adapter_amd.py`` aliases it, so
 """
 from .adapter import GConvAdapter, GCNConvParams
 from .functional import GConvAdapterFunction, gconv_adapter, spmm, gemm_down, gemm_up_fused
-from .graph import GraphPlan, PlanCache, PLAN_CACHE, get_plan, prefetch_plan
+from .graph import GraphPlan, PlanCache, PLAN_CACHE, get_plan, prefetch_plan, CompletionEvent
 from .hydra_compat import instantiate, load_finetune_config
 from . import synth, dist, optim, data, partition, gin, norm, relbias, readout, _lib, _torch_ext
 from .data import MoleculeStore
@@ -33,7 +33,7 @@ def register_ops():
 
 __all__ = [
     "GConvAdapter", "GCNConvParams", "GConvAdapterFunction", "gconv_adapter", "spmm",
-    "gemm_down", "gemm_up_fused", "GraphPlan", "PlanCache", "PLAN_CACHE", "get_plan", "prefetch_plan",
+    "gemm_down", "gemm_up_fused", "GraphPlan", "PlanCache", "PLAN_CACHE", "get_plan", "prefetch_plan", "CompletionEvent",
     "instantiate", "load_finetune_config", "synth", "dist", "optim", "FusedAdam", "data", "MoleculeStore",
     "partition", "RowSlabGConvAdapter", "RowSlabs", "gin", "MolecularGINConv", "norm", "BatchNorm1d", "sync_batch_norm",
     "relbias", "add_conv_relational_bias", "register_ops", "readout", "global_mean_pool", "global_add_pool", "masked_loss",

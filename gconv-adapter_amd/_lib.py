@@ -96,7 +96,7 @@ class PendingFinalize(C.Structure):
 
 FINALIZE_BATCH = 5
 BUILD_BACKGROUND = 1   # GCONV_BUILD_BACKGROUND
-ABI_VERSION = 10   # GCONV_ABI_VERSION of include/gconv_adapter.h this binding was written against
+ABI_VERSION = 11   # GCONV_ABI_VERSION of include/gconv_adapter.h this binding was written against
 
 
 class AdapterParams(C.Structure):
@@ -122,6 +122,7 @@ _graph_p = C.POINTER(GraphStruct)
 #: name -> (restype, argtypes); must list every function declared in include/gconv_adapter.h
 SIGNATURES = {
     "gconv_abi_version": (_i32, []),
+    "gconv_arm_completion_event": (_i32, [C.c_void_p]),
     "gconv_abi_struct_bytes": (_i32, [_i32]),
     "gconv_status_string": (C.c_char_p, [_i32]),
     "gconv_padded_rank": (_i32, [_i32]),

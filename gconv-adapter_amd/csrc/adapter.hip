@@ -239,9 +239,19 @@ static gconv_status_t fwd_stages(const gconv_graph_t* gr, const gconv_adapter_pa
 // `keep` = the caller's saved_* buffers are the outputs of a training forward; !keep = forward only
 // (gconv_adapter_infer_f32): the tile path stores nothing but `out`, the general path carves its two or three
 // rank-width intermediates out of the workspace behind the forward's own scratch.
+// The armed completion event of the calling thread (gconv_arm_completion_event): taken — armed or not used — by the
+// next forward call, whatever that call returns.
+static thread_local void* t_armed_event = nullptr;
+extern "C" gconv_status_t gconv_arm_completion_event(void* event) {
+  t_armed_event = event;
+  return GCONV_OK;
+}
+
 static gconv_status_t adapter_forward(const gconv_graph_t* gr, const gconv_adapter_params_t* p, const float* x,
                                       float* out, float* saved_h, float* saved_h1, float* saved_p, bool keep,
                                       void* workspace, size_t workspace_bytes, gconv_stream_t stream_) {
+  void* const done_event = t_armed_event;
+  t_armed_event = nullptr;
   if (!gr) return GCONV_E_INVALID_ARG;
   const gconv_csr_t* graph = &gr->fwd;
   const float* dis = gr->dis;
@@ -268,7 +278,7 @@ static gconv_status_t adapter_forward(const gconv_graph_t* gr, const gconv_adapt
 #ifdef GCONV_TILE_STAMPS
     t.stamps = static_cast<long long*>(workspace);   // diagnostic build: workspace = stamp buffer
 #endif
-    return launch_tile_fwd(t, gr->n_tiles, gr->tile_nodes_max, gr->tile_edges_max, stream);
+    return launch_tile_fwd(t, gr->n_tiles, gr->tile_nodes_max, gr->tile_edges_max, stream, done_event);
   }
   const FwdWs ws = carve_fwd(workspace, graph, fp);
   size_t need = ws.bytes;
@@ -282,7 +292,10 @@ static gconv_status_t adapter_forward(const gconv_graph_t* gr, const gconv_adapt
     need = c.off;
   }
   if (workspace_bytes < need) return GCONV_E_WORKSPACE;
-  return fwd_stages(gr, p, 0, n, 7, x, out, ws.h0, saved_h, saved_h1, saved_p, ws.seg, stream);
+  st = fwd_stages(gr, p, 0, n, 7, x, out, ws.h0, saved_h, saved_h1, saved_p, ws.seg, stream);
+  if (st == GCONV_OK && done_event && hipEventRecord(static_cast<hipEvent_t>(done_event), stream) != hipSuccess)
+    return GCONV_E_INVALID_ARG;   // (several launches: an ordinary record behind the last one)
+  return st;
 }
 
 extern "C" gconv_status_t gconv_adapter_fwd_f32(const gconv_graph_t* gr,

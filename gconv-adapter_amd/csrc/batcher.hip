@@ -204,7 +204,7 @@ extern "C" gconv_status_t gconv_graph_from_store(const gconv_graph_t* dataset, c
   if (L.ntiles <= kNumCU) {   // one tile per persistent workgroup: node order, no sort (see gconv_graph_build)
     tiles = recs;
   } else if (L.ntiles <= kSmallSortMax) {
-    tile_sort_small_kernel<<<1, 1024, 0, stream>>>(recs, nullptr, L.ntiles, tiles, nullptr);
+    tile_sort_small(recs, nullptr, L.ntiles, tiles, nullptr, stream);
     GCONV_LAUNCH_CHECK();
   } else {
     uint32_t* key = reinterpret_cast<uint32_t*>(arena + L.key);

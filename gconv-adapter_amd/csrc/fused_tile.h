@@ -40,8 +40,9 @@ size_t tile_lds_bytes(int d, int fp, int tile_nodes_max, int tile_edges_max);
 // workgroups the tile kernels are launched with (= partial rows of the backward)
 int tile_grid(int n_tiles);
 
+// done_event: nullable hipEvent_t recorded by the launch's own completion (gconv_arm_completion_event)
 gconv_status_t launch_tile_fwd(TileFwdArgs a, int n_tiles, int tile_nodes_max, int tile_edges_max,
-                               hipStream_t stream);
+                               hipStream_t stream, void* done_event = nullptr);
 gconv_status_t launch_tile_bwd(TileBwdArgs a, int n_tiles, int tile_nodes_max, int tile_edges_max,
                                hipStream_t stream);
 

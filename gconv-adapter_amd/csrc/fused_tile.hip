@@ -24,6 +24,8 @@
 // path (adapter.hip); replaces /root/reference/src/finetune/gconv_adapter.py:80-108 and
 // its autograd backward for the batches the inductive script feeds it
 // (scripts/finetune_inductive_learning.py:43-67).
+#include <hip/hip_ext.h>
+
 #include <atomic>
 #include <cstdlib>
 #include <type_traits>
@@ -1059,11 +1061,17 @@ bool tile_path_ok(const gconv_graph_t* g, int d, int fp) {
 
 template <int FP, int NQ>
 static gconv_status_t launch_tile_fwd_t(const TileFwdArgs& a, int grid, int threads, size_t lds,
-                                        hipStream_t stream) {
-#define GCONV_TILE_FWD_LAUNCH(NORM_, NT_)                                       \
-  do {                                                                          \
-    GCONV_TILE_LDS_OPT_IN((tile_fwd_kernel<FP, NQ, NORM_, NT_>));               \
-    tile_fwd_kernel<FP, NQ, NORM_, NT_><<<grid, threads, lds, stream>>>(a);     \
+                                        hipStream_t stream, hipEvent_t done) {
+  // `done` (gconv_arm_completion_event): recorded by the kernel's OWN completion signal — an event recorded behind the
+  // launch is a barrier packet in front of the stream's next kernel (6.5 us of idle GPU in the whole-batch step)
+#define GCONV_TILE_FWD_LAUNCH(NORM_, NT_)                                                                      \
+  do {                                                                                                         \
+    GCONV_TILE_LDS_OPT_IN((tile_fwd_kernel<FP, NQ, NORM_, NT_>));                                              \
+    if (done)                                                                                                  \
+      hipExtLaunchKernelGGL((tile_fwd_kernel<FP, NQ, NORM_, NT_>), dim3(grid), dim3(threads), lds, stream,     \
+                            nullptr, done, 0, a);                                                              \
+    else                                                                                                       \
+      tile_fwd_kernel<FP, NQ, NORM_, NT_><<<grid, threads, lds, stream>>>(a);                                  \
   } while (0)
   if (a.dis) {
     if (a.store_nt) GCONV_TILE_FWD_LAUNCH(true, true); else GCONV_TILE_FWD_LAUNCH(true, false);
@@ -1111,14 +1119,15 @@ static gconv_status_t launch_tile_bwd_t(const TileBwdArgs& a, int grid, int thre
     default: return GCONV_E_UNSUPPORTED;                                                \
   }
 template <int FP>
-gconv_status_t launch_tile_fwd_fp(const TileFwdArgs& a, int nq, int grid, int threads, size_t lds, hipStream_t stream);
+gconv_status_t launch_tile_fwd_fp(const TileFwdArgs& a, int nq, int grid, int threads, size_t lds, hipStream_t stream,
+                                 hipEvent_t done);
 template <int FP>
 gconv_status_t launch_tile_bwd_fp(const TileBwdArgs& a, int nq, int grid, int threads, size_t lds, hipStream_t stream);
 #define GCONV_TILE_DEFINE_FP(FP_)                                                                          \
   template <>                                                                                              \
   gconv_status_t launch_tile_fwd_fp<FP_>(const TileFwdArgs& a, int nq, int grid, int threads, size_t lds,  \
-                                         hipStream_t stream) {                                             \
-    GCONV_TILE_NQ_SWITCH(launch_tile_fwd_t, FP_, (a, grid, threads, lds, stream))                          \
+                                         hipStream_t stream, hipEvent_t done) {                            \
+    GCONV_TILE_NQ_SWITCH(launch_tile_fwd_t, FP_, (a, grid, threads, lds, stream, done))                    \
   }                                                                                                        \
   template <>                                                                                              \
   gconv_status_t launch_tile_bwd_fp<FP_>(const TileBwdArgs& a, int nq, int grid, int threads, size_t lds,  \
@@ -1167,7 +1176,7 @@ int tile_grid(int n_tiles) {  // persistent: one workgroup per CU
 }
 
 gconv_status_t launch_tile_fwd(TileFwdArgs a, int n_tiles, int tile_nodes_max,
-                               int tile_edges_max, hipStream_t stream) {
+                               int tile_edges_max, hipStream_t stream, void* done_event) {
   const int nq = tile_nq(a.d);
   a.n_tiles = n_tiles;
   n_tiles = tile_grid(n_tiles);
@@ -1177,7 +1186,7 @@ gconv_status_t launch_tile_fwd(TileFwdArgs a, int n_tiles, int tile_nodes_max,
   a.cap = ceil_div(tile_nodes_max > 0 ? tile_nodes_max : 1, 16) * 16;
   const size_t lds = tile_lds_bytes(a.d, a.fp, tile_nodes_max, tile_edges_max);
   const int threads = tile_threads_fwd(a.d, a.fp);
-  GCONV_TILE_DISPATCH(launch_tile_fwd_fp, (a, nq, n_tiles, threads, lds, stream))
+  GCONV_TILE_DISPATCH(launch_tile_fwd_fp, (a, nq, n_tiles, threads, lds, stream, static_cast<hipEvent_t>(done_event)))
 }
 
 gconv_status_t launch_tile_bwd(TileBwdArgs a, int n_tiles, int tile_nodes_max,

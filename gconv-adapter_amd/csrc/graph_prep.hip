@@ -1107,7 +1107,7 @@ static gconv_status_t sort_tiles(const Layout& L, char* arena, gconv_tile_t* rec
     g->tiles_fwd.tiles = recs_f;
     g->tiles_bwd.tiles = recs_b ? recs_b : recs_f;
   } else if (L.ntiles <= kSmallSortMax) {
-    tile_sort_small_kernel<<<1, 1024, 0, stream>>>(recs_f, recs_b, L.ntiles, tiles_f, tiles_b);
+    tile_sort_small(recs_f, recs_b, L.ntiles, tiles_f, tiles_b, stream);
     GCONV_LAUNCH_CHECK();
   } else {  // largest tile first; stable, so the order is a function of the graph alone
     uint32_t* key = reinterpret_cast<uint32_t*>(arena + L.tile_key);

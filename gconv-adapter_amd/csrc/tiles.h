@@ -343,24 +343,51 @@ __global__ __launch_bounds__(256) void tile_build_kernel(const int32_t* __restri
 // workgroup ranks every tile by (rows incl. halo descending, tile index ascending) — the order a
 // stable sort gives — and writes the records of both directions in that order. The persistent
 // workgroups deal themselves tiles from this list boustrophedon, so no workgroup gets two big ones.
-constexpr int kSmallSortMax = 2048;
-static __global__ __launch_bounds__(1024) void tile_sort_small_kernel(const gconv_tile_t* __restrict__ recs_f,
-                                                                      const gconv_tile_t* __restrict__ recs_b,
-                                                                      int ntiles, gconv_tile_t* __restrict__ out_f,
-                                                                      gconv_tile_t* __restrict__ out_b) {
-  __shared__ int32_t size[kSmallSortMax];
-  for (int t = threadIdx.x; t < ntiles; t += 1024) size[t] = recs_f[t].n0;
-  __syncthreads();
-  for (int t = threadIdx.x; t < ntiles; t += 1024) {
-    const int sz = size[t];
-    int rank = 0;
-    for (int u = 0; u < ntiles; ++u) {
-      const int su = size[u];
-      rank += (su > sz) || (su == sz && u < t);
-    }
-    out_f[rank] = recs_f[t];
-    if (recs_b) out_b[rank] = recs_b[t];
+// Four waves, PER tiles per thread, one unique key per tile ((size descending) : index) in LDS: a
+// tile's rank is the number of smaller keys. (Round 5: this was one 1024-thread workgroup of 40
+// VGPRs — 160 per SIMD, which does not fit beside a backward tile workgroup (2 x 208 of 512): on
+// the side stream it waited for a CU to fall free at a kernel boundary and the next tile kernel's
+// workgroup for that CU then waited for IT. One wave per SIMD under 96 VGPRs runs beside.)
+constexpr int kSmallSortMax = 2048, kSmallSortThreads = 256;
+template <int PER>
+static __global__ __launch_bounds__(kSmallSortThreads) void tile_sort_small_kernel(const gconv_tile_t* __restrict__ recs_f,
+                                                                                   const gconv_tile_t* __restrict__ recs_b,
+                                                                                   int ntiles, gconv_tile_t* __restrict__ out_f,
+                                                                                   gconv_tile_t* __restrict__ out_b) {
+  static_assert(PER * kSmallSortThreads <= kSmallSortMax, "a key per tile in LDS");
+  __shared__ uint32_t key[kSmallSortMax];
+  const int tid = threadIdx.x;
+  uint32_t mine[PER];
+  int rank[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int t = tid + j * kSmallSortThreads;
+    // (11 bits of index below 2048 tiles; a tile has fewer than 2^20 rows)
+    mine[j] = t < ntiles ? (static_cast<uint32_t>(0xFFFFF - min(recs_f[t].n0, 0xFFFFF)) << 11) | static_cast<uint32_t>(t) : 0xFFFFFFFFu;
+    if (t < ntiles) key[t] = mine[j];
+    rank[j] = 0;
   }
+  __syncthreads();
+  for (int u = 0; u < ntiles; ++u) {
+    const uint32_t ku = key[u];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) rank[j] += ku < mine[j] ? 1 : 0;
+  }
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int t = tid + j * kSmallSortThreads;
+    if (t < ntiles) {
+      out_f[rank[j]] = recs_f[t];
+      if (recs_b) out_b[rank[j]] = recs_b[t];
+    }
+  }
+}
+// (queued on `stream`; ntiles <= kSmallSortMax)
+static inline void tile_sort_small(const gconv_tile_t* recs_f, const gconv_tile_t* recs_b, int ntiles, gconv_tile_t* out_f,
+                                   gconv_tile_t* out_b, hipStream_t stream) {
+  if (ntiles <= 2 * kSmallSortThreads) tile_sort_small_kernel<2><<<1, kSmallSortThreads, 0, stream>>>(recs_f, recs_b, ntiles, out_f, out_b);
+  else if (ntiles <= 4 * kSmallSortThreads) tile_sort_small_kernel<4><<<1, kSmallSortThreads, 0, stream>>>(recs_f, recs_b, ntiles, out_f, out_b);
+  else tile_sort_small_kernel<8><<<1, kSmallSortThreads, 0, stream>>>(recs_f, recs_b, ntiles, out_f, out_b);
 }
 
 // large tile counts: stable radix sort of (key, tile id) pairs, then this gather

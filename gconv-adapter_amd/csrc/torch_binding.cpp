@@ -79,8 +79,11 @@ using gin_agg_fn_t = gconv_status_t (*)(const gconv_csr_t*, const float*, const 
 using gin_agg_pair_fn_t = gconv_status_t (*)(const gconv_csr_t*, const float*, const int32_t*, const float*,
                                              const float*, void*, int32_t, gconv_stream_t);
 
+using arm_fn_t = gconv_status_t (*)(void*);
+
 struct Lib {
   void* handle = nullptr;
+  arm_fn_t arm = nullptr;
   bn_bytes_fn_t bn_bytes = nullptr;
   bn_fwd_fn_t bn_fwd = nullptr;
   bn_bwd_fn_t bn_bwd = nullptr;
@@ -115,6 +118,7 @@ void load_library(const std::string& path) {
   g_lib.fwd = reinterpret_cast<fwd_fn_t>(dlsym(h, "gconv_adapter_fwd_f32"));
   g_lib.bwd = reinterpret_cast<bwd_fn_t>(dlsym(h, "gconv_adapter_bwd_f32"));
   g_lib.infer = reinterpret_cast<infer_fn_t>(dlsym(h, "gconv_adapter_infer_f32"));
+  g_lib.arm = reinterpret_cast<arm_fn_t>(dlsym(h, "gconv_arm_completion_event"));
   g_lib.str = reinterpret_cast<str_fn_t>(dlsym(h, "gconv_status_string"));
   g_lib.build_bytes = reinterpret_cast<bytes_fn_t>(dlsym(h, "gconv_graph_build_bytes"));
   g_lib.build = reinterpret_cast<build_fn_t>(dlsym(h, "gconv_graph_build"));
@@ -140,7 +144,7 @@ void load_library(const std::string& path) {
   TORCH_CHECK(g_lib.bn_bytes && g_lib.bn_fwd && g_lib.bn_bwd && g_lib.pair_bytes && g_lib.split_rows &&
                   g_lib.pair_gemm && g_lib.gin_agg && g_lib.gin_agg_pair,
               "gconv_adapter_amd: C ABI symbols of the fine-tune surroundings missing in ", path);
-  TORCH_CHECK(g_lib.fwd && g_lib.infer && g_lib.bwd && g_lib.str && g_lib.build_bytes && g_lib.build && g_lib.bwd_partial &&
+  TORCH_CHECK(g_lib.fwd && g_lib.infer && g_lib.arm && g_lib.bwd && g_lib.str && g_lib.build_bytes && g_lib.build && g_lib.bwd_partial &&
                   g_lib.bwd_finalize && g_lib.ln_fwd && g_lib.ln_bwd && g_lib.ln_bytes && g_lib.padded_rank &&
                   g_lib.ws_fwd && g_lib.ws_bwd && g_lib.spmm_ws && g_lib.spmm && g_lib.build_ex,
               "gconv_adapter_amd: C ABI symbols missing in ", path);
@@ -673,15 +677,21 @@ at::Tensor adapter_apply(at::Tensor x, at::Tensor w_down, c10::optional<at::Tens
 //
 // Memory: the arena is allocated by the submitting thread on ITS current stream; the side
 // stream first waits for an event recorded there at submit time (edge_index is complete and
-// every earlier use of the recycled block has drained). gconv_graph_build returns with its last
-// launch (the size sort of the component tiles) still queued on the side stream, so the worker
-// records a second event behind the build and plan_take() makes the CONSUMER's stream wait for it.
+// every earlier use of the recycled block has drained) — or for the caller's completion event
+// (gconv_arm_completion_event). gconv_graph_build returns with its last launch (the size sort of the
+// component tiles) still queued on the side stream: the worker synchronises the side stream once more, so
+// a plan that plan_take() hands out has nothing pending anywhere and the consumer's stream waits for nothing.
 // ---------------------------------------------------------------------------------------
+// Events that only ORDER device work (the build's side stream behind the caller's stream): no timing, device-scope
+// release (the scope makes no measurable difference here: 4.9 against 5.0 us in front of the stream's next kernel).
+static const unsigned kOrderingEventFlags = hipEventDisableTiming | hipEventReleaseToDevice;
+
 struct PlanJob {
   at::Tensor edge_index, arena;
   int64_t num_edges = 0;
   int32_t num_nodes = 0, normalize = 0, device = 0;
-  hipEvent_t ready = nullptr, built = nullptr;
+  hipEvent_t ready = nullptr;
+  bool own_ready = true;   // false: the caller's completion event (plan_submit's ready_event)
   void* side_stream = nullptr;
   gconv_graph_t graph{};
   gconv_status_t status = 0;
@@ -699,8 +709,10 @@ class PlanWorker {
     if (thread_.joinable()) thread_.join();
   }
 
+  // ready_event: 0, or a hipEvent_t that is (or will be, by a launch already made) recorded on `main_stream` behind
+  // everything the build has to wait for — the submitting thread then queues nothing on its stream here
   int64_t submit(at::Tensor edge_index, int64_t num_nodes, bool normalize, int64_t main_stream,
-                 int64_t side_stream) {
+                 int64_t side_stream, int64_t ready_event) {
     TORCH_CHECK(g_lib.handle, "gconv_adapter_amd: library not loaded");
     TORCH_CHECK(edge_index.is_cuda() && edge_index.scalar_type() == at::kLong && edge_index.dim() == 2 &&
                     edge_index.size(0) == 2 && edge_index.is_contiguous(),
@@ -714,10 +726,14 @@ class PlanWorker {
     job->side_stream = reinterpret_cast<void*>(side_stream);
     const size_t bytes = g_lib.build_bytes(job->num_edges, job->num_nodes);
     job->arena = at::empty({static_cast<int64_t>(bytes)}, edge_index.options().dtype(at::kByte));
-    TORCH_CHECK(hipEventCreateWithFlags(&job->ready, hipEventDisableTiming) == hipSuccess &&
-                    hipEventCreateWithFlags(&job->built, hipEventDisableTiming) == hipSuccess &&
-                    hipEventRecord(job->ready, reinterpret_cast<hipStream_t>(main_stream)) == hipSuccess,
-                "gconv_adapter_amd: cannot record the prefetch event");
+    if (ready_event != 0) {
+      job->ready = reinterpret_cast<hipEvent_t>(ready_event);
+      job->own_ready = false;
+    } else {
+      TORCH_CHECK(hipEventCreateWithFlags(&job->ready, kOrderingEventFlags) == hipSuccess &&
+                      hipEventRecord(job->ready, reinterpret_cast<hipStream_t>(main_stream)) == hipSuccess,
+                  "gconv_adapter_amd: cannot record the prefetch event");
+    }
     std::lock_guard<std::mutex> lk(mu_);
     const int64_t id = next_id_++;
     jobs_[id] = job;
@@ -727,8 +743,7 @@ class PlanWorker {
     return id;
   }
 
-  // (arena, gconv_graph_t bytes, status); blocks until the build call has returned and orders
-  // `consumer_stream` behind everything the build queued on the side stream
+  // (arena, gconv_graph_t bytes, status); blocks until the build call has returned and the side stream has drained
   std::tuple<at::Tensor, py::bytes, int64_t> take(int64_t id, int64_t consumer_stream) {
     std::shared_ptr<PlanJob> job;
     {
@@ -741,11 +756,10 @@ class PlanWorker {
       jobs_.erase(it);
     }
     gconv_status_t st = job->status;
-    if (st == 0)   // status > 0 is a hipError_t
-      st = static_cast<gconv_status_t>(
-          hipStreamWaitEvent(reinterpret_cast<hipStream_t>(consumer_stream), job->built, 0));
-    (void)hipEventDestroy(job->ready);
-    (void)hipEventDestroy(job->built);
+    // status > 0 is a hipError_t. The worker has synchronised the side stream behind the build's last launch:
+    // nothing is pending there, the consumer's stream needs no wait (see run()).
+    (void)consumer_stream;
+    if (job->own_ready) (void)hipEventDestroy(job->ready);
     job->status = st;
     return {job->arena, py::bytes(reinterpret_cast<const char*>(&job->graph), sizeof(gconv_graph_t)),
             static_cast<int64_t>(job->status)};
@@ -774,7 +788,12 @@ class PlanWorker {
         st = g_lib.build_ex(job->edge_index.data_ptr<int64_t>(), job->num_edges, job->num_nodes, job->normalize,
                             GCONV_BUILD_BACKGROUND, job->arena.data_ptr(), static_cast<size_t>(job->arena.numel()),
                             &job->graph, side);
-      if (st == 0) st = static_cast<gconv_status_t>(hipEventRecord(job->built, side));
+      // gconv_graph_build returns with its last launch (the size sort of > 256 tiles) still queued: wait for it here,
+      // on this thread, so that the consumer needs no cross-stream wait. An event recorded behind the sort and
+      // queried / waited for by plan_take cost the consumer stream's next kernel 6 us of idle GPU every step
+      // (tools/lab/r05_timeline.sh: the gap in front of the step's first kernel; gone with the event). Only batches of
+      // more than 256 tiles have that launch, and their steps leave the host the time.
+      if (st == 0) st = static_cast<gconv_status_t>(hipStreamSynchronize(side));
       {
         std::lock_guard<std::mutex> lk(mu_);
         job->status = st;
@@ -799,8 +818,20 @@ PlanWorker& worker() {
 }
 
 int64_t plan_submit(at::Tensor edge_index, int64_t num_nodes, bool normalize, int64_t main_stream,
-                    int64_t side_stream) {
-  return worker().submit(std::move(edge_index), num_nodes, normalize, main_stream, side_stream);
+                    int64_t side_stream, int64_t ready_event) {
+  return worker().submit(std::move(edge_index), num_nodes, normalize, main_stream, side_stream, ready_event);
+}
+// a HIP event for gconv_arm_completion_event (graph.CompletionEvent owns it)
+int64_t event_create() {
+  hipEvent_t ev = nullptr;
+  TORCH_CHECK(hipEventCreateWithFlags(&ev, kOrderingEventFlags) == hipSuccess, "gconv_adapter_amd: hipEventCreate failed");
+  return reinterpret_cast<int64_t>(ev);
+}
+void event_destroy(int64_t ev) { (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(ev)); }
+bool event_query(int64_t ev) { return hipEventQuery(reinterpret_cast<hipEvent_t>(ev)) == hipSuccess; }
+void arm_completion_event(int64_t ev) {
+  TORCH_CHECK(g_lib.handle, "gconv_adapter_amd: library not loaded");
+  check(g_lib.arm(reinterpret_cast<void*>(ev)), "arm_completion_event");
 }
 std::tuple<at::Tensor, py::bytes, int64_t> plan_take(int64_t id, int64_t consumer_stream) {
   return worker().take(id, consumer_stream);
@@ -1279,6 +1310,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("set_grad_sink", &set_grad_sink, pybind11::arg("param"), pybind11::arg("dest"),
         pybind11::arg("only_if") = c10::optional<at::Tensor>());
   m.def("plan_submit", &plan_submit);
+  m.def("event_create", &event_create);
+  m.def("event_destroy", &event_destroy);
+  m.def("event_query", &event_query);
+  m.def("arm_completion_event", &arm_completion_event);
   m.def("plan_take", &plan_take);
   m.def("layer_norm_scale", &layer_norm_scale);
   m.def("batch_norm", &batch_norm);

@@ -245,8 +245,8 @@ class PlanCache:
         fut = self._pending.pop(key, None)
         if isinstance(fut, tuple):                # (job id, edge_index) of the native worker
             from . import _torch_ext
-            # plan_take orders this stream behind the side stream's last launch (the tile size sort
-            # is queued after the build's final host synchronisation)
+            # plan_take returns once the worker has seen the side stream drain (the tile size sort is queued
+            # behind the build's host synchronisation; the worker waits for it too): nothing to order here
             plan = GraphPlan(fut[1], num_nodes, normalize, _built=_torch_ext.get().plan_take(
                 fut[0], torch._C._cuda_getCurrentRawStream(fut[1].device.index)))
             self.hits += 1
@@ -268,8 +268,12 @@ class PlanCache:
         """Registers a plan that was built elsewhere (``data.MoleculeStore``) for this tensor."""
         self._store(self._key(edge_index, num_nodes, normalize), edge_index, plan)
 
-    def prefetch(self, edge_index: torch.Tensor, num_nodes: int, normalize: bool) -> None:
-        """Starts building the plan of a future batch; returns immediately."""
+    def prefetch(self, edge_index: torch.Tensor, num_nodes: int, normalize: bool,
+                 ready: Optional["CompletionEvent"] = None) -> None:
+        """Starts building the plan of a future batch; returns immediately. The build's side stream waits for what
+        the current stream holds now (an event recorded here) — or, with ``ready``, for that event alone: a
+        ``CompletionEvent`` armed in front of an adapter forward that has already been called (nothing is queued on
+        the current stream then)."""
         key = self._key(edge_index, num_nodes, normalize)
         if key in self._entries or key in self._pending:
             return
@@ -287,8 +291,9 @@ class PlanCache:
             ei = edge_index if edge_index.is_contiguous() else edge_index.contiguous()
             with torch.cuda.device(dev):
                 job = ext.plan_submit(ei, int(num_nodes), bool(normalize),
-                                      torch._C._cuda_getCurrentRawStream(dev.index), side.cuda_stream)
-            self._pending[key] = (job, ei)
+                                      torch._C._cuda_getCurrentRawStream(dev.index), side.cuda_stream,
+                                      ready.handle if ready is not None and ready.used else 0)
+            self._pending[key] = (job, ei, ready)   # (the event outlives the worker's wait for it)
             return
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(dev))   # edge_index is complete after this point
@@ -323,6 +328,46 @@ def get_plan(edge_index: torch.Tensor, num_nodes: int, normalize: bool) -> Graph
     return PLAN_CACHE.get(edge_index, num_nodes, normalize)
 
 
-def prefetch_plan(edge_index: torch.Tensor, num_nodes: int, normalize: bool = True) -> None:
+def prefetch_plan(edge_index: torch.Tensor, num_nodes: int, normalize: bool = True,
+                  ready: Optional["CompletionEvent"] = None) -> None:
     """Overlap the graph build of the NEXT batch with the current step (see PlanCache)."""
-    PLAN_CACHE.prefetch(edge_index, num_nodes, normalize)
+    PLAN_CACHE.prefetch(edge_index, num_nodes, normalize, ready)
+
+
+class CompletionEvent:
+    """A HIP event that the NEXT adapter forward of this thread records at the completion of its last kernel
+    (``gconv_arm_completion_event``, ``include/gconv_adapter.h``): on the fused tile path it rides on the kernel's own
+    completion signal, so nothing is queued between the forward pass and the backward pass — an event recorded
+    behind the forward is a barrier packet in front of the first backward kernel (6.5 us of idle GPU per step of a
+    whole 4096-molecule batch, ``tools/lab/r05_timeline.sh``). Use::
+
+        ev = CompletionEvent()
+        ...
+        ev.arm()                      # in front of the forward pass's LAST adapter call
+        h = adapter(h, edge_index)
+        prefetch_plan(next_edge_index, n, normalize, ready=ev)   # the build runs beside the backward pass
+
+    Needs the native binding (``_torch_ext``); without it ``arm`` does nothing and ``prefetch_plan`` records its own
+    event as before. One event serves every step (re-armed, re-recorded)."""
+
+    def __init__(self):
+        from . import _torch_ext
+        self._ext = _torch_ext.get()
+        self.handle = self._ext.event_create() if self._ext is not None else 0
+        self.used = False
+
+    def arm(self) -> None:
+        if self._ext is not None:
+            self._ext.arm_completion_event(self.handle)
+            self.used = True
+
+    def done(self) -> bool:
+        return self._ext is None or not self.used or bool(self._ext.event_query(self.handle))
+
+    def __del__(self):
+        if getattr(self, "_ext", None) is not None and self.handle:
+            try:
+                self._ext.event_destroy(self.handle)
+            except Exception:
+                pass
+            self.handle = 0

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GCONV_ABI_VERSION 10
+#define GCONV_ABI_VERSION 11
 
 typedef int32_t gconv_status_t;
 typedef void*   gconv_stream_t; /* hipStream_t */
@@ -315,6 +315,16 @@ gconv_status_t gconv_adapter_infer_f32(const gconv_graph_t* graph,
                                        const gconv_adapter_params_t* params, const float* x,
                                        float* out, void* workspace, size_t workspace_bytes,
                                        gconv_stream_t stream);
+
+/* Arms `event` (a hipEvent_t; NULL disarms) for the calling thread: the NEXT gconv_adapter_fwd_f32 /
+ * gconv_adapter_infer_f32 call of this thread records it at the completion of its last kernel and disarms it
+ * (also when that call fails: the event is then not recorded). On the fused tile path the event rides on the
+ * kernel's own completion signal (hipExtLaunchKernel's stop event): no packet is queued between this call and
+ * the stream's next kernel, where a hipEventRecord behind the call costs the step of a whole 4096-molecule
+ * batch 6.5 us of idle GPU in front of the backward pass. Use: the side stream that builds the NEXT batches'
+ * graph plans (the reference's DataLoader workers, `scripts/finetune_inductive_learning.py:246-258,291-293`)
+ * waits for the forward pass's last adapter this way and runs beside the backward pass.  (ABI 11)            */
+gconv_status_t gconv_arm_completion_event(void* event);
 
 /* replaces: the autograd backward of the same ops, entered from
  * `loss.backward()` (`scripts/finetune_inductive_learning.py:66`,

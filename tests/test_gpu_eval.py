@@ -173,3 +173,48 @@ def test_tile_walk_order_does_not_change_the_outputs(dev):
     with torch.no_grad():
         mod(b.x.to(dev), ei); mod(b.x.to(dev), ei)
     assert plan._walk == w0 and plan.next_walk() == w0 and plan.next_walk() == w0 ^ 1
+
+
+@pytest.mark.parametrize("kind", ["tile", "general"])
+def test_completion_event_of_a_forward_orders_a_prefetched_build(dev, kind):
+    """Round 5 (ABI 11): `gconv_arm_completion_event` — the next forward of the thread records the event at the
+    completion of its last kernel (tile path: the kernel's own completion signal; general path: a record behind
+    the last launch), and `prefetch_plan(..., ready=event)` makes the build's side stream wait for it without
+    queueing anything on the caller's stream. The plan built that way equals the foreground plan."""
+    if ga._torch_ext.get() is None:
+        pytest.skip("needs the native binding")
+    if kind == "tile":
+        b = ga.synth.molecule_batch("hiv", 600, hidden=300, seed=3); d, r = 300, 8
+        nxt = ga.synth.molecule_batch("hiv", 500, hidden=8, seed=4)
+    else:
+        b = ga.synth.arxiv_like(20_000, 80_000, hidden=64, seed=1); d, r = 64, 16
+        nxt = ga.synth.arxiv_like(9_000, 30_000, hidden=8, seed=2)
+    mod = ga.GConvAdapter(d, r, learnable_scalar=True).to(dev)
+    x, ei = b.x.to(dev), b.edge_index.to(dev)
+    nei = nxt.edge_index.to(dev)
+    plan = ga.get_plan(ei, b.num_nodes, True)
+    assert (plan.n_tiles > 0) == (kind == "tile" and not os.environ.get("GCONV_NO_TILE_PATH"))
+    torch.cuda.synchronize()
+    ev = ga.CompletionEvent()
+    assert ev.done()                       # never armed: nothing to wait for
+    want = mod(x, ei)
+    for _ in range(3):                     # re-armed and re-recorded, as a training loop does
+        ev.arm()
+        out = mod(x, ei)
+        ga.prefetch_plan(nei, nxt.num_nodes, True, ready=ev)
+        out.square().mean().backward()
+        got = ga.get_plan(nei, nxt.num_nodes, True)
+        ref = ga.GraphPlan(nei, nxt.num_nodes, True)
+        assert torch.equal(out, want)
+        assert got.n_tiles == ref.n_tiles and got.fwd.nnz == ref.fwd.nnz
+        h = torch.randn(nxt.num_nodes, 8, generator=torch.Generator().manual_seed(1)).to(dev)
+        assert torch.equal(ga.spmm(got, h), ga.spmm(ref, h))
+        ga.PLAN_CACHE.discard(nei, nxt.num_nodes, True)
+    torch.cuda.synchronize()
+    assert ev.done()
+    ev.arm()                               # armed, then a call that is rejected: the next good call still works
+    with pytest.raises(RuntimeError):
+        mod(x[:-1], ei)
+    y = mod(x, ei)
+    torch.cuda.synchronize()
+    assert torch.equal(y, want) and ev.done()

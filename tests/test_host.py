@@ -139,7 +139,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_library_host_only_entry_points():
     lib = ga._lib.load()
-    assert lib.gconv_abi_version() == 10
+    assert lib.gconv_abi_version() == 11
     assert [lib.gconv_padded_rank(r) for r in (0, 1, 4, 5, 8, 16, 17, 33, 64, 65)] == \
         [0, 4, 4, 8, 8, 16, 32, 64, 64, 0]
     assert b"workspace" in lib.gconv_status_string(-3)

@@ -12,7 +12,9 @@ shard = None
 if os.environ.get("GCONV_LAB_SHARD"):   # "0/2": rank 0's share of the batch cut over 2 ranks (a point of the strong-scaling curve)
     r, w = os.environ["GCONV_LAB_SHARD"].split("/")
     shard = (int(r), int(w))
-stream = bench.BatchStream(name, 0, dev, k=4, fresh=not os.environ.get("GCONV_LAB_STATIC"), shard=shard)   # STATIC: one cached plan
+# STATIC: one batch, its plan cached; STATIC + ROTATE: four batches in turn, their four plans cached (no build, the step's data rotate)
+stream = bench.BatchStream(name, 0, dev, k=4, fresh=not os.environ.get("GCONV_LAB_STATIC"), shard=shard,
+                           rotate=bool(os.environ.get("GCONV_LAB_ROTATE")))
 mods = list(bench.build_adapters(stream.cfg, True, dev))
 params = [p for m in mods for p in m.parameters()]
 bench.pin_host_threads()
