@@ -662,6 +662,9 @@ __device__ __forceinline__ void stc(int32_t* p, int v) {
 #ifndef GCONV_COUNT_STAMPS
 #define GCONV_COUNT_STAMPS 0
 #endif
+#ifndef GCONV_COUNT_SPLIT_COH   // (lab: 1 = the split launches with the one-launch kernel's device-scope accesses)
+#define GCONV_COUNT_SPLIT_COH 0
+#endif
 #ifndef GCONV_COUNT_TILES_CACHED
 #define GCONV_COUNT_TILES_CACHED 1
 #endif
@@ -716,7 +719,11 @@ __device__ __forceinline__ bool grid_sync(int32_t* state, uint32_t& gen, int* ok
   return *ok_s != 0;
 }
 
-template <int GRID>
+// COH: data that one workgroup writes and another reads travels INSIDE the launch (phases separated by grid barriers):
+// device-scope accesses. !COH: a launch per phase (the split builder of background builds) — what a phase reads was
+// written by an earlier LAUNCH, so plain cached accesses do: the per-edge symmetry test of phase B then finds a row's
+// 64-byte ELL line and degree in L1 / L2 instead of fetching both across the fabric for every edge.
+template <int GRID, bool COH = true>
 __global__ __launch_bounds__(kCountThreads) void counting_build_kernel(CountArgs a) {
   static_assert(GRID % 64 == 0 && GRID % kCountGroups == 0 && GRID <= kCountGrid, "chunk totals: GRID / 64 per lane");
   __shared__ int ok_s, last_s;
@@ -785,21 +792,23 @@ __global__ __launch_bounds__(kCountThreads) void counting_build_kernel(CountArgs
   const int r0 = min(wg * chunk + tid * per, n);
   const int r1 = min(min(r0 + per, (wg + 1) * chunk), n);
   const rsrc_t ell_r = make_rsrc(a.ell, static_cast<uint32_t>(n) * kEllWidth * 4u);
+  auto ldv = [](const int32_t* p) -> int { if constexpr (COH) return ldc(p); else return *p; };
+  auto stv = [](int32_t* p, int v) { if constexpr (COH) stc(p, v); else *p = v; };
   auto ell_row = [&](int row, i32x4 (&v)[kEllWidth / 4]) {
 #pragma unroll
     for (int q = 0; q < kEllWidth / 4; ++q)
-      v[q] = __builtin_amdgcn_raw_buffer_load_b128(ell_r, (row * kEllWidth + 4 * q) * 4, 0, kAuxDeviceScope);
+      v[q] = __builtin_amdgcn_raw_buffer_load_b128(ell_r, (row * kEllWidth + 4 * q) * 4, 0, COH ? kAuxDeviceScope : 0);
   };
   if (run_b) {
     // every load of the phase that does not depend on the scan is issued here, in one batch: the chunk
     // totals, the degrees and the slots of the thread's first row, and both ELL rows of its first edge
-    const bool bad = ldc(info + INFO_BAD) != 0;                   // grid-uniform: the host refuses the list
+    const bool bad = ldv(info + INFO_BAD) != 0;                   // grid-uniform: the host refuses the list
     int cc[GRID / 64];
 #pragma unroll
-    for (int k = 0; k < GRID / 64; ++k) cc[k] = ldc(chunk_cnt + k * 64 + lane);
+    for (int k = 0; k < GRID / 64; ++k) cc[k] = ldv(chunk_cnt + k * 64 + lane);
     i32x4 row0[kEllWidth / 4], rd[kEllWidth / 4], rs[kEllWidth / 4];
     ell_row(min(r0, n - 1), row0);
-    const int dd0 = ldc(deg + d0), ds0 = ldc(deg + s0);
+    const int dd0 = ldv(deg + d0), ds0 = ldv(deg + s0);
     ell_row(d0, rd);
     ell_row(s0, rs);
     int below = 0, all = 0;                            // GRID chunk totals: GRID / 64 per lane
@@ -812,7 +821,7 @@ __global__ __launch_bounds__(kCountThreads) void counting_build_kernel(CountArgs
     all = wave_sum_i(all);
     int mysum = 0, mymax = 0;
     for (int i = r0; i < r1; ++i) {
-      const int v = ldc(deg + i);
+      const int v = ldv(deg + i);
       mysum += v;
       mymax = max(mymax, v);
     }
@@ -832,9 +841,9 @@ __global__ __launch_bounds__(kCountThreads) void counting_build_kernel(CountArgs
       if (w < wave) wbase += wred[w];
     int run = below + wbase + incl - mysum;
     for (int i = r0; i < r1; ++i) {
-      const int dg = ldc(deg + i);
-      stc(a.rowptr + i, run);
-      if (a.dis) stc(reinterpret_cast<int32_t*>(a.dis) + i, __float_as_int(1.0f / sqrtf(static_cast<float>(dg + 1))));
+      const int dg = ldv(deg + i);
+      stv(a.rowptr + i, run);
+      if (a.dis) stv(reinterpret_cast<int32_t*>(a.dis) + i, __float_as_int(1.0f / sqrtf(static_cast<float>(dg + 1))));
       if (i > r0) ell_row(i, row0);
       if (!bad && dg <= kEllWidth && dg > 0) {         // the row's slots, ranked in registers -> ascending
 #pragma unroll
@@ -847,14 +856,14 @@ __global__ __launch_bounds__(kCountThreads) void counting_build_kernel(CountArgs
               const int vk = row0[k / 4][k % 4];
               rank += (k < dg) && (vk < vj || (vk == vj && k < j));
             }
-            stc(a.col + run + rank, vj);
+            stv(a.col + run + rank, vj);
           }
         }
       }
       run += dg;
     }
     if (wg == 0 && tid == 0) {
-      stc(a.rowptr + n, all);
+      stv(a.rowptr + n, all);
       atomicExch(&info[a.fwd + 0], all);               // nnz; no long rows on this path (n_long = n_seg = 0)
     }
     if (!bad) {   // symmetry, a thread per edge, on the ELL rows (complete since the barrier)
@@ -879,7 +888,7 @@ __global__ __launch_bounds__(kCountThreads) void counting_build_kernel(CountArgs
       if (count_near && gtid < E) near_cnt += near(s0, d0);
       for (int64_t e = gtid + gsize; e < E; e += gsize) {
         const int s = static_cast<int>(a.ei[e]), d = static_cast<int>(a.ei[E + e]);
-        const int dd = ldc(deg + d), ds = ldc(deg + s);
+        const int dd = ldv(deg + d), ds = ldv(deg + s);
         ell_row(d, rd);
         ell_row(s, rs);
         test(s, d, dd, ds);
@@ -1269,8 +1278,8 @@ extern "C" gconv_status_t gconv_graph_build_ex(const int64_t* edge_index, int64_
     if (cp.split) {          // a launch per phase: nothing waits inside a kernel
       for (int ph = 1; ph <= 4; ph <<= 1) {
         a.phases = ph;
-        if (cp.grid == kCountGrid) counting_build_kernel<kCountGrid><<<kCountGrid, kCountThreads, 0, stream>>>(a);
-        else counting_build_kernel<kCountGridNarrow><<<kCountGridNarrow, kCountThreads, 0, stream>>>(a);
+        if (cp.grid == kCountGrid) counting_build_kernel<kCountGrid, GCONV_COUNT_SPLIT_COH != 0><<<kCountGrid, kCountThreads, 0, stream>>>(a);
+        else counting_build_kernel<kCountGridNarrow, GCONV_COUNT_SPLIT_COH != 0><<<kCountGridNarrow, kCountThreads, 0, stream>>>(a);
       }
     } else {
       a.phases = 7;
