@@ -749,6 +749,9 @@ __global__ __launch_bounds__(kCountThreads) void counting_build_kernel(CountArgs
 #define GCONV_STAMP(k) do { } while (0)
 #endif
 
+  auto ldv = [](const int32_t* p) -> int { if constexpr (COH) return ldc(p); else return *p; };
+  auto stv = [](int32_t* p, int v) { if constexpr (COH) stc(p, v); else *p = v; };
+
   // ---- A: gather ----
   GCONV_STAMP(0);
   int s0 = 0, d0 = 0;                                  // the thread's first edge, kept for phase B (0, 0: none / invalid)
@@ -768,7 +771,7 @@ __global__ __launch_bounds__(kCountThreads) void counting_build_kernel(CountArgs
         if (e == gtid) { s0 = static_cast<int>(s); d0 = di; }
         if (!(a.normalize && s == d)) {
           const int p = atomicAdd(&deg[di], 1);
-          if (p < kEllWidth) stc(a.ell + static_cast<size_t>(di) * kEllWidth + p, static_cast<int32_t>(s));
+          if (p < kEllWidth) stv(a.ell + static_cast<size_t>(di) * kEllWidth + p, static_cast<int32_t>(s));
           ck = di / chunk;
         }
       }
@@ -792,8 +795,6 @@ __global__ __launch_bounds__(kCountThreads) void counting_build_kernel(CountArgs
   const int r0 = min(wg * chunk + tid * per, n);
   const int r1 = min(min(r0 + per, (wg + 1) * chunk), n);
   const rsrc_t ell_r = make_rsrc(a.ell, static_cast<uint32_t>(n) * kEllWidth * 4u);
-  auto ldv = [](const int32_t* p) -> int { if constexpr (COH) return ldc(p); else return *p; };
-  auto stv = [](int32_t* p, int v) { if constexpr (COH) stc(p, v); else *p = v; };
   auto ell_row = [&](int row, i32x4 (&v)[kEllWidth / 4]) {
 #pragma unroll
     for (int q = 0; q < kEllWidth / 4; ++q)
