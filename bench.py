@@ -936,13 +936,20 @@ def run_workload(name: str, normalize: bool, steps: int, warmup: int, rank: int,
     def step():
         graphs[0] += adapter_step(mods, params, stream, normalize, bucket)
 
-    settled = settle(step, device, world)
-    graphs[0] = 0
-    cfs0 = ga.dist.cpu_throttle_stats()
-    dt = timed_steps(step, steps, warmup, world, device)
-    for _ in range(reps - 1):   # (extras only: a 15 ms window of a host-bound step is one scheduler hiccup long)
-        dt = min(dt, timed_steps(step, steps, 0, world, device))
-    cfs1 = ga.dist.cpu_throttle_stats()
+    # Host-bound batches (the reference's 32-molecule ESOL batches: 0.12 ms of kernels per step, 0.16 of host work): the
+    # autograd nodes run on the calling thread — no hand-off to the engine's device thread and back per backward()
+    # (tools/stepprof.py esol fresh [st]: backward 83 -> 75 us of host time, step 163 -> 153 us). A training script
+    # does the same with one line. GCONV_BENCH_AUTOGRAD_THREADS=1 keeps the engine's threads (A/B).
+    host_bound = (not by_rows and isinstance(stream, BatchStream) and not stream.prefetch_beside_backward and world == 1
+                  and not os.environ.get("GCONV_BENCH_AUTOGRAD_THREADS"))
+    with torch.autograd.set_multithreading_enabled(not host_bound):
+        settled = settle(step, device, world)
+        graphs[0] = 0
+        cfs0 = ga.dist.cpu_throttle_stats()
+        dt = timed_steps(step, steps, warmup, world, device)
+        for _ in range(reps - 1):   # (extras only: a 15 ms window of a host-bound step is one scheduler hiccup long)
+            dt = min(dt, timed_steps(step, steps, 0, world, device))
+        cfs1 = ga.dist.cpu_throttle_stats()
     if world > 1:   # what a bad scaling point needs to be read: was the container throttled inside the timed region?
         LAST_DIAG["cfs_throttle_delta_over_timed_region"] = {k: cfs1[k] - cfs0[k] for k in cfs0}
         if bucket is not None:

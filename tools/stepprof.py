@@ -1,5 +1,5 @@
 """Host-side phases of the bench step (fresh plan per step, prefetch thread), per workload:
-    python tools/stepprof.py [esol|hiv] [fresh|cached] [heat] [nopin]"""
+    python tools/stepprof.py [esol|hiv] [fresh|cached] [heat] [nopin] [st]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,6 +16,8 @@ pinned = [] if "nopin" in sys.argv else ga.dist.pin_to_local_cores()   # as benc
 cfg = stream.cfg
 mods = [ga.GConvAdapter(cfg["d"], cfg["r"], learnable_scalar=True).to(dev) for _ in range(cfg["adapters"])]
 params = [p for m in mods for p in m.parameters()]
+if "st" in sys.argv:     # autograd nodes on the calling thread (no hand-off to the device thread)
+    torch.autograd.set_multithreading_enabled(False)
 N = 300
 acc = [0.0] * 6
 for it in range(N + 30):
