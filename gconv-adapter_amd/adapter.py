@@ -23,7 +23,7 @@ import torch.nn as nn
 
 from . import _lib, _torch_ext
 from .functional import GConvAdapterFunction, LayerNormScaleFunction, _stream, adapter_infer
-from .graph import get_plan
+from .graph import get_plan, replicated_edge_index
 from .norm import BatchNorm1d
 
 #: default of ``GConvAdapter.direct_param_grads`` (env GCONV_AUTOGRAD_PARAM_GRADS=1 turns it off)
@@ -260,10 +260,16 @@ class GConvAdapter(nn.Module):
             # B = 1 (what the reference passes, nodeformer.py:391): a VIEW both ways — x[0] would put
             # a SelectBackward node behind the adapter (a zero-filled [1, N, d] tensor plus a copy per
             # backward pass)
-            out = torch.stack([self._forward_2d(x[b], edge_index, fuse_scalar)
-                               for b in range(x.size(0))]) if x.size(0) != 1 else \
-                self._forward_2d(x.view(x.size(1), x.size(2)) if x.is_contiguous() else x[0],
-                                 edge_index, fuse_scalar).unsqueeze(0)
+            # B > 1: ONE call over B disjoint copies of the graph (a reshape of x, no loop over the entries)
+            b, n = x.size(0), x.size(1)
+            if b == 1:
+                out = self._forward_2d(x.view(n, x.size(2)) if x.is_contiguous() else x[0],
+                                       edge_index, fuse_scalar).unsqueeze(0)
+            elif b == 0 or b * n >= 2 ** 31:
+                raise RuntimeError(f"x of shape {tuple(x.shape)}: B * N must be in [1, 2^31)")
+            else:
+                out = self._forward_2d(x.reshape(b * n, x.size(2)), replicated_edge_index(edge_index, n, b),
+                                       fuse_scalar).view(b, n, x.size(2))
 
         if isinstance(self.normalization, nn.BatchNorm1d):
             if out.size(0) > 1:  # reference :99 (always skipped for [1, N, d])

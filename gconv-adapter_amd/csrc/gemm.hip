@@ -34,6 +34,20 @@ namespace gconv {
 // the current block has fed its MFMAs, the same register is re-loaded with k-step q of the
 // wave's NEXT block, so NQ loads stay in flight per wave under straight-line code (no
 // branch between a load and its use: hipcc can then emit counted vmcnt waits).
+// Lab variants of the K1 / B1 memory schedule (tools/lab/r05_k1.sh; 0 = product): bit 0 ring refills issued in
+// pairs (both halves of a 128-byte line back to back), bit 1 non-temporal X loads, bit 2 non-temporal `out` stores,
+// bit 3 no `out` stores at all (a bound; wrong results)
+#ifndef GCONV_LAB_ROWSA
+#define GCONV_LAB_ROWSA 0
+#endif
+__device__ __forceinline__ f32x4 rowsA_ldg4(const float* p) {
+#if GCONV_LAB_ROWSA & 2
+  return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+#else
+  return ldg4(p);
+#endif
+}
+
 template <int NCB, int NQ, int DEPTH>
 __global__ __launch_bounds__(256) void gemm_rowsA_kernel(RowsAArgs a) {
   extern __shared__ f32x4 wl[];  // [NQ][NCB][64] weight fragments
@@ -107,7 +121,7 @@ __global__ __launch_bounds__(256) void gemm_rowsA_kernel(RowsAArgs a) {
     load_epi(b0, rs[dd], pv[dd]);
     const float* xb = a.X + static_cast<size_t>(min(b0 * 16 + node, a.n - 1)) * a.d;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) x[dd][q] = ldg4(xb + koff[q]);
+    for (int q = 0; q < NQ; ++q) x[dd][q] = rowsA_ldg4(xb + koff[q]);
   }
   while (blk < nblk) {
 #pragma unroll
@@ -133,7 +147,16 @@ __global__ __launch_bounds__(256) void gemm_rowsA_kernel(RowsAArgs a) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const f32x4 xv = kok[q] ? x[dd][q] : zero;
-        x[dd][q] = ldg4(xn + koff[q]);  // ring: refill this slot ...
+#if GCONV_LAB_ROWSA & 1
+        if (q & 1) {
+          x[dd][q - 1] = rowsA_ldg4(xn + koff[q - 1]);
+          x[dd][q] = rowsA_ldg4(xn + koff[q]);
+        } else if (q == NQ - 1) {
+          x[dd][q] = rowsA_ldg4(xn + koff[q]);
+        }
+#else
+        x[dd][q] = rowsA_ldg4(xn + koff[q]);  // ring: refill this slot ...
+#endif
         if (q + 1 < NQ) {
 #pragma unroll
           for (int cb = 0; cb < NCB; ++cb) wq[(q + 1) & 1][cb] = wl[((q + 1) * NCB + cb) * 64 + lane];
@@ -161,7 +184,14 @@ __global__ __launch_bounds__(256) void gemm_rowsA_kernel(RowsAArgs a) {
             float v = res[m];
             ds_acc += v * (has_p ? pv[dd][cb][m] : 0.f);
             if (a.mode == ROWSA_DP) v *= sval;
+#if GCONV_LAB_ROWSA & 8
+            if (v == 123.456f)
+#endif
+#if GCONV_LAB_ROWSA & 4
+            __builtin_nontemporal_store(v * (has_rs ? rs[dd][m] : 1.f), &a.out[static_cast<size_t>(row) * a.fp + c]);
+#else
             a.out[static_cast<size_t>(row) * a.fp + c] = v * (has_rs ? rs[dd][m] : 1.f);
+#endif
           }
         }
       }
@@ -204,6 +234,8 @@ int rowsA_grid(int n, int d, int fp) {
   static const int wgpc = std::getenv("GCONV_ROWSA_WGPC") ? std::atoi(std::getenv("GCONV_ROWSA_WGPC")) : 2;
   // (a weight table above 80 KB of LDS leaves room for one workgroup per CU)
   const int per_cu = rowsA_lds_bytes(d, fp) > 80 * 1024 ? 1 : wgpc;
+  static const int lab_grid = std::getenv("GCONV_LAB_ROWSA_GRID") ? std::atoi(std::getenv("GCONV_LAB_ROWSA_GRID")) : 0;
+  if (lab_grid > 0 && lab_grid <= 2048) return g < lab_grid ? g : lab_grid;   // (lab: any grid; ds partial buffers hold 2048)
   return g < 1 ? 1 : (g > per_cu * launch_cus() ? per_cu * launch_cus() : g);   // measured best at S-arxiv: 2 (27 us) vs 3-6 (28-29 us)
 }
 

@@ -328,6 +328,37 @@ def get_plan(edge_index: torch.Tensor, num_nodes: int, normalize: bool) -> Graph
     return PLAN_CACHE.get(edge_index, num_nodes, normalize)
 
 
+#: (edge_index key, copies) -> (edge_index, its block-diagonal repetition); the repetition must keep ONE identity
+#: per source list, or every forward of a [B, N, d] input would miss the plan cache
+_REPLICAS: "OrderedDict[tuple, Tuple[torch.Tensor, torch.Tensor]]" = OrderedDict()
+
+
+def replicated_edge_index(edge_index: torch.Tensor, num_nodes: int, copies: int) -> torch.Tensor:
+    """``edge_index`` of ``copies`` disjoint copies of the graph (copy b shifted by ``b * num_nodes``), cached per
+    source list. ``[B, N, d]`` inputs with B > 1 (PyG's ``node_dim = -2``: every batch entry is propagated over the
+    same graph, /root/reference/src/finetune/gconv_adapter.py:82-92) run as ONE call over the block-diagonal graph of
+    ``B * N`` nodes instead of B calls: a copy's rows only reference that copy's rows, so the result per entry is the
+    2-D result."""
+    key = PlanCache._key(edge_index, num_nodes, True)[:-1] + (copies,)
+    hit = _REPLICAS.get(key)
+    if hit is not None:
+        _REPLICAS.move_to_end(key)
+        return hit[1]
+    _check_edge_index(edge_index)
+    if edge_index.numel():
+        # an endpoint >= N would land in the NEXT copy instead of failing the graph build: checked here, once per
+        # cached list (one host synchronisation)
+        lo, hi = torch.aminmax(edge_index)
+        if int(lo) < 0 or int(hi) >= num_nodes:
+            raise RuntimeError("gconv_graph_build: edge_index entry outside [0, num_nodes) (GCONV_E_BAD_INDEX)")
+    shift = torch.arange(copies, device=edge_index.device, dtype=edge_index.dtype) * num_nodes
+    rep = (edge_index.unsqueeze(1) + shift.view(1, copies, 1)).reshape(2, -1)   # [2, B, E] -> [2, B * E], copy-major
+    _REPLICAS[key] = (edge_index, rep)
+    while len(_REPLICAS) > 4:
+        _REPLICAS.popitem(last=False)
+    return rep
+
+
 def prefetch_plan(edge_index: torch.Tensor, num_nodes: int, normalize: bool = True,
                   ready: Optional["CompletionEvent"] = None) -> None:
     """Overlap the graph build of the NEXT batch with the current step (see PlanCache)."""

@@ -1179,6 +1179,22 @@ def test_adapter_batched_3d_and_non_contiguous_inputs(dev):
     assert_close(xd.grad.cpu().double(), want["x"], "dx [3, N, d]")
     for k, p in mod.named_parameters():
         assert_close(p.grad.cpu().double(), want[k], f"grad {k}", atol=grad_atol(want[k]))
+    # B > 1 runs as ONE call over B disjoint copies of the graph: per entry the numbers of the 2-D call (1e-5: the
+    # tiles of the repeated graph are cut elsewhere), one plan for all calls with the same list, and an endpoint
+    # outside [0, N) still fails instead of reaching into the next copy
+    eid = batch.edge_index.to(dev)
+    with torch.no_grad():
+        o3 = mod(xd.detach(), eid)
+        misses = ga.graph.PLAN_CACHE.misses
+        o3b = mod(xd.detach(), eid)
+        assert ga.graph.PLAN_CACHE.misses == misses and torch.equal(o3, o3b)
+        for b in range(3):
+            assert_close(o3[b].cpu().double(), mod(xd.detach()[b], eid).cpu().double(), f"entry {b} vs 2-D call")
+        bad = eid.clone()
+        bad[1, 5] = n
+        with pytest.raises(RuntimeError, match="outside"):
+            mod(xd.detach(), bad)
+        assert mod(xd.detach().transpose(0, 1).contiguous().transpose(0, 1), eid).shape == (3, n, d)   # strided [B, N, d]
     # non-contiguous x / edge_index: same numbers as their contiguous copies
     xt = torch.randn(d, n, generator=gen).to(dev).t()                 # [n, d] view with strides (1, n)
     ei_nc = torch.stack([batch.edge_index[0], batch.edge_index[1]], dim=1).to(dev).t()   # [2, E] view of [E, 2]
