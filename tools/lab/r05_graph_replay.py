@@ -1,0 +1,12 @@
+"""configs[3] adapter step, eager against ONE replayed HIP graph (bench.measure_transductive)."""
+import faulthandler, os, sys
+faulthandler.enable()
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import bench
+import gconv_adapter_amd as ga
+dev = torch.device("cuda:0")
+torch.cuda.set_device(0)
+ga._lib.load()
+for n in ("cora", "pubmed"):
+    print(bench.measure_transductive(dev, n), flush=True)
