@@ -674,42 +674,62 @@ def measure_transductive(device, name: str) -> dict:
             q.grad = None
         out.backward(gout, retain_graph=True)
     bwd_ms = best_event_time_ms(bwd, 50)
-    # The transductive loop runs the SAME graph every epoch: with the plan built, forward + backward make no
-    # allocation outside torch's allocator and no host read-back, so the step is captured in ONE HIP graph and
-    # replayed (tests/test_gpu_parity.py::test_adapter_step_is_hip_graph_capturable: same bits) — what a launch-bound
-    # step costs without the host in it.
-    graph_us = None
-    if ga._torch_ext.get() is not None and not os.environ.get("GCONV_BENCH_NO_GRAPH"):
-        out = None   # (no older autograd graph alive: its grad accumulators belong to another stream than the capture's)
-        x = x.detach().clone().requires_grad_(True)
-        leaves = [x] + list(mod.parameters())
-
-        def whole():
-            for q in leaves:
-                q.grad = None
-            mod(x, ei).backward(gout)
-        eager_ms = best_event_time_ms(whole, 50)
-        side = torch.cuda.Stream(device=device)
-        side.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                whole()
-        torch.cuda.current_stream(device).wait_stream(side)
-        for q in leaves:
-            q.grad = None
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            mod(x, ei).backward(gout)
-        graph_us = (round(eager_ms * 1e3, 1), round(best_event_time_ms(graph.replay, 50) * 1e3, 1))
-        del graph
     ga.PLAN_CACHE.clear()
-    if graph_us is not None:
-        extra_graph = {f"{name}_adapter_step_eager_us": graph_us[0], f"{name}_adapter_step_hip_graph_us": graph_us[1]}
-    else:
-        extra_graph = {}
-    return {**extra_graph, f"{name}_spmm_us": round(sp_ms * 1e3, 1),
+    return {f"{name}_spmm_us": round(sp_ms * 1e3, 1),
             f"{name}_spmm_GBs": round(spmm_algorithmic_bytes(n, plan.fwd.nnz, fp) / (sp_ms * 1e-3) / 1e9, 1),
             f"{name}_adapter_fwd_us": round(fwd_ms * 1e3, 1), f"{name}_adapter_bwd_us": round(bwd_ms * 1e3, 1)}
+
+
+def measure_graph_replay(device, name: str) -> dict:
+    """configs[3], the transductive loop: the SAME graph every epoch. With the plan built, forward + backward make no
+    allocation outside torch's allocator and no host read-back, so the step is captured in ONE HIP graph and replayed
+    (tests/test_gpu_parity.py::test_adapter_step_is_hip_graph_capturable: same bits) — what a launch-bound step costs
+    without the host in it. Run in a CHILD process by `graph_replay_child` (a failed capture must not cost the line)."""
+    batch, cfg = ga.synth.make_workload(name)
+    n, d, r = batch.num_nodes, cfg["d"], cfg["r"]
+    ei = batch.edge_index.to(device)
+    ga.get_plan(ei, n, True)
+    mod = build_adapters(dict(d=d, r=r, adapters=1), True, device)[0]
+    x = batch.x.reshape(1, n, d).to(device).requires_grad_(True)
+    gout = torch.randn(1, n, d, device=device)
+    leaves = [x] + list(mod.parameters())
+
+    def whole():
+        for q in leaves:
+            q.grad = None
+        mod(x, ei).backward(gout)
+    eager_ms = best_event_time_ms(whole, 50)
+    side = torch.cuda.Stream(device=device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            whole()
+    torch.cuda.current_stream(device).wait_stream(side)
+    for q in leaves:
+        q.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):   # (no older autograd graph of these leaves is alive here: INTEGRATION.md)
+        mod(x, ei).backward(gout)
+    replay_ms = best_event_time_ms(graph.replay, 50)
+    del graph
+    ga.PLAN_CACHE.clear()
+    return {f"{name}_adapter_step_eager_us": round(eager_ms * 1e3, 1),
+            f"{name}_adapter_step_hip_graph_us": round(replay_ms * 1e3, 1)}
+
+
+def graph_replay_child(timeout_s: float = 180.0) -> dict:
+    """`measure_graph_replay` for Cora and PubMed in a child process (`bench.py --graph-replay`): its last stdout line."""
+    if ga._torch_ext.get() is None or os.environ.get("GCONV_BENCH_NO_GRAPH"):
+        return {}
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--graph-replay"], capture_output=True, text=True,
+                           timeout=timeout_s)
+        if r.returncode == 0 and r.stdout.strip():
+            return json.loads(r.stdout.strip().splitlines()[-1])
+        return {"graph_replay_child": f"failed (rc {r.returncode})"}
+    except (subprocess.TimeoutExpired, OSError, ValueError) as e:
+        return {"graph_replay_child": f"failed ({type(e).__name__})"}
 
 
 def measure_no_prefetch_step(device, normalize: bool, name: str = "esol", steps: int = 200) -> dict:
@@ -1019,6 +1039,8 @@ def main() -> None:
                     help="1 = D^-1/2 (A+I) D^-1/2 (north_star subject); 0 = YAML default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--graph-replay", action="store_true",
+                    help="(child of the default run) configs[3] adapter step, eager vs one replayed HIP graph: one JSON line")
     ap.add_argument("--banded", action="store_true", help="also time the SpMM on a banded 1M-node graph")
     ap.add_argument("--resident", type=int, default=0, metavar="G",
                     help="keep a G-molecule dataset in HBM and draw a fresh random batch every step "
@@ -1032,6 +1054,17 @@ def main() -> None:
                          "of the graph per GPU, 'rows' splits the ONE graph by rows over the GPUs "
                          "(strong scaling; all-gathers of the rank-width operands between the stages)")
     args = ap.parse_args()
+    if args.graph_replay:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device (there is no CPU product path)")
+        torch.cuda.set_device(0)
+        ga._lib.load()
+        pin_host_threads()
+        res = {}
+        for tname in ("cora", "pubmed"):
+            res.update(measure_graph_replay(torch.device("cuda", 0), tname))
+        print(json.dumps(res))
+        return
     global RESIDENT, PARTITION
     RESIDENT = args.resident
     PARTITION = args.partition
@@ -1177,6 +1210,7 @@ def main() -> None:
             extra.update(measure_no_prefetch_step(device, normalize))
             for tname in ("cora", "pubmed"):
                 extra.update(measure_transductive(device, tname))
+            extra.update(graph_replay_child())
             other = "esol" if args.workload != "esol" else "hiv"
             o = run_workload(other, normalize, max(20, min(args.steps, 200) // 2), args.warmup, rank, world,
                              device, with_cpu=not args.no_cpu_baseline, reps=3)

@@ -1,4 +1,4 @@
-"""configs[3] adapter step, eager against ONE replayed HIP graph (bench.measure_transductive)."""
+"""configs[3] adapter step, eager against ONE replayed HIP graph (bench.measure_graph_replay; the default bench run starts it as `bench.py --graph-replay` in a child process)."""
 import faulthandler, os, sys
 faulthandler.enable()
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -9,4 +9,4 @@ dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
 ga._lib.load()
 for n in ("cora", "pubmed"):
-    print(bench.measure_transductive(dev, n), flush=True)
+    print(bench.measure_graph_replay(dev, n), flush=True)
