@@ -41,6 +41,9 @@ The JSON line also carries
                 roofline subject), timed live with HIP events on the launch stream
   cpu_baseline  the oracle (PyG op order, fp32, autograd) on the host cores,
                 same workload, bounded sample            (rank 0, N=1 only)
+
+`--graph-replay` (started by the default run as a child process): configs[3]'s adapter step on the static Cora / PubMed
+graphs, eager against ONE replayed HIP graph — one JSON line, merged into `extra`.
 """
 from __future__ import annotations
 
