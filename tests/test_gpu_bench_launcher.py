@@ -41,3 +41,15 @@ def test_more_ranks_than_gpus_is_refused_without_the_rehearsal_switch(dev):
     out = _run(["--gpus", str(n), "--steps", "2", "--no-extra", "--no-cpu-baseline"], {"GCONV_BENCH_BACKEND": ""})
     assert out.returncode != 0 and "GPU(s) visible" in out.stderr
     assert not out.stdout.strip().startswith("{")
+
+
+def test_graph_replay_child_line(dev):
+    """`bench.py --graph-replay` (the child process of the default run): configs[3]'s adapter step eager and as ONE
+    replayed HIP graph, for both graphs, as one JSON line; the replay is not slower than driving the same launches
+    from the host."""
+    out = _run(["--graph-replay"], {}, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    for name in ("cora", "pubmed"):
+        eager, replay = line[f"{name}_adapter_step_eager_us"], line[f"{name}_adapter_step_hip_graph_us"]
+        assert 0 < replay <= eager * 1.05, (name, eager, replay)
