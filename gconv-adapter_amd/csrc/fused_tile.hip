@@ -798,7 +798,11 @@ __global__ __launch_bounds__(512, GCONV_BWD_WAVES) void tile_bwd_kernel(TileBwdA
 #pragma unroll
       for (int n = 0; n < 16; ++n) {
         const int off = voff1 + (16 * blk + n) * rowb;
+#ifdef GCONV_LAB_BWD_NO_GREAD   // lab build (wrong results): what phase 4 costs without its re-read of G
+        gq[n] = 0.f;
+#else
         gq[n] = buf_ld1(rg, off);
+#endif
         xq[n] = buf_ld1(rx, off);
       }
     };
